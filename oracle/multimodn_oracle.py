@@ -1,0 +1,450 @@
+"""CPU ORACLE for the MultiModN sequential-fusion training step.  TEST INFRASTRUCTURE ONLY.
+
+This file is a numpy restatement of the reference algorithm
+(EPFLiGHT/MultiModN, `multimodn/multimodn.py:89-252` train_epoch and the plugin
+modules it drives).  It is the *checker* for the HIP path: only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it.
+Nothing under `multimodn_amd/` imports or calls it; the product path raises when
+the HIP library is missing instead of falling back here.
+
+Pinning: the reference ships no golden vectors or tests for this path
+(SURVEY.md section 4), so the oracle is pinned against outputs of the reference
+itself, imported in the build container with three import shims
+(`tests/golden/make_golden.py`, which also commits the resulting vectors under
+`tests/golden/*.npz`).  `tests/test_oracle_golden.py` re-checks the oracle
+against those vectors on every run.
+
+Arithmetic: the reference computes in fp32 through ATen (third-party: PyTorch,
+pinned `torch==1.13.1` in requirements-cpu.txt; golden vectors were generated
+with torch 2.10.0 whose Linear/relu/sigmoid/log_softmax/nll_loss/Adam semantics
+are unchanged).  Here every op is restated from its published definition in
+numpy at a caller-chosen dtype (float32 to mimic, float64 as truth).
+
+Parameter naming follows the reference `state_dict()` keys:
+    init_state.state_value                 [1, S]        (state.py:25-27)
+    encoders.{e}.layers.{l}.weight / .bias               (mlp_encoder.py:64-72)
+    decoders.{d}.fc.weight / .bias         [2, S] / [2]  (decoders.py:16)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+ACT_IDENTITY, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+_ACT_NAMES = {"identity": ACT_IDENTITY, "relu": ACT_RELU, "sigmoid": ACT_SIGMOID}
+
+
+@dataclass
+class EncoderSpec:
+    """MLPEncoder shape (mlp_encoder.py:51-72).  hidden=() gives SLP/Linear/LogisticEncoder
+    (slp_encoders.py:5-34) whose activation is never applied."""
+    n_features: int
+    hidden: Tuple[int, ...] = ()
+    activation: int = ACT_RELU
+
+    def layer_shapes(self, state_size: int) -> List[Tuple[int, int]]:
+        dims = [self.n_features] + list(self.hidden) + [state_size]
+        shapes = []
+        for i, (din, dout) in enumerate(zip(dims, dims[1:])):
+            if i == len(dims) - 2:          # state concatenated into the LAST layer only
+                shapes.append((dout, din + state_size))
+            else:
+                shapes.append((dout, din))
+        return shapes
+
+
+@dataclass
+class ModelSpec:
+    state_size: int
+    encoders: List[EncoderSpec]
+    n_decoders: int
+    err_penalty: float = 1.0
+    state_change_penalty: float = 0.0       # the *user* value; x0.01 applied here (multimodn.py:86)
+
+    @property
+    def E(self) -> int:
+        return len(self.encoders)
+
+    @property
+    def D(self) -> int:
+        return self.n_decoders
+
+    def param_names(self) -> List[str]:
+        """named_parameters() order: init_state, encoders.*, decoders.* (SURVEY 9.11)."""
+        names = ["init_state.state_value"]
+        for e, enc in enumerate(self.encoders):
+            for l in range(len(enc.hidden) + 1):
+                names += [f"encoders.{e}.layers.{l}.weight", f"encoders.{e}.layers.{l}.bias"]
+        for d in range(self.n_decoders):
+            names += [f"decoders.{d}.fc.weight", f"decoders.{d}.fc.bias"]
+        return names
+
+    def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        S = self.state_size
+        shapes: Dict[str, Tuple[int, ...]] = {"init_state.state_value": (1, S)}
+        for e, enc in enumerate(self.encoders):
+            for l, (o, i) in enumerate(enc.layer_shapes(S)):
+                shapes[f"encoders.{e}.layers.{l}.weight"] = (o, i)
+                shapes[f"encoders.{e}.layers.{l}.bias"] = (o,)
+        for d in range(self.n_decoders):
+            shapes[f"decoders.{d}.fc.weight"] = (2, S)
+            shapes[f"decoders.{d}.fc.bias"] = (2,)
+        return shapes
+
+
+def init_params(spec: ModelSpec, seed: int, dtype=np.float32) -> Dict[str, np.ndarray]:
+    """Synthetic parameters with nn.Linear-like scale (uniform +-1/sqrt(fan_in)) and a randn
+    init state.  NOT the torch RNG stream; parity tests load captured weights instead."""
+    rng = np.random.default_rng(seed)
+    params = {}
+    for name, shape in spec.param_shapes().items():
+        if name == "init_state.state_value":
+            params[name] = rng.standard_normal(shape).astype(dtype)
+        else:
+            fan_in = shape[1] if len(shape) == 2 else None
+            if fan_in is None:   # bias: fan_in of its weight
+                fan_in = spec.param_shapes()[name[:-4] + "weight"][1]
+            bound = 1.0 / np.sqrt(fan_in)
+            params[name] = rng.uniform(-bound, bound, size=shape).astype(dtype)
+    return params
+
+
+def _act(a: np.ndarray, kind: int) -> np.ndarray:
+    if kind == ACT_RELU:
+        return np.maximum(a, 0)
+    if kind == ACT_SIGMOID:
+        return 1.0 / (1.0 + np.exp(-a))
+    return a
+
+
+def _act_grad_from_output(h: np.ndarray, kind: int) -> np.ndarray:
+    """d act / d pre expressed through the activation OUTPUT h."""
+    if kind == ACT_RELU:
+        return (h > 0).astype(h.dtype)
+    if kind == ACT_SIGMOID:
+        return h * (1 - h)
+    return np.ones_like(h)
+
+
+def default_sequence(E: int) -> List[Tuple[int, int]]:
+    """multimodn.py:515-516: (data_idx, enc_idx) = enumerate(range(E))."""
+    return [(i, i) for i in range(E)]
+
+
+def encoder_iterable(E: int, encoder_sequence: Optional[np.ndarray]) -> List[Tuple[int, int]]:
+    """multimodn.py:509-531 without shuffle: all rows of the batch's sequence must agree."""
+    if encoder_sequence is None:
+        return default_sequence(E)
+    seq = np.asarray(encoder_sequence)
+    first = seq[0]
+    if not (seq == first).all():
+        raise ValueError("Encoder sequence has different values across the batch. "
+                         "Hint: set batch size to 1 to avoid this error.")
+    return [(k, int(e)) for k, e in enumerate(first)]
+
+
+@dataclass
+class StepResult:
+    loss: float
+    err_loss: np.ndarray            # [(E+1), D]  (multimodn.py:123,146,181)
+    state_change: np.ndarray        # [E]         (multimodn.py:124,174)
+    n_correct: np.ndarray           # [(E+1), D]  (multimodn.py:147,183)
+    tp: np.ndarray
+    tn: np.ndarray
+    fp: np.ndarray
+    fn: np.ndarray
+    executed: np.ndarray            # [E] bool: encoder ran (no NaN skip) (multimodn.py:168-171)
+    grads: Dict[str, Optional[np.ndarray]] = field(default_factory=dict)
+    states: Dict[int, np.ndarray] = field(default_factory=dict)   # row -> [B,S] (row 0 = init)
+
+
+def forward_backward(params: Dict[str, np.ndarray], spec: ModelSpec,
+                     xs: Sequence[np.ndarray], y: np.ndarray,
+                     encoder_sequence: Optional[np.ndarray] = None,
+                     batch_global: Optional[int] = None,
+                     present_override: Optional[Sequence[bool]] = None,
+                     dtype=np.float32, want_grads: bool = True,
+                     keep_states: bool = False) -> StepResult:
+    """One mini-batch of train_epoch's body (multimodn.py:119-203) with a hand-derived backward.
+
+    xs[k]: [B, F_k] features of data slot k; y: [B, D] int targets in {0,1}.
+    batch_global: divisor used for every batch mean (defaults to B).  A data-parallel shard
+    passes the GLOBAL batch size so that summing shard results reproduces the full batch.
+    present_override[k]: NaN-skip decision per data slot (the reference decides it on the whole
+    batch, multimodn.py:168; a shard must use the global decision).
+    Skipped encoders get grad None (autograd never touches them), everything else an array.
+    """
+    S, E, D = spec.state_size, spec.E, spec.D
+    dt = np.dtype(dtype)
+    P = {k: np.asarray(v, dtype=dt) for k, v in params.items()}
+    xs = [np.asarray(x, dtype=dt) for x in xs]
+    y = np.asarray(y).astype(np.int64)
+    B = y.shape[0]
+    Bg = B if batch_global is None else int(batch_global)
+    alpha = dt.type(spec.err_penalty)
+    beta = dt.type(0.01 * spec.state_change_penalty)       # multimodn.py:86
+    seq = encoder_iterable(E, encoder_sequence)
+    enc_ids = [e for _, e in seq]
+    if len(set(enc_ids)) != len(enc_ids):
+        raise ValueError("repeated encoder ids in encoder_sequence are not supported")
+
+    err_loss = np.zeros((E + 1, D), dt)
+    state_change = np.zeros(E, dt)
+    n_correct = np.zeros((E + 1, D), np.int64)
+    tp = np.zeros((E + 1, D), np.int64); tn = np.zeros_like(tp)
+    fp = np.zeros_like(tp); fn = np.zeros_like(tp)
+    executed = np.zeros(E, bool)
+
+    Wd = [P[f"decoders.{d}.fc.weight"] for d in range(D)]
+    bd = [P[f"decoders.{d}.fc.bias"] for d in range(D)]
+    dz_rows: Dict[int, np.ndarray] = {}
+
+    def decode(row: int, s: np.ndarray):
+        """decoders.py:19-20 + multimodn.py:144-157: sigmoid(Linear), argmax (ties -> 0),
+        CrossEntropyLoss = mean_b(-log_softmax(o)[y]) over the sigmoid OUTPUTS, confusion matrix."""
+        dz = np.zeros((B, D, 2), dt)
+        for d in range(D):
+            z = s @ Wd[d].T + bd[d]
+            o = 1.0 / (1.0 + np.exp(-z))
+            m = o.max(axis=1, keepdims=True)
+            lse = m[:, 0] + np.log(np.exp(o - m).sum(axis=1))
+            t = y[:, d]
+            o_t = o[np.arange(B), t]
+            err_loss[row, d] = (lse - o_t).sum(dtype=dt) / dt.type(Bg)
+            pred = (o[:, 1] > o[:, 0]).astype(np.int64)     # torch.max: first index on ties
+            n_correct[row, d] += int((pred == t).sum())
+            tp[row, d] += int(((pred == 1) & (t == 1)).sum())
+            tn[row, d] += int(((pred == 0) & (t == 0)).sum())
+            fp[row, d] += int(((pred == 1) & (t == 0)).sum())   # cm[true=0][pred=1] (multimodn.py:57)
+            fn[row, d] += int(((pred == 0) & (t == 1)).sum())   # cm[true=1][pred=0] (multimodn.py:58)
+            if want_grads:
+                p = np.exp(o - lse[:, None])
+                g = p.copy()
+                g[np.arange(B), t] -= 1
+                dz[:, d, :] = g * o * (1 - o)
+        dz_rows[row] = dz
+
+    state = np.tile(P["init_state.state_value"], (B, 1))      # state.py:29-32
+    states = {0: state}
+    decode(0, state)
+
+    tape = []    # (enc_idx, s_in_row, hs) for executed encoders, in execution order
+    prev_row = 0
+    for k, e in seq:
+        x = xs[k]
+        if present_override is not None:
+            present = bool(present_override[k])
+        else:
+            present = not np.isnan(x).any()                   # multimodn.py:168
+        if not present:
+            continue
+        executed[e] = True
+        enc = spec.encoders[e]
+        L = len(enc.hidden)
+        hs = [x]
+        h = x
+        for l in range(L):                                    # mlp_encoder.py:75-76
+            h = _act(h @ P[f"encoders.{e}.layers.{l}.weight"].T + P[f"encoders.{e}.layers.{l}.bias"],
+                     enc.activation)
+            hs.append(h)
+        cat = np.concatenate([h, state], axis=1)              # mlp_encoder.py:78 (h first, state last)
+        new_state = cat @ P[f"encoders.{e}.layers.{L}.weight"].T + P[f"encoders.{e}.layers.{L}.bias"]
+        diff = new_state - state
+        state_change[e] = (diff * diff).sum(dtype=dt) / dt.type(Bg * S)   # multimodn.py:174
+        tape.append((e, prev_row, hs))
+        state = new_state
+        states[e + 1] = state
+        prev_row = e + 1
+        decode(e + 1, state)
+
+    global_err = err_loss.sum(dtype=dt) / dt.type(D * (E + 1))            # multimodn.py:194
+    global_sc = state_change.sum(dtype=dt) / dt.type(E)                   # multimodn.py:196
+    loss = global_err * alpha + global_sc * beta                          # multimodn.py:199-202
+
+    res = StepResult(float(loss), err_loss, state_change, n_correct, tp, tn, fp, fn, executed)
+    if keep_states:
+        res.states = states
+    if not want_grads:
+        return res
+
+    grads: Dict[str, Optional[np.ndarray]] = {n: None for n in spec.param_names()}
+    cL = alpha / dt.type(D * (E + 1) * Bg)
+    cS = beta * dt.type(2.0) / dt.type(E * Bg * S)
+    gWd = [np.zeros_like(Wd[d]) for d in range(D)]
+    gbd = [np.zeros_like(bd[d]) for d in range(D)]
+
+    def decoder_back(row: int) -> np.ndarray:
+        dz = dz_rows[row] * cL
+        s = states[row]
+        gs = np.zeros_like(s)
+        for d in range(D):
+            gWd[d] += dz[:, d, :].T @ s
+            gbd[d] += dz[:, d, :].sum(axis=0)
+            gs += dz[:, d, :] @ Wd[d]
+        return gs
+
+    G = np.zeros((B, S), dt)
+    for e, in_row, hs in reversed(tape):
+        enc = spec.encoders[e]
+        L = len(enc.hidden)
+        s_out, s_in = states[e + 1], states[in_row]
+        diff = s_out - s_in
+        G = G + decoder_back(e + 1) + cS * diff
+        Wl = P[f"encoders.{e}.layers.{L}.weight"]
+        HL = hs[-1].shape[1]
+        cat = np.concatenate([hs[-1], s_in], axis=1)
+        grads[f"encoders.{e}.layers.{L}.weight"] = G.T @ cat
+        grads[f"encoders.{e}.layers.{L}.bias"] = G.sum(axis=0)
+        dcat = G @ Wl
+        dh = dcat[:, :HL]
+        carry = dcat[:, HL:] - cS * diff
+        for l in range(L - 1, -1, -1):
+            dpre = dh * _act_grad_from_output(hs[l + 1], enc.activation)
+            grads[f"encoders.{e}.layers.{l}.weight"] = dpre.T @ hs[l]
+            grads[f"encoders.{e}.layers.{l}.bias"] = dpre.sum(axis=0)
+            if l > 0:
+                dh = dpre @ P[f"encoders.{e}.layers.{l}.weight"]
+        G = carry
+    G = G + decoder_back(0)
+    grads["init_state.state_value"] = G.sum(axis=0, keepdims=True)        # grad of tile = sum_b
+    for d in range(D):
+        grads[f"decoders.{d}.fc.weight"] = gWd[d]
+        grads[f"decoders.{d}.fc.bias"] = gbd[d]
+    res.grads = grads
+    return res
+
+
+class Adam:
+    """torch.optim.Adam (lr, betas=(0.9,0.999), eps=1e-8, no weight decay, no amsgrad), the
+    optimiser every reference pipeline builds (titanic_mlp_pipeline.py:74).  Parameters whose
+    grad is None are skipped entirely: no moment decay, no step increment."""
+
+    def __init__(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.state: Dict[str, dict] = {}
+
+    def step(self, params: Dict[str, np.ndarray], grads: Dict[str, Optional[np.ndarray]]) -> None:
+        b1, b2 = self.betas
+        for name, g in grads.items():
+            if g is None:
+                continue
+            p = params[name]
+            dt = p.dtype
+            st = self.state.setdefault(name, {"step": 0, "m": np.zeros_like(p), "v": np.zeros_like(p)})
+            st["step"] += 1
+            t = st["step"]
+            g = g.astype(dt)
+            st["m"] = (st["m"] * dt.type(b1) + g * dt.type(1 - b1)).astype(dt)
+            st["v"] = (st["v"] * dt.type(b2) + (g * g) * dt.type(1 - b2)).astype(dt)
+            bc1 = 1 - b1 ** t
+            bc2_sqrt = (1 - b2 ** t) ** 0.5
+            step_size = self.lr / bc1
+            denom = (np.sqrt(st["v"]) / dt.type(bc2_sqrt) + dt.type(self.eps)).astype(dt)
+            params[name] = (p - dt.type(step_size) * (st["m"] / denom)).astype(dt)
+
+
+@dataclass
+class EpochResult:
+    """The six arrays train_epoch appends to MultiModNHistory (multimodn.py:244-250), with the
+    reference's dtypes: loss/accuracy/state_change float64, sens/spec/bal-acc float32."""
+    loss: np.ndarray
+    accuracy: np.ndarray
+    state_change: np.ndarray
+    sensitivity: np.ndarray
+    specificity: np.ndarray
+    balanced_accuracy: np.ndarray
+    step_losses: List[float]
+
+
+def aggregate_epoch(E: int, D: int, step_results: Sequence[StepResult],
+                    batch_sizes: Sequence[int]) -> EpochResult:
+    """multimodn.py:104-115, 206-212, 222-242 given per-step results."""
+    n_batches = len(step_results)
+    n_samples = np.ones((E + 1, 1))                              # starts at ONE (multimodn.py:105)
+    err = np.zeros((E + 1, D)); sc = np.zeros(E); ncor = np.zeros((E + 1, D))
+    tp = np.zeros((E + 1, D), np.float32); tn = tp.copy(); fp = tp.copy(); fn = tp.copy()
+    for r, bs in zip(step_results, batch_sizes):
+        n_samples[0] += bs
+        for e in range(E):
+            if r.executed[e]:
+                n_samples[e + 1] += bs
+        err += r.err_loss.astype(np.float32)                     # f32 step values summed in f64
+        sc += r.state_change.astype(np.float32)
+        ncor += r.n_correct
+        tp += r.tp.astype(np.float32); tn += r.tn.astype(np.float32)
+        fp += r.fp.astype(np.float32); fn += r.fn.astype(np.float32)
+    err /= n_batches
+    sc /= n_batches
+    acc = ncor / n_samples
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sd = tp + fn
+        sens = np.where(sd == 0, np.float32(0), tp / sd).astype(np.float32)
+        pd_ = tn + fp
+        spec_ = np.where(pd_ == 0, np.float32(0), tn / pd_).astype(np.float32)
+    bal = (sens + spec_) / 2
+    return EpochResult(err, acc, sc, sens, spec_, bal, [r.loss for r in step_results])
+
+
+def train_epoch(params: Dict[str, np.ndarray], spec: ModelSpec, batches, optimizer: Adam,
+                dtype=np.float32) -> EpochResult:
+    """One epoch over `batches` = iterable of (xs, y) or (xs, y, encoder_sequence); updates
+    `params` in place (dict entries replaced)."""
+    results, sizes = [], []
+    for batch in batches:
+        xs, y, seq = (list(batch) + [None])[:3]
+        r = forward_backward(params, spec, xs, y, seq, dtype=dtype)
+        optimizer.step(params, r.grads)
+        results.append(r)
+        sizes.append(np.asarray(y).shape[0])
+    return aggregate_epoch(spec.E, spec.D, results, sizes)
+
+
+def per_sample_step(params, spec: ModelSpec, xs, y, sequences, dtype=np.float32) -> StepResult:
+    """Build-defined extension for per-sample missingness / per-sample encoder order (SURVEY 9.6,
+    BASELINE config 5): the reference only defines this at batch size 1 (multimodn.py:518-523 raises
+    otherwise, :168 skips per batch).  The batch result is the mean over samples of the reference's
+    batch-size-1 result: cells sum_present CE / B, state change sum_present mean_j(ds^2) / B,
+    counters over present samples only; grads are the mean of per-sample grads (None -> 0)."""
+    B = np.asarray(y).shape[0]
+    E, D = spec.E, spec.D
+    acc: Optional[StepResult] = None
+    gsum: Dict[str, np.ndarray] = {}
+    for b in range(B):
+        xb = [np.asarray(x)[b:b + 1] for x in xs]
+        sb = None if sequences is None else np.asarray(sequences)[b:b + 1]
+        r = forward_backward(params, spec, xb, np.asarray(y)[b:b + 1], sb, batch_global=B, dtype=dtype)
+        for n, g in r.grads.items():
+            if g is not None:
+                gsum[n] = g if n not in gsum else gsum[n] + g
+        if acc is None:
+            acc = r
+        else:
+            acc.err_loss = acc.err_loss + r.err_loss
+            acc.state_change = acc.state_change + r.state_change
+            acc.n_correct += r.n_correct; acc.tp += r.tp; acc.tn += r.tn; acc.fp += r.fp; acc.fn += r.fn
+            acc.executed |= r.executed
+            acc.loss += r.loss
+    acc.grads = {n: gsum.get(n) for n in spec.param_names()}
+    return acc
+
+
+def synthetic_batches(spec: ModelSpec, n_rows: int, batch_size: int, seed: int,
+                      learnable: bool = True):
+    """SURVEY 8d generator: standard-normal float32 features, binary int64 targets (either
+    independent coin flips or y_d = 1[x.w_d + 0.5 eps > 0])."""
+    rng = np.random.default_rng(seed)
+    Fs = [e.n_features for e in spec.encoders]
+    X = rng.standard_normal((n_rows, sum(Fs))).astype(np.float32)
+    if learnable:
+        w = rng.standard_normal((sum(Fs), spec.D)).astype(np.float32)
+        y = ((X @ w + 0.5 * rng.standard_normal((n_rows, spec.D)).astype(np.float32)) > 0).astype(np.int64)
+    else:
+        y = rng.integers(0, 2, size=(n_rows, spec.D)).astype(np.int64)
+    offs = np.cumsum([0] + Fs)
+    batches = []
+    for s in range(0, n_rows, batch_size):
+        xs = [X[s:s + batch_size, offs[k]:offs[k + 1]].copy() for k in range(len(Fs))]
+        batches.append((xs, y[s:s + batch_size].copy()))
+    return batches

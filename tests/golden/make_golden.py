@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the train_epoch hot path by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference).  Nothing here travels as reference
+code: the script imports the reference modules, feeds them seeded inputs, and stores only
+inputs + observed outputs as .npz data files next to this script.
+
+The reference does not import as-is; three shims are installed in THIS
+process only, none of which touches the arithmetic of the path:
+  * `torchsummary`  (not installed)            -> stub module with a no-op `summary`
+  * `torchmetrics`  (not installed)            -> stub whose binary ConfusionMatrix returns
+        bincount(target*2+preds).reshape(2,2) = C[true][pred], the documented torchmetrics layout
+        that multimodn.py:53-58 relies on
+  * `torch._utils._accumulate` (removed)       -> itertools.accumulate
+Per-step values are observed through the caller-injected criterion / optimizer objects and by
+wrapping Tensor.backward (instrumentation of the harness, not of the reference).
+
+Usage:  python tests/golden/make_golden.py            (rewrites tests/golden/*.npz and verifies
+                                                       the oracle against every vector)
+"""
+import itertools
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+def install_shims():
+    ts = types.ModuleType("torchsummary")
+    ts.summary = lambda *a, **k: None
+    sys.modules["torchsummary"] = ts
+
+    tm = types.ModuleType("torchmetrics")
+
+    class ConfusionMatrix:
+        def __init__(self, task="binary", num_classes=2, **kw):
+            pass
+
+        def to(self, device):
+            return self
+
+        def __call__(self, preds, target):
+            idx = target.long() * 2 + preds.long()
+            return torch.bincount(idx, minlength=4).reshape(2, 2)
+
+    class _Inert:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return torch.tensor(float("nan"))
+
+    tm.ConfusionMatrix = ConfusionMatrix
+    for n in ("F1Score", "ROC", "PrecisionRecallCurve", "Accuracy", "AUROC"):
+        setattr(tm, n, type(n, (_Inert,), {}))
+    sys.modules["torchmetrics"] = tm
+
+    import torch._utils
+    torch._utils._accumulate = itertools.accumulate
+    sys.path.insert(0, REF)
+
+
+install_shims()
+from multimodn.multimodn import MultiModN                      # noqa: E402  (reference)
+from multimodn.encoders import MLPEncoder                      # noqa: E402
+from multimodn.decoders import LogisticDecoder                 # noqa: E402
+from multimodn.history import MultiModNHistory                 # noqa: E402
+import datasets as _ref_datasets                               # noqa: E402
+assert _ref_datasets.__file__.startswith(REF), "HuggingFace `datasets` shadowed the reference's"
+
+sys.path.insert(0, REPO)
+from oracle import multimodn_oracle as O                       # noqa: E402
+
+ACTS = {"relu": torch.nn.functional.relu, "sigmoid": torch.sigmoid, "identity": (lambda x: x)}
+ACT_ID = {"relu": O.ACT_RELU, "sigmoid": O.ACT_SIGMOID, "identity": O.ACT_IDENTITY}
+
+
+class RecordingCriterion:
+    def __init__(self):
+        self.inner = torch.nn.CrossEntropyLoss()
+        self.calls = []
+
+    def __call__(self, out, tgt):
+        loss = self.inner(out, tgt)
+        self.calls.append(float(loss.detach()))
+        return loss
+
+
+class OptimizerProxy:
+    """Delegates to a real torch.optim.Adam; snapshots grads before and params after step()."""
+
+    def __init__(self, model, lr):
+        self.model = model
+        self.opt = torch.optim.Adam(list(model.parameters()), lr)
+        self.grads, self.params = [], []
+
+    def zero_grad(self):
+        self.opt.zero_grad()
+
+    def step(self):
+        self.grads.append({n: (None if p.grad is None else p.grad.detach().numpy().copy())
+                           for n, p in self.model.named_parameters()})
+        self.opt.step()
+        self.params.append({n: p.detach().numpy().copy() for n, p in self.model.named_parameters()})
+
+
+CONFIGS = {
+    # name: dict(F, H, S, D, B, N, lr, pen, epochs, act, + optional nan / seq)
+    "c1_titanic": dict(F=[6], H=(5, 5), S=32, D=1, B=32, N=100, lr=0.01, pen=(0.7, 0.3), epochs=3,
+                       act="relu", store="all"),
+    "c1_curve20": dict(F=[6], H=(5, 5), S=32, D=1, B=32, N=96, lr=0.01, pen=(0.7, 0.3), epochs=20,
+                       act="relu", store="epochs"),
+    "c2_split": dict(F=[3, 2], H=(5, 5), S=64, D=2, B=64, N=150, lr=0.01, pen=(0.7, 0.3), epochs=2,
+                     act="relu", store="all"),
+    "c3_small": dict(F=[64] * 4, H=(32, 32), S=128, D=3, B=64, N=128, lr=1e-3, pen=(1.0, 0.3),
+                     epochs=1, act="relu", store="first_last"),
+    "nan_skip": dict(F=[4, 3, 5], H=(8,), S=16, D=2, B=16, N=48, lr=0.01, pen=(1.0, 0.5), epochs=2,
+                     act="relu", store="all", nan=[(1, 1, 3, 2)]),   # (batch, slot, row, col)
+    "seq_perm": dict(F=[4, 3, 5, 2], H=(6, 7), S=24, D=2, B=16, N=32, lr=0.01, pen=(1.0, 0.5),
+                     epochs=2, act="relu", store="all", seq=[2, 0, 1, 3]),
+    "slp_sigmoid": dict(F=[5, 7], H=(), S=16, D=1, B=16, N=40, lr=0.01, pen=(0.7, 0.3), epochs=2,
+                        act="sigmoid", store="all"),
+    "mlp_sigmoid": dict(F=[5, 7], H=(9,), S=16, D=2, B=16, N=40, lr=0.01, pen=(0.7, 0.3), epochs=2,
+                        act="sigmoid", store="all"),
+    "mlp_identity": dict(F=[6], H=(4, 4, 4), S=8, D=3, B=8, N=24, lr=0.01, pen=(1.0, 1.0), epochs=2,
+                         act="identity", store="all"),
+}
+
+
+def make_data(cfg, seed):
+    rng = np.random.default_rng(seed)
+    D, N = cfg["D"], cfg["N"]
+    # data slot k feeds encoders[seq[k]] (multimodn.py:162-163), so slot k has THAT encoder's width
+    Fs = [cfg["F"][e] for e in cfg["seq"]] if "seq" in cfg else cfg["F"]
+    X = rng.standard_normal((N, sum(Fs))).astype(np.float32)
+    w = rng.standard_normal((sum(Fs), D)).astype(np.float32)
+    y = ((X @ w + 0.5 * rng.standard_normal((N, D)).astype(np.float32)) > 0).astype(np.int64)
+    offs = np.cumsum([0] + Fs)
+    batches = []
+    for bi, s in enumerate(range(0, N, cfg["B"])):
+        xs = [X[s:s + cfg["B"], offs[k]:offs[k + 1]].copy() for k in range(len(Fs))]
+        for (b, slot, r, c) in cfg.get("nan", []):
+            if b == bi:
+                xs[slot][r, c] = np.nan
+        yb = y[s:s + cfg["B"]].copy()
+        if "seq" in cfg:
+            batches.append((xs, yb, np.tile(np.array(cfg["seq"], np.int64), (len(yb), 1))))
+        else:
+            batches.append((xs, yb))
+    return batches
+
+
+def run_reference(name, cfg, seed=0):
+    torch.manual_seed(seed)
+    torch.set_num_threads(1)
+    S, D = cfg["S"], cfg["D"]
+    encoders = [MLPEncoder(S, f, tuple(cfg["H"]), ACTS[cfg["act"]]) for f in cfg["F"]]
+    decoders = [LogisticDecoder(S) for _ in range(D)]
+    model = MultiModN(S, encoders, decoders, cfg["pen"][0], cfg["pen"][1], device=torch.device("cpu"))
+    init = {n: p.detach().numpy().copy() for n, p in model.named_parameters()}
+    batches_np = make_data(cfg, seed + 1)
+    loader = [tuple([[torch.from_numpy(x) for x in b[0]], torch.from_numpy(b[1])] +
+                    ([torch.from_numpy(b[2])] if len(b) > 2 else [])) for b in batches_np]
+    crit = RecordingCriterion()
+    opt = OptimizerProxy(model, cfg["lr"])
+    hist = MultiModNHistory([f"t{d}" for d in range(D)])
+    losses = []
+    orig_backward = torch.Tensor.backward
+
+    def rec_backward(self, *a, **k):
+        losses.append(float(self.detach()))
+        return orig_backward(self, *a, **k)
+
+    torch.Tensor.backward = rec_backward
+    try:
+        for _ in range(cfg["epochs"]):
+            model.train_epoch(loader, opt, crit, hist)
+    finally:
+        torch.Tensor.backward = orig_backward
+    return dict(init=init, batches=batches_np, crit_calls=crit.calls, grads=opt.grads,
+                params=opt.params, losses=losses, hist=hist)
+
+
+def spec_of(cfg):
+    return O.ModelSpec(cfg["S"], [O.EncoderSpec(f, tuple(cfg["H"]), ACT_ID[cfg["act"]]) for f in cfg["F"]],
+                       cfg["D"], cfg["pen"][0], cfg["pen"][1])
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-12)) if a.size else 0.0
+
+
+def main():
+    worst = {}
+    for name, cfg in CONFIGS.items():
+        ref = run_reference(name, cfg)
+        spec = spec_of(cfg)
+        n_steps = len(ref["losses"])
+        nb = len(ref["batches"])
+        out = {"config_json": np.array(json.dumps({k: v for k, v in cfg.items()})),
+               "torch_version": np.array(torch.__version__), "numpy_version": np.array(np.__version__),
+               "param_names": np.array(spec.param_names()),
+               "step_loss": np.array(ref["losses"], np.float64)}
+        for n, v in ref["init"].items():
+            out[f"init/{n}"] = v
+        for bi, b in enumerate(ref["batches"]):
+            for k, x in enumerate(b[0]):
+                out[f"batch{bi}/x{k}"] = x
+            out[f"batch{bi}/y"] = b[1]
+            if len(b) > 2:
+                out[f"batch{bi}/seq"] = b[2]
+        h = ref["hist"]
+        out["hist/state_change"] = np.stack(h.state_change_loss)
+        out["hist/loss"] = np.stack(h.loss["train"])
+        out["hist/accuracy"] = np.stack(h.accuracy["train"])
+        out["hist/sensitivity"] = np.stack(h.sensitivity["train"])
+        out["hist/specificity"] = np.stack(h.specificity["train"])
+        out["hist/balanced_accuracy"] = np.stack(h.balanced_accuracy["train"])
+        assert h.loss["train"][0].dtype == np.float64 and h.sensitivity["train"][0].dtype == np.float32
+
+        store = cfg["store"]
+        steps_to_store = {"all": range(n_steps), "first_last": [0], "epochs": []}[store]
+        for s in steps_to_store:
+            for n, g in ref["grads"][s].items():
+                if g is not None:
+                    out[f"step{s}/grad/{n}"] = g
+            out[f"step{s}/grad_none"] = np.array([n for n, g in ref["grads"][s].items() if g is None])
+            if store == "all":
+                for n, p in ref["params"][s].items():
+                    out[f"step{s}/param/{n}"] = p
+        for n, p in ref["params"][-1].items():
+            out[f"final/{n}"] = p
+
+        # ---- verify the oracle (fp32 and fp64) against what the reference just produced
+        params = {n: v.copy() for n, v in ref["init"].items()}
+        opt = O.Adam(cfg["lr"])
+        w = dict(loss=0.0, grad=0.0, param=0.0, hist=0.0, crit=0.0)
+        ci = 0
+        ep_results = []
+        for ep in range(cfg["epochs"]):
+            results, sizes = [], []
+            for bi, b in enumerate(ref["batches"]):
+                s = ep * nb + bi
+                xs, y, seq = (list(b) + [None])[:3]
+                r = O.forward_backward(params, spec, xs, y, seq)
+                w["loss"] = max(w["loss"], abs(r.loss - ref["losses"][s]) / abs(ref["losses"][s]))
+                # criterion call order: row 0 decoders, then each executed encoder in sequence order
+                rows = [0] + [e + 1 for _, e in O.encoder_iterable(spec.E, seq) if r.executed[e]]
+                for row in rows:
+                    for d in range(spec.D):
+                        w["crit"] = max(w["crit"], abs(float(r.err_loss[row, d]) - ref["crit_calls"][ci])
+                                        / abs(ref["crit_calls"][ci]))
+                        ci += 1
+                for n, g in ref["grads"][s].items():
+                    assert (g is None) == (r.grads[n] is None), (name, s, n)
+                    if g is not None:
+                        w["grad"] = max(w["grad"], rel(r.grads[n].reshape(g.shape), g))
+                opt.step(params, r.grads)
+                for n, p in ref["params"][s].items():
+                    w["param"] = max(w["param"], rel(params[n], p))
+                results.append(r); sizes.append(len(y))
+            er = O.aggregate_epoch(spec.E, spec.D, results, sizes)
+            ep_results.append(er)
+            w["hist"] = max(w["hist"], rel(er.loss, h.loss["train"][ep]), rel(er.state_change, h.state_change_loss[ep]))
+            assert np.array_equal(er.accuracy, h.accuracy["train"][ep]), name
+            assert np.array_equal(er.sensitivity, h.sensitivity["train"][ep]), name
+            assert np.array_equal(er.specificity, h.specificity["train"][ep]), name
+            assert np.array_equal(er.balanced_accuracy, h.balanced_accuracy["train"][ep]), name
+        assert ci == len(ref["crit_calls"])
+        worst[name] = w
+        print(f"{name:14s} steps={n_steps:3d} oracle-vs-reference rel err: " +
+              " ".join(f"{k}={v:.2e}" for k, v in w.items()))
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    bad = {n: w for n, w in worst.items() if w["loss"] > 2e-6 or w["crit"] > 2e-6}
+    assert not bad, bad
+
+
+if __name__ == "__main__":
+    main()

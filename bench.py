@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- samples/sec of the MultiModN training step on MI355X (BASELINE.json metric).
+
+Workload (N=1): BASELINE.json configs[2], the configuration the metric is quoted on:
+synthetic MIMIC-shaped tabular data, 4 modalities x 64 features, 3 binary tasks, state_dim 128,
+encoder hidden (32, 32) relu, batch 4096 per GPU, Adam lr 1e-3, err_penalty 1, state_change 0.3.
+A "step" = one full training step of one mini-batch whose inputs are already resident in HBM:
+NaN scan + forward chain + backward chain + weight grads + reduction [+ one RCCL all-reduce of
+grads+stats when N>1] + loss/epoch accumulation + torch.optim.Adam(fused) step.
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]
+         N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+import numpy as np
+import torch
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix) = vector peak
+HBM_PEAK_GBS = 8000.0
+
+
+def c3_spec(O):
+    return O.ModelSpec(128, [O.EncoderSpec(64, (32, 32), O.ACT_RELU) for _ in range(4)], 3, 1.0, 0.3)
+
+
+def flops_per_sample(spec):
+    """Algorithmic FLOPs (MAC = 2) per sample of each launch (SURVEY.md section 8d formulas)."""
+    S, E, D = spec.state_size, spec.E, spec.D
+    fwd = bwd = wg = 0
+    for enc in spec.encoders:
+        dims = [enc.n_features] + list(enc.hidden)
+        hidden = sum(a * b for a, b in zip(dims, dims[1:]))
+        last = (dims[-1] + S) * S
+        fwd += hidden + last
+        wg += hidden + last
+        bwd += last + (hidden - dims[0] * dims[1] if len(dims) > 1 else 0)   # no grad flows to x
+    dec = (E + 1) * D * 2 * S
+    return {"k_chain_fwd": 2 * (fwd + dec), "k_chain_bwd": 2 * (bwd + dec), "k_wgrad": 2 * (wg + dec)}
+
+
+def cpu_baseline(O, spec, batch_size, budget_s=15.0):
+    """The numpy oracle (a port of the reference step, oracle/multimodn_oracle.py) timed on the
+    host cores on a bounded sample of the same workload."""
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    params = O.init_params(spec, 0)
+    batches = O.synthetic_batches(spec, batch_size * 2, batch_size, seed=3, learnable=False)
+    opt = O.Adam(1e-3)
+    r = O.forward_backward(params, spec, *batches[0])          # warm-up
+    opt.step(params, r.grads)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        xs, y = batches[n % 2]
+        r = O.forward_backward(params, spec, xs, y)
+        opt.step(params, r.grads)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 200:
+            break
+    return {"value": n * batch_size / el, "unit": "samples/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} training steps of batch {batch_size} (numpy fp32 oracle: fwd+bwd+Adam), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="rows per GPU per step")
+    ap.add_argument("--resident-batches", type=int, default=8)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
+    ap.add_argument("--graph", action="store_true", help="force hipGraph replay also for N>1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import multimodn_amd as mm
+    from helpers import build_torch_model
+    from oracle import multimodn_oracle as O      # cpu_baseline leg + synthetic generator only
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+
+    spec = c3_spec(O)
+    B = args.batch
+    params = O.init_params(spec, 0)                           # same weights on every rank
+    model = build_torch_model(spec, params, dev, mm)
+    model.nan_policy = "device"
+    if world > 1:
+        model.enable_data_parallel()
+    eng = model._get_engine(B)
+    opt = torch.optim.Adam(list(model.parameters()), 1e-3, fused=True, capturable=True)
+
+    # synthetic data resident in HBM (weak scaling: every rank its own B rows per step)
+    host = O.synthetic_batches(spec, B * args.resident_batches, B, seed=100 + rank, learnable=True)
+    resident = []
+    for xs, y in host:
+        resident.append(([torch.from_numpy(x).to(dev) for x in xs], torch.from_numpy(y).to(dev)))
+    pairs = [(i, i) for i in range(spec.E)]
+    batches = [eng.make_batch(xs, y, pairs, batch_global=B * world, device_nan_flags=True) for xs, y in resident]
+    alpha, beta = float(model.err_penalty), float(model.state_change_penalty)
+
+    def step(i):
+        b = batches[i % len(batches)]
+        eng.nan_scan(b)
+        eng.local_step(b, alpha, beta)
+        if world > 1:
+            dist.all_reduce(eng.reduce_buf)                  # ONE collective per step: grads + stats
+        eng.accumulate(alpha, beta)
+        opt.step()
+
+    eng.assign_grads(None)
+    eng.epoch_reset()
+    use_graph = (not args.no_graph) and (world == 1 or args.graph)
+    graphs = None
+    for i in range(3):                                        # eager warm-up (also initialises Adam state)
+        step(i)
+    torch.cuda.synchronize()
+    if use_graph:
+        try:
+            graphs = []
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for i in range(len(batches)):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):
+                        step(i)
+                    graphs.append(g)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+        except Exception as exc:                              # pragma: no cover - depends on the box
+            print(f"[bench] hipGraph capture failed ({exc!r}); running eagerly", file=sys.stderr)
+            graphs = None
+
+    def run(i):
+        if graphs is not None:
+            graphs[i % len(graphs)].replay()
+        else:
+            step(i)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        run(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = B * world * args.steps / elapsed
+
+    # ---- per-kernel durations with HIP events on the launch stream (instrumented eager pass)
+    lib, plan, C = eng.lib, eng._plan, __import__("ctypes")
+    stream = torch.cuda.current_stream().cuda_stream
+    kern = {
+        "k_chain_fwd": lambda b: lib.mmn_chain_fwd(plan, C.byref(b), alpha, beta, 1, stream),
+        "k_chain_bwd": lambda b: lib.mmn_chain_bwd(plan, C.byref(b), beta, stream),
+        "k_wgrad": lambda b: lib.mmn_wgrad(plan, C.byref(b), stream),
+        "k_reduce": lambda b: lib.mmn_reduce(plan, C.byref(b), stream),
+    }
+    n_ev = min(args.steps, 100)
+    durs = {k: [] for k in kern}
+    for i in range(n_ev):
+        b = batches[i % len(batches)]
+        eng.nan_scan(b)
+        for name, fn in kern.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(b)
+            e1.record()
+            assert rc == 0
+            durs[name].append((e0, e1))
+    torch.cuda.synchronize()
+    avg_us = {k: float(np.mean([a.elapsed_time(b_) for a, b_ in v])) * 1e3 for k, v in durs.items()}
+    fl = flops_per_sample(spec)
+    dominant = max(fl, key=lambda k: avg_us[k])
+    achieved = fl[dominant] * B / (avg_us[dominant] * 1e-6) / 1e12
+    roofline = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "avg_launch_us": avg_us, "flops_per_sample": fl,
+                "step_frac_of_fp32_roof": value / world * sum(fl.values()) / (FP32_MFMA_PEAK_TFLOPS * 1e12)}
+
+    out = {
+        "metric": "samples/sec/GPU (MIMIC 4-enc/3-dec, state_dim=128) + CPU-match Δloss",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "MIMIC-shaped tabular: 4 modalities x 64 features, hidden (32,32) relu, 3 binary tasks, "
+                               "state_dim 128, batch 4096 per GPU, Adam(fused) lr 1e-3, penalties 1.0/0.3",
+                   "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
+                   "launch": "hipGraph replay" if graphs is not None else "eager",
+                   "samples_per_sec_per_gpu": value / world},
+        "roofline": roofline,
+    }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(O, spec, B, args.cpu_budget)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,192 @@
+/*
+ * mmn_hip.h -- C ABI of libmmn_hip.so: the MI355X (gfx950) implementation of MultiModN's
+ * sequential-fusion training step.
+ *
+ * The reference (EPFLiGHT/MultiModN) is pure Python on PyTorch and has NO FFI, operator registry
+ * or plugin loader for this path; its boundary is the Python class surface
+ * MultiModN(encoders, decoders, state).train_epoch(...) (multimodn/multimodn.py:66-98).  This
+ * header is therefore the C ABI a maintainer would bind from that method's inner loop body
+ * (multimodn/multimodn.py:119-212); each entry point cites the reference lines it replaces.
+ * The binding the reference side would add is shown in INTEGRATION.md (ctypes, as used by
+ * multimodn_amd/hip.py).
+ *
+ * Conventions
+ *   - plain C, no torch types: device pointers, sizes, a hipStream_t passed as void*.
+ *   - every pointer inside mmn_model / mmn_batch is a DEVICE pointer owned by the caller
+ *     (PyTorch's allocator); the library never allocates device memory: the caller provides one
+ *     workspace of mmn_workspace_bytes() bytes.
+ *   - all launches are asynchronous on `stream`, capture-safe (no sync, no malloc) except
+ *     mmn_plan_create (one synchronous hipMemcpy of descriptor tables) and mmn_epoch_read.
+ *   - return value: 0 = ok, <0 = error (mmn_error_string()).  Nothing throws.
+ *   - arithmetic: fp32 in, fp32 accumulate (v_mfma_f32_16x16x4_f32 = exact fp32 FMA chains);
+ *     int64 targets; deterministic (no float atomics: fixed-order two-stage reductions).
+ */
+#ifndef MMN_HIP_H
+#define MMN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMN_VERSION 100            /* 0.1.0 */
+#define MMN_MAX_ENCODERS 16
+#define MMN_MAX_DECODERS 8
+#define MMN_MAX_LAYERS 8           /* hidden layers + the state-update Linear */
+#define MMN_MAX_DIM 256            /* state_size and every hidden width; n_features is unbounded */
+
+/* activation of MLPEncoder hidden layers (multimodn/encoders/mlp_encoder.py:56,75-76) */
+#define MMN_ACT_IDENTITY 0
+#define MMN_ACT_RELU 1
+#define MMN_ACT_SIGMOID 2
+
+enum {
+    MMN_OK = 0,
+    MMN_ERR_ARG = -1,          /* null pointer / out-of-range size */
+    MMN_ERR_UNSUPPORTED = -2,  /* dims beyond MMN_MAX_* or LDS budget */
+    MMN_ERR_WORKSPACE = -3,    /* workspace too small / misaligned */
+    MMN_ERR_HIP = -4,          /* a HIP runtime call failed (see mmn_last_hip_error) */
+    MMN_ERR_SEQUENCE = -5      /* encoder sequence invalid (repeat / out of range) */
+};
+
+/* One nn.Linear: weight [out_dim, in_dim] row-major, bias [out_dim]; gw/gb receive the grads.
+ * (encoders.{e}.layers.{l}.weight/.bias in the reference state_dict) */
+typedef struct mmn_linear {
+    const float* w;
+    const float* b;
+    float* gw;
+    float* gb;
+    int32_t out_dim;
+    int32_t in_dim;
+} mmn_linear;
+
+/* MLPEncoder (multimodn/encoders/mlp_encoder.py:49-80): n_layers-1 hidden Linear+activation on x
+ * only, then Linear(cat[h, state]) with no activation.  layer[n_layers-1].in_dim = h_dim + S with
+ * the h columns FIRST (mlp_encoder.py:78).  n_layers == 1 is SLP/Linear/LogisticEncoder. */
+typedef struct mmn_encoder {
+    int32_t n_features;
+    int32_t n_layers;
+    int32_t activation;
+    int32_t reserved;
+    mmn_linear layer[MMN_MAX_LAYERS];
+} mmn_encoder;
+
+/* ClassDecoder with sigmoid and n_classes = 2 = LogisticDecoder (decoders.py:9-20,49-53):
+ * fc.weight [2, S], fc.bias [2]. */
+typedef struct mmn_decoder {
+    const float* w;
+    const float* b;
+    float* gw;
+    float* gb;
+} mmn_decoder;
+
+/* MultiModN(state_size, encoders, decoders, ...) with TrainableInitState
+ * (multimodn.py:66-87, state.py:19-32). */
+typedef struct mmn_model {
+    int32_t state_size;
+    int32_t n_encoders;
+    int32_t n_decoders;
+    int32_t reserved;
+    const float* init_state;       /* [S]  (init_state.state_value) */
+    float* g_init_state;           /* [S] */
+    mmn_encoder enc[MMN_MAX_ENCODERS];
+    mmn_decoder dec[MMN_MAX_DECODERS];
+} mmn_model;
+
+/* One mini-batch as train_epoch sees it after collate + .to(device) (multimodn.py:119,132-135):
+ * data slot k -> x[k] [batch, F] fp32 (row stride ldx[k] floats), targets [batch, D] int64.
+ * (seq_data[t], seq_enc[t]) is get_encoder_iterable's t-th pair (multimodn.py:509-531): feed data
+ * slot seq_data[t] to encoder seq_enc[t].  nan_flags (optional, device, one int per DATA SLOT, as
+ * written by mmn_nan_scan): nonzero = that slot's batch contained a NaN, skip its encoder
+ * (multimodn.py:168-169).  NULL = the caller already removed skipped slots from the sequence.
+ * batch_global: divisor of every batch mean; > batch for a data-parallel shard. */
+typedef struct mmn_batch {
+    const float* x[MMN_MAX_ENCODERS];
+    int32_t ldx[MMN_MAX_ENCODERS];
+    const int64_t* y;
+    const int32_t* nan_flags;
+    int32_t batch;
+    int32_t batch_global;
+    int32_t n_seq;
+    int32_t reserved;
+    int32_t seq_data[MMN_MAX_ENCODERS];
+    int32_t seq_enc[MMN_MAX_ENCODERS];
+} mmn_batch;
+
+/* Per-step statistics block, fp32, written by mmn_reduce (local sums, ready for an all-reduce)
+ * and consumed by mmn_epoch_accumulate.  R = n_encoders + 1, D = n_decoders.
+ *   [0, R*D)                 err_loss grid      (multimodn.py:123,146,181)
+ *   [R*D, R*D+E)             state_change       (multimodn.py:124,174)
+ *   then 5 blocks of R*D     n_correct, tp, tn, fp, fn as exact fp32 counts (multimodn.py:147,157)
+ *   then R                   rows executed this step: batch rows if the state row was produced
+ *                            (n_samples_epoch increments, multimodn.py:121,171)
+ *   then 4                   loss, global_err_loss, global_state_change, reserved
+ *                            (multimodn.py:194-202; filled by mmn_epoch_accumulate) */
+size_t mmn_stats_floats(const mmn_model* m);
+
+typedef struct mmn_plan mmn_plan;   /* opaque host handle */
+
+int mmn_version(void);
+const char* mmn_error_string(int code);
+int mmn_last_hip_error(void);
+
+/* Bytes of device workspace needed for batches of up to max_batch rows. */
+size_t mmn_workspace_bytes(const mmn_model* m, int max_batch);
+
+/* Build launch tables for (model, max_batch) inside `workspace` (256-byte aligned device memory).
+ * `stats` = device fp32 block of mmn_stats_floats(); put it right behind the flat gradient buffer
+ * to all-reduce grads + stats in one collective.  Synchronous (descriptor upload). */
+int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t workspace_bytes,
+                    float* stats, mmn_plan** out);
+void mmn_plan_destroy(mmn_plan* p);
+
+/* multimodn.py:168: nan_flags_out[k] = 1 iff any element of data slot k is NaN (k over the slots
+ * named by the sequence).  nan_flags_out: device, MMN_MAX_ENCODERS ints (memset + one launch). */
+int mmn_nan_scan(mmn_plan* p, const mmn_batch* b, int32_t* nan_flags_out, void* stream);
+
+/* Forward chain, one launch: init-state broadcast (state.py:29-32), every executed encoder
+ * (mlp_encoder.py:74-80), state-change partials (multimodn.py:174), all D decoders on all E+1
+ * states with CrossEntropy-over-sigmoids, argmax and confusion counts (decoders.py:19-20,
+ * multimodn.py:141-157,176-191).  want_grads != 0 also stores what backward needs. */
+int mmn_chain_fwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float state_change_penalty_x001,
+                  int want_grads, void* stream);
+
+/* Reverse chain (the activation-gradient half of loss.backward(), multimodn.py:203). */
+int mmn_chain_bwd(mmn_plan* p, const mmn_batch* b, float state_change_penalty_x001, void* stream);
+
+/* Weight/bias/init-state gradients as split-K partial slabs (the other half of :203). */
+int mmn_wgrad(mmn_plan* p, const mmn_batch* b, void* stream);
+
+/* Fixed-order reduction of slabs -> gw/gb/g_init_state and of per-tile partials -> stats. */
+int mmn_reduce(mmn_plan* p, const mmn_batch* b, void* stream);
+
+/* Loss combination (multimodn.py:194-202) and epoch accumulators (multimodn.py:206-212) from
+ * `stats` (call after the all-reduce when data-parallel). */
+int mmn_epoch_accumulate(mmn_plan* p, float err_penalty, float state_change_penalty_x001, void* stream);
+
+/* All five launches above in order: one full multimodn.py:137-203 body (without optimizer.step). */
+int mmn_train_step(mmn_plan* p, const mmn_batch* b, float err_penalty, float state_change_penalty_x001,
+                   int accumulate_epoch, void* stream);
+
+/* Forward-only step for test()/predict() (multimodn.py:255-419): fwd + reduce (+ accumulate). */
+int mmn_eval_step(mmn_plan* p, const mmn_batch* b, int accumulate_epoch, void* stream);
+
+/* Epoch accumulators (device, inside the workspace): reset at epoch start, read at epoch end.
+ * mmn_epoch_read synchronises the stream.  Layout of `out` (doubles): err_sum[R*D], sc_sum[E],
+ * n_correct[R*D], tp[R*D], tn[R*D], fp[R*D], fn[R*D] (the four accumulated in fp32 like the
+ * reference's torch.zeros tensors, multimodn.py:112-115,209-212), rows[R], n_steps[1]. */
+size_t mmn_epoch_doubles(const mmn_model* m);
+int mmn_epoch_reset(mmn_plan* p, void* stream);
+int mmn_epoch_read(mmn_plan* p, double* out_host, void* stream);
+
+/* Debug/parity access to intermediate buffers of the last step (device pointers into the
+ * workspace): kind 0 = state row r [max_batch? no: batch rows x S] (r>=1), 1 = dz row r [B, 2D],
+ * 2 = dS for encoder r [B,S] (r = n_encoders -> dS0). Returns NULL if out of range. */
+const float* mmn_debug_buffer(mmn_plan* p, int kind, int index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMN_HIP_H */

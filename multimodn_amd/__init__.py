@@ -1,0 +1,17 @@
+"""multimodn_amd: MI355X-native implementation of MultiModN's sequential-fusion training hot
+path behind the reference's plugin surface (MultiModN / MultiModEncoder / MultiModDecoder /
+InitState / MultiModDataset / MultiModNHistory)."""
+from .state import InitState, TrainableInitState, StaticInitState
+from .encoders import MultiModEncoder, MLPEncoder, SLPEncoder, LinearEncoder, LogisticEncoder
+from .decoders import MultiModDecoder, ClassDecoder, LogisticDecoder
+from .history import MultiModNHistory
+from .datasets import MultiModDataset, PartitionDataset, FeatureWiseDataset, JointDatasets
+from .multimodn import MultiModN
+from .engine import HipChainEngine, UnsupportedModelError
+
+__all__ = [
+    "InitState", "TrainableInitState", "StaticInitState", "MultiModEncoder", "MLPEncoder", "SLPEncoder",
+    "LinearEncoder", "LogisticEncoder", "MultiModDecoder", "ClassDecoder", "LogisticDecoder",
+    "MultiModNHistory", "MultiModDataset", "PartitionDataset", "FeatureWiseDataset", "JointDatasets",
+    "MultiModN", "HipChainEngine", "UnsupportedModelError",
+]

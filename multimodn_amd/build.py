@@ -1,0 +1,39 @@
+"""Build libmmn_hip.so in-tree with hipcc for gfx950.  `python -m multimodn_amd.build`."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "mmn_kernels.hip")
+INC = os.path.join(os.path.dirname(HERE), "include")
+OUT = os.path.join(HERE, "libmmn_hip.so")
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    newest = max(os.path.getmtime(p) for p in (SRC, os.path.join(INC, "mmn_hip.h")))
+    return os.path.getmtime(OUT) < newest
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return OUT
+    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+           f"-I{INC}", SRC, "-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

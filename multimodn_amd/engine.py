@@ -1,0 +1,286 @@
+"""HipChainEngine: owns the flat parameter / gradient buffers, the device workspace and the
+launch plan of libmmn_hip.so for one MultiModN model, and runs the training step
+(reference: multimodn/multimodn.py:137-203) as HIP launches on torch's current stream.
+
+PyTorch is plumbing here: device memory (tensors), streams, torch.distributed.  All arithmetic
+of the step happens in the HIP kernels; there is no torch-op or CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import hip
+from .decoders import ClassDecoder
+from .encoders import MLPEncoder, _identity
+from .state import TrainableInitState
+
+
+class UnsupportedModelError(NotImplementedError):
+    pass
+
+
+def activation_code(fn) -> int:
+    if fn in (F.relu, torch.relu):
+        return hip.ACT_RELU
+    if fn in (torch.sigmoid, F.sigmoid):
+        return hip.ACT_SIGMOID
+    if fn is _identity:
+        return hip.ACT_IDENTITY
+    raise UnsupportedModelError(
+        f"encoder activation {fn!r} is not on the HIP path (supported: relu, sigmoid, identity via "
+        f"LinearEncoder)")
+
+
+def check_supported(model) -> None:
+    """The HIP path covers exactly the reference's tabular hot path:
+    TrainableInitState + MLPEncoder family + two-class sigmoid ClassDecoder."""
+    if not isinstance(model.init_state, TrainableInitState):
+        raise UnsupportedModelError("init_state must be TrainableInitState")
+    if len(model.encoders) > hip.MAX_ENCODERS or len(model.decoders) > hip.MAX_DECODERS:
+        raise UnsupportedModelError("too many encoders / decoders for libmmn_hip")
+    for enc in model.encoders:
+        if not isinstance(enc, MLPEncoder):
+            raise UnsupportedModelError(f"encoder {type(enc).__name__} is not on the HIP path (MLPEncoder family only)")
+        if len(enc.layers) > hip.MAX_LAYERS:
+            raise UnsupportedModelError("too many encoder layers")
+        if len(enc.layers) > 1:
+            activation_code(enc.activation)
+    for dec in model.decoders:
+        if not isinstance(dec, ClassDecoder) or dec.n_classes != 2 or dec.activation not in (torch.sigmoid, F.sigmoid):
+            raise UnsupportedModelError("decoders must be ClassDecoder(n_classes=2, sigmoid) / LogisticDecoder")
+
+
+def check_criterion(criterion) -> None:
+    """The decoder-grid kernel implements nn.CrossEntropyLoss() exactly as every reference
+    pipeline constructs it (titanic_mlp_pipeline.py:76): mean reduction, no weights/smoothing."""
+    ok = (isinstance(criterion, torch.nn.CrossEntropyLoss) and criterion.reduction == "mean"
+          and criterion.weight is None and getattr(criterion, "label_smoothing", 0.0) == 0.0)
+    if not ok:
+        raise UnsupportedModelError(
+            "criterion must be torch.nn.CrossEntropyLoss() (mean reduction, no class weights, no label smoothing)")
+
+
+class HipChainEngine:
+    def __init__(self, model, max_batch: int):
+        check_supported(model)
+        self.lib = hip.load()
+        self.model = model
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise hip.MmnError(
+                f"MultiModN parameters live on {dev}; the training hot path only runs on an AMD GPU "
+                f"(torch device 'cuda' on ROCm). There is no CPU fallback.")
+        self.device = dev
+        self.params: List[torch.nn.Parameter] = list(model.parameters())
+        self.names: List[str] = [n for n, _ in model.named_parameters()]
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise UnsupportedModelError("parameters must be float32")
+        self._flatten_params()
+        self.n_params = self.flat_params.numel()
+        self._build(max_batch)
+
+    # ------------------------------------------------------------------ buffers and plan
+    def _flatten_params(self) -> None:
+        """Make every Parameter a view into one flat buffer (same Parameter objects, so an
+        optimizer built earlier keeps working; values preserved)."""
+        total = sum(p.numel() for p in self.params)
+        flat = torch.empty(total, dtype=torch.float32, device=self.device)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + n].view(p.shape)
+                off += n
+        self.flat_params = flat
+
+    def _build(self, max_batch: int) -> None:
+        lib, model = self.lib, self.model
+        m = hip.Model()
+        m.state_size = model.init_state.state_size
+        m.n_encoders = len(model.encoders)
+        m.n_decoders = len(model.decoders)
+        n_stats_probe = None
+        # reduce buffer = [flat grads | stats] so that data-parallel needs ONE all-reduce
+        # (stats size needs the model dims only)
+        m_probe = hip.Model()
+        m_probe.state_size, m_probe.n_encoders, m_probe.n_decoders = m.state_size, m.n_encoders, m.n_decoders
+        self.n_stats = int(lib.mmn_stats_floats(C.byref(m_probe)))
+        self.reduce_buf = torch.zeros(self.n_params + self.n_stats, dtype=torch.float32, device=self.device)
+        self.flat_grads = self.reduce_buf[:self.n_params]
+        self.stats = self.reduce_buf[self.n_params:]
+        self.grad_views: List[torch.Tensor] = []
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.grad_views.append(self.flat_grads[off:off + n].view(p.shape))
+            off += n
+        gv: Dict[int, torch.Tensor] = {id(p): g for p, g in zip(self.params, self.grad_views)}
+
+        def ptrs(p):
+            return p.data_ptr(), gv[id(p)].data_ptr()
+
+        m.init_state, m.g_init_state = ptrs(model.init_state.state_value)
+        self.enc_param_ids: List[List[int]] = []
+        for e, enc in enumerate(model.encoders):
+            me = m.enc[e]
+            me.n_features = enc.n_features
+            me.n_layers = len(enc.layers)
+            me.activation = activation_code(enc.activation) if len(enc.layers) > 1 else hip.ACT_IDENTITY
+            ids = []
+            for l, lin in enumerate(enc.layers):
+                ml = me.layer[l]
+                ml.w, ml.gw = ptrs(lin.weight)
+                ml.b, ml.gb = ptrs(lin.bias)
+                ml.out_dim, ml.in_dim = lin.out_features, lin.in_features
+                ids += [id(lin.weight), id(lin.bias)]
+            self.enc_param_ids.append(ids)
+        for d, dec in enumerate(model.decoders):
+            md = m.dec[d]
+            md.w, md.gw = ptrs(dec.fc.weight)
+            md.b, md.gb = ptrs(dec.fc.bias)
+        self._m = m
+        self.max_batch = int(max_batch)
+        ws_bytes = int(lib.mmn_workspace_bytes(C.byref(m), self.max_batch))
+        if ws_bytes == 0:
+            raise UnsupportedModelError("model dimensions are outside libmmn_hip's limits "
+                                        f"(state/hidden width <= {hip.MAX_DIM})")
+        self.workspace = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=self.device)
+        base = self.workspace.data_ptr()
+        self._ws_ptr = (base + 255) // 256 * 256
+        plan = C.c_void_p()
+        hip.check(lib.mmn_plan_create(C.byref(m), self.max_batch, self._ws_ptr, ws_bytes,
+                                      self.stats.data_ptr(), C.byref(plan)), "mmn_plan_create")
+        self._plan = plan
+        self.nan_flags = torch.zeros(hip.MAX_ENCODERS, dtype=torch.int32, device=self.device)
+        self.n_epoch = int(lib.mmn_epoch_doubles(C.byref(m)))
+        self._sig = tuple(p.data_ptr() for p in self.params)
+        self.E, self.D, self.S = m.n_encoders, m.n_decoders, m.state_size
+
+    def __del__(self):
+        try:
+            if getattr(self, "_plan", None):
+                self.lib.mmn_plan_destroy(self._plan)
+                self._plan = None
+        except Exception:
+            pass
+
+    def ensure(self, batch: int) -> None:
+        """Re-plan if the batch outgrew the workspace or the parameters moved (model.to(), ...)."""
+        moved = tuple(p.data_ptr() for p in self.params) != self._sig
+        if moved:
+            self._flatten_params()
+        if moved or batch > self.max_batch:
+            self.lib.mmn_plan_destroy(self._plan)
+            self._plan = None
+            self._build(max(batch, self.max_batch))
+
+    # ------------------------------------------------------------------ per-step
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def make_batch(self, xs: Sequence[torch.Tensor], y: torch.Tensor, pairs: Sequence[Tuple[int, int]],
+                   batch_global: Optional[int] = None, device_nan_flags: bool = False) -> hip.Batch:
+        """xs / y must be device tensors (float32 / int64).  The returned struct holds raw
+        pointers: the caller keeps xs / y alive until the step's launches have run."""
+        b = hip.Batch()
+        B = int(y.shape[0])
+        for k, x in enumerate(xs):
+            if x.dtype != torch.float32 or x.device != self.device or x.dim() != 2 or x.stride(1) != 1:
+                raise ValueError(f"data slot {k}: expected a float32 [B, F] tensor on {self.device} with unit inner stride")
+            b.x[k] = x.data_ptr()
+            b.ldx[k] = x.stride(0)
+        if y.dtype != torch.int64 or not y.is_contiguous() or y.device != self.device:
+            raise ValueError("targets must be a contiguous int64 [B, D] tensor on the model's device")
+        b.y = y.data_ptr()
+        b.nan_flags = self.nan_flags.data_ptr() if device_nan_flags else None
+        b.batch = B
+        b.batch_global = int(batch_global) if batch_global else B
+        b.n_seq = len(pairs)
+        for t, (k, e) in enumerate(pairs):
+            b.seq_data[t] = k
+            b.seq_enc[t] = e
+        return b
+
+    def nan_scan(self, b: hip.Batch) -> None:
+        hip.check(self.lib.mmn_nan_scan(self._plan, C.byref(b), self.nan_flags.data_ptr(), self._stream()), "mmn_nan_scan")
+
+    def local_step(self, b: hip.Batch, err_penalty: float, sc_penalty_x001: float) -> None:
+        """fwd + bwd + wgrad + reduce: afterwards reduce_buf = [grads | stats] holds this rank's
+        sums (already divided by batch_global)."""
+        hip.check(self.lib.mmn_train_step(self._plan, C.byref(b), err_penalty, sc_penalty_x001, 0, self._stream()),
+                  "mmn_train_step")
+
+    def eval_step(self, b: hip.Batch) -> None:
+        hip.check(self.lib.mmn_eval_step(self._plan, C.byref(b), 0, self._stream()), "mmn_eval_step")
+
+    def accumulate(self, err_penalty: float, sc_penalty_x001: float) -> None:
+        hip.check(self.lib.mmn_epoch_accumulate(self._plan, err_penalty, sc_penalty_x001, self._stream()),
+                  "mmn_epoch_accumulate")
+
+    def assign_grads(self, executed: Optional[Sequence[bool]] = None) -> None:
+        """Point every Parameter's .grad at its slice of the flat gradient buffer; encoders that
+        were skipped (NaN batch) get grad None, as autograd would leave them (multimodn.py:168)."""
+        skipped = set()
+        if executed is not None:
+            for e, ran in enumerate(executed):
+                if not ran:
+                    skipped.update(self.enc_param_ids[e])
+        for p, g in zip(self.params, self.grad_views):
+            p.grad = None if id(p) in skipped else g
+
+    # ------------------------------------------------------------------ epoch accumulators
+    def epoch_reset(self) -> None:
+        hip.check(self.lib.mmn_epoch_reset(self._plan, self._stream()), "mmn_epoch_reset")
+
+    def epoch_read(self) -> Dict[str, np.ndarray]:
+        out = np.zeros(self.n_epoch, np.float64)
+        hip.check(self.lib.mmn_epoch_read(self._plan, out.ctypes.data_as(C.POINTER(C.c_double)), self._stream()),
+                  "mmn_epoch_read")
+        return split_epoch(out, self.E, self.D)
+
+    def step_values(self) -> Dict[str, np.ndarray]:
+        """Last step's stats block (synchronises)."""
+        return split_stats(self.stats.detach().cpu().numpy(), self.E, self.D)
+
+    def debug_tensor(self, kind: int, index: int, rows: int, cols: int) -> torch.Tensor:
+        ptr = self.lib.mmn_debug_buffer(self._plan, kind, index)
+        if not ptr:
+            raise IndexError((kind, index))
+        off = (ptr - self._ws_ptr)
+        raw = self.workspace[(self._ws_ptr - self.workspace.data_ptr()) + off:]
+        return raw[:rows * cols * 4].view(torch.float32).view(rows, cols)
+
+
+def split_stats(st: np.ndarray, E: int, D: int) -> Dict[str, np.ndarray]:
+    R = E + 1
+    RD = R * D
+    o = RD + E
+    names = ("n_correct", "tp", "tn", "fp", "fn")
+    out = {"err_loss": st[:RD].reshape(R, D), "state_change": st[RD:RD + E]}
+    for i, n in enumerate(names):
+        out[n] = st[o + i * RD:o + (i + 1) * RD].reshape(R, D)
+    out["rows"] = st[o + 5 * RD:o + 5 * RD + R]
+    tail = st[o + 5 * RD + R:]
+    out["loss"], out["global_err"], out["global_sc"] = tail[0], tail[1], tail[2]
+    return out
+
+
+def split_epoch(ep: np.ndarray, E: int, D: int) -> Dict[str, np.ndarray]:
+    R = E + 1
+    RD = R * D
+    o = RD + E
+    names = ("n_correct", "tp", "tn", "fp", "fn")
+    out = {"err_sum": ep[:RD].reshape(R, D).copy(), "sc_sum": ep[RD:RD + E].copy()}
+    for i, n in enumerate(names):
+        out[n] = ep[o + i * RD:o + (i + 1) * RD].reshape(R, D).copy()
+    out["rows"] = ep[o + 5 * RD:o + 5 * RD + R].copy()
+    out["n_steps"] = ep[o + 5 * RD + R]
+    return out

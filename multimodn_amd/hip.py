@@ -1,0 +1,133 @@
+"""ctypes binding of libmmn_hip.so (include/mmn_hip.h).  No torch types cross this boundary:
+device pointers are passed as integers, the stream as a void*.
+
+The library is built in-tree by `__graft_entry__.build()` / `python -m multimodn_amd.build`.
+There is no CPU fallback: if the shared object is missing or does not export the full ABI,
+`load()` raises and every training entry point fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+MAX_ENCODERS = 16
+MAX_DECODERS = 8
+MAX_LAYERS = 8
+MAX_DIM = 256
+VERSION = 100
+
+ACT_IDENTITY, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+LIB_NAME = "libmmn_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+#: every symbol include/mmn_hip.h declares
+ABI_SYMBOLS = (
+    "mmn_version", "mmn_error_string", "mmn_last_hip_error", "mmn_stats_floats", "mmn_epoch_doubles",
+    "mmn_workspace_bytes", "mmn_plan_create", "mmn_plan_destroy", "mmn_nan_scan", "mmn_chain_fwd",
+    "mmn_chain_bwd", "mmn_wgrad", "mmn_reduce", "mmn_epoch_accumulate", "mmn_train_step",
+    "mmn_eval_step", "mmn_epoch_reset", "mmn_epoch_read", "mmn_debug_buffer",
+)
+
+
+class Linear(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("gw", C.c_void_p), ("gb", C.c_void_p),
+                ("out_dim", C.c_int32), ("in_dim", C.c_int32)]
+
+
+class Encoder(C.Structure):
+    _fields_ = [("n_features", C.c_int32), ("n_layers", C.c_int32), ("activation", C.c_int32),
+                ("reserved", C.c_int32), ("layer", Linear * MAX_LAYERS)]
+
+
+class Decoder(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("gw", C.c_void_p), ("gb", C.c_void_p)]
+
+
+class Model(C.Structure):
+    _fields_ = [("state_size", C.c_int32), ("n_encoders", C.c_int32), ("n_decoders", C.c_int32),
+                ("reserved", C.c_int32), ("init_state", C.c_void_p), ("g_init_state", C.c_void_p),
+                ("enc", Encoder * MAX_ENCODERS), ("dec", Decoder * MAX_DECODERS)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("x", C.c_void_p * MAX_ENCODERS), ("ldx", C.c_int32 * MAX_ENCODERS),
+                ("y", C.c_void_p), ("nan_flags", C.c_void_p),
+                ("batch", C.c_int32), ("batch_global", C.c_int32), ("n_seq", C.c_int32),
+                ("reserved", C.c_int32),
+                ("seq_data", C.c_int32 * MAX_ENCODERS), ("seq_enc", C.c_int32 * MAX_ENCODERS)]
+
+
+class MmnError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load(path: Optional[str] = None) -> C.CDLL:
+    """dlopen the HIP library and bind argument types.  Raises if it is absent or incomplete."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise MmnError(
+            f"{p} not found: the MI355X HIP library is not built. Run `python -c 'import "
+            f"__graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback for the "
+            f"training hot path.")
+    lib = C.CDLL(p)
+    missing = [s for s in ABI_SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise MmnError(f"{p} does not export {missing}")
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    lib.mmn_version.restype = i32
+    lib.mmn_error_string.restype = C.c_char_p
+    lib.mmn_error_string.argtypes = [i32]
+    lib.mmn_last_hip_error.restype = i32
+    lib.mmn_stats_floats.restype = C.c_size_t
+    lib.mmn_stats_floats.argtypes = [C.POINTER(Model)]
+    lib.mmn_epoch_doubles.restype = C.c_size_t
+    lib.mmn_epoch_doubles.argtypes = [C.POINTER(Model)]
+    lib.mmn_workspace_bytes.restype = C.c_size_t
+    lib.mmn_workspace_bytes.argtypes = [C.POINTER(Model), i32]
+    lib.mmn_plan_create.restype = i32
+    lib.mmn_plan_create.argtypes = [C.POINTER(Model), i32, vp, C.c_size_t, vp, C.POINTER(vp)]
+    lib.mmn_plan_destroy.restype = None
+    lib.mmn_plan_destroy.argtypes = [vp]
+    lib.mmn_nan_scan.restype = i32
+    lib.mmn_nan_scan.argtypes = [vp, C.POINTER(Batch), vp, vp]
+    lib.mmn_chain_fwd.restype = i32
+    lib.mmn_chain_fwd.argtypes = [vp, C.POINTER(Batch), f32, f32, i32, vp]
+    lib.mmn_chain_bwd.restype = i32
+    lib.mmn_chain_bwd.argtypes = [vp, C.POINTER(Batch), f32, vp]
+    lib.mmn_wgrad.restype = i32
+    lib.mmn_wgrad.argtypes = [vp, C.POINTER(Batch), vp]
+    lib.mmn_reduce.restype = i32
+    lib.mmn_reduce.argtypes = [vp, C.POINTER(Batch), vp]
+    lib.mmn_epoch_accumulate.restype = i32
+    lib.mmn_epoch_accumulate.argtypes = [vp, f32, f32, vp]
+    lib.mmn_train_step.restype = i32
+    lib.mmn_train_step.argtypes = [vp, C.POINTER(Batch), f32, f32, i32, vp]
+    lib.mmn_eval_step.restype = i32
+    lib.mmn_eval_step.argtypes = [vp, C.POINTER(Batch), i32, vp]
+    lib.mmn_epoch_reset.restype = i32
+    lib.mmn_epoch_reset.argtypes = [vp, vp]
+    lib.mmn_epoch_read.restype = i32
+    lib.mmn_epoch_read.argtypes = [vp, C.POINTER(C.c_double), vp]
+    lib.mmn_debug_buffer.restype = vp
+    lib.mmn_debug_buffer.argtypes = [vp, i32, i32]
+    if lib.mmn_version() != VERSION:
+        raise MmnError(f"{p}: ABI version {lib.mmn_version()} != expected {VERSION}; rebuild")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        lib = load()
+        msg = lib.mmn_error_string(rc).decode()
+        extra = f" (hipError {lib.mmn_last_hip_error()})" if rc == -4 else ""
+        raise MmnError(f"{what} failed: {msg}{extra}")

@@ -1,0 +1,262 @@
+"""MultiModN: the reference's model-driver surface (multimodn/multimodn.py:65-531) with the
+training step executed by hand-written HIP kernels on MI355X.
+
+Drop-in contract: same constructor and method signatures, same attribute
+and state_dict names, same History arrays (names, shapes, dtypes).  What differs is inside one
+mini-batch: the body of the reference's batch loop (multimodn.py:137-203) is one call into
+libmmn_hip.so (multimodn_amd/engine.py); per-step grids stay on the device and are read once per
+epoch.  There is no torch-op fallback for that body: without the HIP library or off an AMD GPU
+`train_epoch` raises.
+"""
+from __future__ import annotations
+
+import random
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch import Tensor
+from torch.optim import Optimizer
+from torch.utils.data import DataLoader
+
+from .decoders import MultiModDecoder
+from .encoders import MultiModEncoder
+from .engine import HipChainEngine, check_criterion
+from .history import MultiModNHistory
+from .state import InitState, TrainableInitState
+
+
+class MultiModN(nn.Module):
+    def __init__(
+            self,
+            state_size: int,
+            encoders: List[MultiModEncoder],
+            decoders: List[MultiModDecoder],
+            err_penalty: float,
+            state_change_penalty: float,
+            shuffle_mode: Optional[bool] = False,
+            init_state: Optional[InitState] = None,
+            device: Optional[torch.device] = None,
+    ):
+        super().__init__()
+        self.shuffle_mode = shuffle_mode
+        self.device = device if device else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.init_state = init_state if init_state else TrainableInitState(state_size, self.device)
+        self.encoders = nn.ModuleList(encoders)
+        self.decoders = nn.ModuleList(decoders)
+        self.err_penalty = err_penalty
+        self.state_change_penalty = 0.01 * state_change_penalty      # multimodn.py:86
+        self.to(self.device)
+        # not part of the reference surface -----------------------------------------------------
+        self._engine = None
+        self._engine_factory: Callable = HipChainEngine    # tests may inject a checker backend
+        self._dp_group = None
+        self._dp_world = 1
+        #: "host": decide NaN-skips on the host like the reference (exact grad=None semantics);
+        #: "device": keep the decision on the GPU (no sync; skipped encoders get zero grads)
+        self.nan_policy = "host"
+
+    # nn.Module pickling: the engine holds raw device handles and is rebuilt on demand
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engine"] = None
+        state["_dp_group"] = None
+        state["_dp_world"] = 1
+        return state
+
+    # ------------------------------------------------------------------------------------------
+    def enable_data_parallel(self, process_group=None) -> None:
+        """One process per GPU: every rank feeds its shard of each global mini-batch; gradients and
+        the per-step statistics are summed with ONE all-reduce (RCCL over xGMI) per step."""
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self._dp_group = process_group if process_group is not None else dist.group.WORLD
+        self._dp_world = dist.get_world_size(self._dp_group)
+
+    def _get_engine(self, batch: int):
+        if self._engine is None:
+            self._engine = self._engine_factory(self, max(int(batch), 1))
+        self._engine.ensure(int(batch))
+        return self._engine
+
+    def get_encoder_iterable(self, encoder_sequence, shuffle_mode: bool, train: bool) -> List[Tuple[int, int]]:
+        """(data_idx, enc_idx) pairs for one batch (multimodn.py:509-531)."""
+        if encoder_sequence is None:
+            pairs = [(i, i) for i in range(len(self.encoders))]
+        else:
+            seq = encoder_sequence.cpu().numpy() if isinstance(encoder_sequence, Tensor) else np.asarray(encoder_sequence)
+            first = seq[0]
+            if not (seq == first).all():
+                raise ValueError("Encoder sequence has different values across the batch. "
+                                 "Hint: set batch size to 1 to avoid this error.")
+            pairs = [(k, int(e)) for k, e in enumerate(first)]
+        if shuffle_mode and train:
+            random.shuffle(pairs)
+        return pairs
+
+    # ------------------------------------------------------------------------------------------
+    def _ingest(self, data: Sequence[Tensor], target, pairs):
+        """Host half of multimodn.py:132-135,168: move the batch to the device, decide NaN skips.
+        Returns (xs_dev, y_dev, executed_pairs, executed_mask or None)."""
+        use_device_policy = self.nan_policy == "device"
+        present: Optional[List[bool]] = None
+        if not use_device_policy:
+            present = []
+            for k, _ in pairs:
+                t = data[k]
+                present.append(not bool(torch.isnan(t).any()))      # one vectorised test per slot
+        xs = [t.to(self.device, dtype=torch.float32, non_blocking=True).contiguous() for t in data]
+        if not isinstance(target, Tensor):
+            target = torch.as_tensor(np.asarray(target))
+        y = target.to(torch.int64).to(self.device, non_blocking=True).contiguous()
+        if y.dim() == 1:
+            y = y.view(-1, 1)
+        if use_device_policy:
+            return xs, y, list(pairs), None
+        if self._dp_group is not None:                               # the decision is per GLOBAL batch
+            import torch.distributed as dist
+            flags = torch.tensor([0 if p else 1 for p in present], dtype=torch.int32,
+                                 device=self.device if dist.get_backend(self._dp_group) == "nccl" else "cpu")
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self._dp_group)
+            present = [int(f) == 0 for f in flags.tolist()]
+        exec_pairs = [pe for pe, ok in zip(pairs, present) if ok]
+        executed = [False] * len(self.encoders)
+        for _, e in exec_pairs:
+            executed[e] = True
+        return xs, y, exec_pairs, executed
+
+    def _run_step(self, eng, data, target, encoder_sequence, train: bool, batch_global: Optional[int] = None):
+        pairs = self.get_encoder_iterable(encoder_sequence, self.shuffle_mode, train=train)
+        xs, y, exec_pairs, executed = self._ingest(data, target, pairs)
+        B = int(y.shape[0])
+        b = eng.make_batch(xs, y, exec_pairs, batch_global=batch_global or B * self._dp_world,
+                           device_nan_flags=executed is None)
+        if executed is None:
+            eng.nan_scan(b)
+        if train:
+            eng.local_step(b, float(self.err_penalty), float(self.state_change_penalty))
+        else:
+            eng.eval_step(b)
+        if self._dp_group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(eng.reduce_buf if train else eng.stats, group=self._dp_group)
+        eng.accumulate(float(self.err_penalty) if train else 1.0, float(self.state_change_penalty) if train else 0.0)
+        return executed, (xs, y)
+
+    def train_epoch(
+            self,
+            train_loader: DataLoader,
+            optimizer: Optimizer,
+            criterion: Union[nn.Module, Callable],
+            history: Optional[MultiModNHistory] = None,
+            log_interval: Optional[int] = None,
+            logger: Optional[Callable] = None,
+            last_epoch: Optional[bool] = False,
+    ) -> None:
+        """One pass over train_loader (multimodn.py:89-252)."""
+        check_criterion(criterion)
+        if log_interval and not logger:
+            logger = print
+        self.train()
+        n_batches = len(train_loader)
+        eng = None
+        keep = None
+        for batch_idx, batch in enumerate(train_loader):
+            data, target, encoder_sequence = (list(batch) + [None])[:3]
+            if eng is None:
+                eng = self._get_engine(int(target.shape[0]))
+                eng.epoch_reset()
+            else:
+                eng.ensure(int(target.shape[0]))
+            optimizer.zero_grad()
+            executed, keep = self._run_step(eng, data, target, encoder_sequence, train=True)
+            eng.assign_grads(executed)          # what loss.backward() leaves behind (multimodn.py:203)
+            optimizer.step()
+            if log_interval and batch_idx % log_interval == log_interval - 1:
+                v = eng.step_values()
+                logger(f"Batch {batch_idx + 1}/{n_batches}\n"
+                       f"\tLoss: {float(v['loss']):.4f}\n"
+                       f"\tErr loss: {float(v['global_err']):.4f}\n"
+                       f"\tState change: {float(v['global_sc']):.4f}")
+        if eng is None:
+            return None
+        arrays = self._epoch_arrays(eng, n_batches)
+        del keep
+        if history is not None:
+            history.state_change_loss.append(arrays["state_change"])
+            history.loss["train"].append(arrays["loss"])
+            history.accuracy["train"].append(arrays["accuracy"])
+            history.sensitivity["train"].append(arrays["sensitivity"])
+            history.specificity["train"].append(arrays["specificity"])
+            history.balanced_accuracy["train"].append(arrays["balanced_accuracy"])
+        if last_epoch:
+            return self.test(train_loader, criterion, history=None)
+        return None
+
+    def _epoch_arrays(self, eng, n_batches: int):
+        """multimodn.py:222-242 from the device-side epoch accumulators."""
+        ep = eng.epoch_read()
+        n_samples = np.ones((len(self.encoders) + 1, 1)) + ep["rows"].reshape(-1, 1)   # starts at ONE (:105)
+        loss = ep["err_sum"] / n_batches
+        sc = ep["sc_sum"] / n_batches
+        acc = ep["n_correct"] / n_samples
+        tp, tn = ep["tp"].astype(np.float32), ep["tn"].astype(np.float32)
+        fp, fn = ep["fp"].astype(np.float32), ep["fn"].astype(np.float32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            sd = tp + fn
+            sens = np.where(sd == 0, np.float32(0), tp / sd).astype(np.float32)
+            pd_ = tn + fp
+            spec = np.where(pd_ == 0, np.float32(0), tn / pd_).astype(np.float32)
+        return {"loss": loss, "state_change": sc, "accuracy": acc, "sensitivity": sens,
+                "specificity": spec, "balanced_accuracy": (sens + spec) / 2}
+
+    def test(
+            self,
+            test_loader: DataLoader,
+            criterion: Union[nn.Module, Callable],
+            history: Optional[MultiModNHistory] = None,
+            tag: str = 'test',
+            log_results: bool = False,
+            logger: Optional[Callable] = None,
+    ):
+        """Forward-only epoch (multimodn.py:255-409) on the same HIP forward kernel.  The
+        torchmetrics-based per-decoder report (multimodn.py:410-419) is outside this round's
+        scope: returns None."""
+        check_criterion(criterion)
+        if log_results and not logger:
+            logger = print
+        self.eval()
+        n_batches = len(test_loader)
+        eng = None
+        keep = None
+        for batch in test_loader:
+            data, target, encoder_sequence = (list(batch) + [None])[:3]
+            if eng is None:
+                eng = self._get_engine(int(target.shape[0]))
+                eng.epoch_reset()
+            else:
+                eng.ensure(int(target.shape[0]))
+            _, keep = self._run_step(eng, data, target, encoder_sequence, train=False)
+        if eng is None:
+            return None
+        arrays = self._epoch_arrays(eng, n_batches)
+        del keep
+        if log_results:
+            logger(f"{tag.capitalize()} results\n"
+                   f"\tAverage loss: {np.mean(arrays['loss']):.4f}\n"
+                   f"\tAccuracy: {np.mean(arrays['accuracy']):.4f}\n"
+                   f"\tBalanced accuracy: {np.mean(arrays['balanced_accuracy']):.4f}")
+        if history is not None:
+            for name in ("loss", "accuracy", "sensitivity", "specificity", "balanced_accuracy"):
+                getattr(history, name).setdefault(tag, []).append(arrays[name])
+        return None
+
+    def predict(self, x: List[Tensor], encoder_sequence: Optional[np.ndarray] = None) -> np.ndarray:
+        raise NotImplementedError("predict() (multimodn.py:422-458) is scheduled after the training "
+                                  "hot path (SURVEY.md section 8f #2)")
+
+    def get_states(self, data_loader: DataLoader) -> List[Tensor]:
+        raise NotImplementedError("get_states() (multimodn.py:460-492) is scheduled after the training "
+                                  "hot path (SURVEY.md section 8f #2)")

@@ -1,0 +1,139 @@
+"""TEST-ONLY step backend: the same engine interface as multimodn_amd.engine.HipChainEngine, with
+the arithmetic done by the numpy oracle on the CPU.  It exists so that the HOST logic of the
+package (batch ingest, NaN policy, sequence handling, data-parallel protocol, epoch aggregation,
+History) can be tested here without a GPU.  It lives under tests/ and is never imported by the
+product; MultiModN's default engine factory is the HIP engine, which refuses to run off-GPU."""
+import numpy as np
+import torch
+
+from multimodn_amd.engine import activation_code, check_supported, split_epoch, split_stats
+from oracle import multimodn_oracle as O
+
+
+class _Batch:
+    pass
+
+
+class OracleEngine:
+    def __init__(self, model, max_batch):
+        check_supported(model)
+        self.model = model
+        self.params = list(model.parameters())
+        self.names = [n for n, _ in model.named_parameters()]
+        self.E, self.D, self.S = len(model.encoders), len(model.decoders), model.init_state.state_size
+        encs = []
+        for enc in model.encoders:
+            act = activation_code(enc.activation) if len(enc.layers) > 1 else O.ACT_IDENTITY
+            encs.append(O.EncoderSpec(enc.n_features, tuple(enc.hidden_layers), act))
+        self.spec = O.ModelSpec(self.S, encs, self.D, float(model.err_penalty), float(model.state_change_penalty) / 0.01)
+        self.n_params = sum(p.numel() for p in self.params)
+        R = self.E + 1
+        self.n_stats = R * self.D + self.E + 5 * R * self.D + R + 4
+        self.reduce_buf = torch.zeros(self.n_params + self.n_stats)
+        self.flat_grads = self.reduce_buf[:self.n_params]
+        self.stats = self.reduce_buf[self.n_params:]
+        self.grad_views, off = [], 0
+        for p in self.params:
+            self.grad_views.append(self.flat_grads[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        self.enc_param_ids = [[id(p) for lin in enc.layers for p in (lin.weight, lin.bias)] for enc in model.encoders]
+        self.epoch = np.zeros(R * self.D + self.E + 5 * R * self.D + R + 1)
+        self.max_batch = max_batch
+
+    def ensure(self, batch):
+        self.max_batch = max(self.max_batch, batch)
+
+    def epoch_reset(self):
+        self.epoch[:] = 0
+
+    def make_batch(self, xs, y, pairs, batch_global=None, device_nan_flags=False):
+        b = _Batch()
+        b.xs = [x.numpy() for x in xs]
+        b.y = y.numpy()
+        b.pairs = list(pairs)
+        b.batch_global = batch_global or len(b.y)
+        b.device_nan = device_nan_flags
+        return b
+
+    def nan_scan(self, b):
+        pass
+
+    def _run(self, b, want_grads):
+        params = {n: p.detach().numpy() for n, p in zip(self.names, self.params)}
+        n_slots = max(k for k, _ in b.pairs) + 1 if b.pairs else 0
+        seq = None
+        xs = b.xs
+        if b.pairs:
+            # oracle takes a [B, n_seq] sequence whose t-th entry feeds data slot t
+            xs = [b.xs[k] for k, _ in b.pairs]
+            seq = np.tile(np.array([e for _, e in b.pairs], np.int64), (len(b.y), 1))
+        override = None if b.device_nan else [True] * len(b.pairs)
+        spec = self.spec
+        if not b.pairs:
+            xs, seq, override = [], np.zeros((len(b.y), 0), np.int64), []
+        r = O.forward_backward(params, spec, xs, b.y, seq, batch_global=b.batch_global,
+                               present_override=override, want_grads=want_grads)
+        R, D, E = self.E + 1, self.D, self.E
+        st = np.zeros(self.n_stats, np.float32)
+        RD = R * D
+        st[:RD] = r.err_loss.reshape(-1)
+        st[RD:RD + E] = r.state_change
+        for i, k in enumerate(("n_correct", "tp", "tn", "fp", "fn")):
+            st[RD + E + i * RD:RD + E + (i + 1) * RD] = getattr(r, k).reshape(-1)
+        rows = np.zeros(R, np.float32)
+        rows[0] = len(b.y)
+        rows[1:][r.executed] = len(b.y)
+        st[RD + E + 5 * RD:RD + E + 5 * RD + R] = rows
+        self.stats.copy_(torch.from_numpy(st))
+        if want_grads:
+            flat = np.concatenate([np.zeros(p.numel(), np.float32) if r.grads[n] is None
+                                   else np.asarray(r.grads[n], np.float32).reshape(-1)
+                                   for n, p in zip(self.names, self.params)])
+            self.flat_grads.copy_(torch.from_numpy(flat))
+
+    def local_step(self, b, alpha, beta):
+        self._run(b, True)
+
+    def eval_step(self, b):
+        spec = self.spec
+        self.spec = O.ModelSpec(spec.state_size, spec.encoders, spec.D, 1.0, 0.0)
+        try:
+            self._run(b, False)
+        finally:
+            self.spec = spec
+
+    def accumulate(self, alpha, beta):
+        """numpy twin of k_epoch_accumulate."""
+        st = self.stats.numpy()
+        R, D, E = self.E + 1, self.D, self.E
+        RD = R * D
+        ge = np.float32(st[:RD].sum(dtype=np.float32) / np.float32(D * R))
+        gs = np.float32(st[RD:RD + E].sum(dtype=np.float32) / np.float32(E))
+        tail = RD + E + 5 * RD + R
+        st[tail] = ge * np.float32(alpha) + gs * np.float32(beta)
+        st[tail + 1], st[tail + 2] = ge, gs
+        ep = self.epoch
+        ep[:RD] += st[:RD].astype(np.float64)
+        ep[RD:RD + E] += st[RD:RD + E].astype(np.float64)
+        o = RD + E
+        ep[o:o + RD] += st[o:o + RD]
+        for k in range(1, 5):
+            sl = slice(o + k * RD, o + (k + 1) * RD)
+            ep[sl] = (ep[sl].astype(np.float32) + st[sl]).astype(np.float64)
+        ep[o + 5 * RD:o + 5 * RD + R] += st[o + 5 * RD:o + 5 * RD + R]
+        ep[-1] += 1
+
+    def assign_grads(self, executed=None):
+        skipped = set()
+        if executed is not None:
+            for e, ran in enumerate(executed):
+                if not ran:
+                    skipped.update(self.enc_param_ids[e])
+        for p, g in zip(self.params, self.grad_views):
+            p.grad = None if id(p) in skipped else g
+
+    def epoch_read(self):
+        return split_epoch(self.epoch.copy(), self.E, self.D)
+
+    def step_values(self):
+        return split_stats(self.stats.numpy().copy(), self.E, self.D)

@@ -154,12 +154,15 @@ def test_full_size_c3_step_matches_oracle(lib):
     stats, grads, _ = run_step(model, batch)
     ref32 = O.forward_backward(params, spec, batch[0], batch[1])
     ref64 = O.forward_backward(params, spec, batch[0], batch[1], dtype=np.float64)
-    check_against(stats, grads, ref32, tol_grad=5e-5)
+    # 4096-term sums that cancel to ~1e-4 (bias grads) move by ~5e-5 with the summation order
+    # alone, so fp32-vs-fp32 gets a looser gradient bound here and fp64 truth is the real judge:
+    check_against(stats, grads, ref32, tol_grad=3e-4)
     # the HIP path must be as close to fp64 truth as the fp32 CPU restatement is (x4 slack)
     for n, g in ref64.grads.items():
         e_hip = rel_err(grads[n].reshape(g.shape), g)
         e_cpu = rel_err(ref32.grads[n], g)
         assert e_hip < max(4 * e_cpu, 2e-6), (n, e_hip, e_cpu)
+    assert rel_err(stats["err_loss"], ref64.err_loss) < 2e-6
 
 
 def test_shard_linearity_full_size(lib):

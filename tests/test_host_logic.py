@@ -1,0 +1,167 @@
+"""Host-side logic of the package on a GPU-less machine: the public surface driven through a
+test-only oracle backend (tests/oracle_engine.py) must reproduce the reference's golden History
+arrays and trained weights; plus the plugin/dataset/history classes themselves."""
+import io
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import multimodn_amd as mm
+from helpers import GOLDEN_NAMES, Golden, build_torch_model, rel_err
+from oracle_engine import OracleEngine
+
+
+def make_loader(g):
+    loader = []
+    for b in g.batches():
+        item = [[torch.from_numpy(x) for x in b[0]], torch.from_numpy(b[1])]
+        if len(b) > 2:
+            item.append(torch.from_numpy(b[2]))
+        loader.append(tuple(item))
+    return loader
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_train_epoch_host_logic_reproduces_golden_history(name):
+    g = Golden(name)
+    model = build_torch_model(g.spec, g.init_params(), "cpu", mm)
+    model._engine_factory = OracleEngine
+    opt = torch.optim.Adam(list(model.parameters()), g.cfg["lr"])
+    hist = mm.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
+    for _ in range(g.epochs):
+        assert model.train_epoch(make_loader(g), opt, torch.nn.CrossEntropyLoss(), hist) is None
+    z = g.z
+    assert rel_err(np.stack(hist.loss["train"]), z["hist/loss"]) < 2e-6
+    assert rel_err(np.stack(hist.state_change_loss), z["hist/state_change"]) < 2e-6
+    for k in ("accuracy", "sensitivity", "specificity", "balanced_accuracy"):
+        got = np.stack(getattr(hist, k)["train"])
+        assert got.dtype == z["hist/" + k].dtype and got.shape == z["hist/" + k].shape
+        assert np.array_equal(got, z["hist/" + k]), k
+    tol = 2e-3 if name == "c1_curve20" else 5e-5
+    sd = model.state_dict()
+    for n, w in g.final_params().items():
+        assert rel_err(sd[n].numpy(), w) < tol, n
+
+
+def test_nan_skip_leaves_grad_none_and_adam_untouched():
+    g = Golden("nan_skip")
+    model = build_torch_model(g.spec, g.init_params(), "cpu", mm)
+    model._engine_factory = OracleEngine
+    opt = torch.optim.Adam(list(model.parameters()), 0.01)
+    loader = make_loader(g)[1:2]                       # the batch with a NaN in data slot 1
+    before = model.encoders[1].layers[0].weight.detach().clone()
+    model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss())
+    assert model.encoders[1].layers[0].weight.grad is None
+    assert torch.equal(before, model.encoders[1].layers[0].weight.detach())
+    assert model.encoders[0].layers[0].weight.grad is not None
+
+
+def test_state_dict_keys_and_pickle_roundtrip():
+    g = Golden("c2_split")
+    model = build_torch_model(g.spec, g.init_params(), "cpu", mm)
+    keys = list(model.state_dict().keys())
+    assert keys[0] == "init_state.state_value"
+    assert "encoders.1.layers.2.bias" in keys and "decoders.1.fc.weight" in keys
+    assert keys == g.spec.param_names()
+    model._engine_factory = OracleEngine
+    model.train_epoch(make_loader(g), torch.optim.Adam(model.parameters(), 0.01), torch.nn.CrossEntropyLoss())
+    clone = pickle.loads(pickle.dumps(model))           # pipelines pkl.dump the whole model
+    assert clone._engine is None
+    for (n1, p1), (n2, p2) in zip(model.state_dict().items(), clone.state_dict().items()):
+        assert n1 == n2 and torch.equal(p1, p2)
+    buf = io.BytesIO()
+    torch.save({"epoch": 1, "model_state_dict": model.state_dict()}, buf)      # MIMIC pipelines' checkpoint
+    buf.seek(0)
+    fresh = build_torch_model(g.spec, g.init_params(), "cpu", mm)
+    fresh.load_state_dict(torch.load(buf)["model_state_dict"])
+    assert torch.equal(fresh.decoders[0].fc.weight, model.decoders[0].fc.weight)
+
+
+def test_encoder_iterable_semantics():
+    g = Golden("seq_perm")
+    model = build_torch_model(g.spec, g.init_params(), "cpu", mm)
+    assert model.get_encoder_iterable(None, False, True) == [(0, 0), (1, 1), (2, 2), (3, 3)]
+    seq = torch.tensor([[2, 0, 1, 3]] * 5)
+    assert model.get_encoder_iterable(seq, False, True) == [(0, 2), (1, 0), (2, 1), (3, 3)]
+    with pytest.raises(ValueError, match="different values across the batch"):
+        model.get_encoder_iterable(torch.tensor([[0, 1, 2, 3], [1, 0, 2, 3]]), False, True)
+    model.shuffle_mode = True
+    assert sorted(model.get_encoder_iterable(None, True, True)) == [(0, 0), (1, 1), (2, 2), (3, 3)]
+    assert model.get_encoder_iterable(None, True, False) == [(0, 0), (1, 1), (2, 2), (3, 3)]
+
+
+def test_state_change_penalty_is_scaled_and_signature_matches():
+    import inspect
+    model = mm.MultiModN(4, [mm.MLPEncoder(4, 3, (2,))], [mm.LogisticDecoder(4)], 0.7, 0.3, device=torch.device("cpu"))
+    assert abs(model.state_change_penalty - 0.003) < 1e-12 and model.err_penalty == 0.7
+    assert list(inspect.signature(mm.MultiModN.__init__).parameters)[1:] == [
+        "state_size", "encoders", "decoders", "err_penalty", "state_change_penalty", "shuffle_mode", "init_state", "device"]
+    assert list(inspect.signature(mm.MultiModN.train_epoch).parameters)[1:] == [
+        "train_loader", "optimizer", "criterion", "history", "log_interval", "logger", "last_epoch"]
+    assert list(inspect.signature(mm.MultiModN.test).parameters)[1:] == [
+        "test_loader", "criterion", "history", "tag", "log_results", "logger"]
+
+
+def test_unsupported_plugins_and_criteria_are_refused():
+    class Odd(mm.MultiModEncoder):
+        def forward(self, state, x):
+            return state
+    model = mm.MultiModN(4, [Odd(4)], [mm.LogisticDecoder(4)], 1.0, 0.0, device=torch.device("cpu"))
+    model._engine_factory = OracleEngine
+    loader = [([torch.zeros(2, 3)], torch.zeros(2, 1, dtype=torch.int64))]
+    with pytest.raises(mm.UnsupportedModelError):
+        model.train_epoch(loader, torch.optim.Adam(model.parameters()), torch.nn.CrossEntropyLoss())
+    ok = mm.MultiModN(4, [mm.MLPEncoder(4, 3, (2,))], [mm.LogisticDecoder(4)], 1.0, 0.0, device=torch.device("cpu"))
+    with pytest.raises(mm.UnsupportedModelError):
+        ok.train_epoch(loader, torch.optim.Adam(ok.parameters()), torch.nn.CrossEntropyLoss(reduction="sum"))
+
+
+def test_product_engine_refuses_cpu_device():
+    ok = mm.MultiModN(4, [mm.MLPEncoder(4, 3, (2,))], [mm.LogisticDecoder(4)], 1.0, 0.0, device=torch.device("cpu"))
+    loader = [([torch.zeros(2, 3)], torch.zeros(2, 1, dtype=torch.int64))]
+    with pytest.raises(mm.hip.MmnError, match="no CPU fallback"):
+        ok.train_epoch(loader, torch.optim.Adam(ok.parameters()), torch.nn.CrossEntropyLoss())
+
+
+def test_plugin_forward_contract():
+    torch.manual_seed(0)
+    enc = mm.MLPEncoder(5, 3, (4, 2))
+    s, x = torch.randn(6, 5), torch.randn(6, 3)
+    h = torch.relu(enc.layers[1](torch.relu(enc.layers[0](x))))
+    assert torch.allclose(enc(s, x), enc.layers[2](torch.cat([h, s], 1)))
+    assert enc.layers[2].in_features == 2 + 5
+    slp = mm.LogisticEncoder(5, 3)
+    assert len(slp.layers) == 1 and slp.layers[0].in_features == 8
+    dec = mm.LogisticDecoder(5)
+    assert dec.n_classes == 2 and dec(s).shape == (6, 2) and float(dec(s).max()) < 1
+    init = mm.TrainableInitState(5)
+    assert init(3).shape == (3, 5) and torch.equal(init(3)[0], init.state_value[0])
+
+
+def test_partition_dataset_and_collate():
+    X = np.arange(40, dtype=np.float32).reshape(8, 5)
+    y = np.arange(16).reshape(8, 2) % 2
+    ds = mm.PartitionDataset(X, y, [3, 2])
+    xs, t = ds[2]
+    assert [tuple(v.shape) for v in xs] == [(3,), (2,)] and np.array_equal(t, y[2])
+    with pytest.raises(ValueError):
+        mm.PartitionDataset(X, y, [3, 3])
+    batch = next(iter(torch.utils.data.DataLoader(ds, 4)))
+    assert batch[0][0].shape == (4, 3) and batch[0][1].shape == (4, 2) and batch[1].shape == (4, 2)
+    parts = ds.random_split((0.5, 0.5), seed=0, balanced_target_idx=0)
+    assert sorted(parts[0].indices + parts[1].indices) == list(range(8))
+    assert len(mm.FeatureWiseDataset(X, y)[0][0]) == 5
+
+
+def test_history_results_table(tmp_path):
+    h = mm.MultiModNHistory(["a", "b"])
+    h.state_change_loss.append(np.array([0.5, 0.25]))
+    for k in ("loss", "accuracy", "sensitivity", "specificity", "balanced_accuracy"):
+        getattr(h, k)["train"].append(np.arange(6, dtype=float).reshape(3, 2))
+    df = h.get_results()
+    assert list(df.index) == ["a", "b"] and df.shape == (2, 6)
+    assert df["State change loss"].tolist() == [0.25, 0.25] and df["Train loss"].tolist() == [4.0, 5.0]
+    h.save_results(tmp_path / "r.csv")
+    assert (tmp_path / "r.csv").read_text().startswith("Target,State change loss,Train loss")

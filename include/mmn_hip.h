@@ -142,9 +142,18 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
                     float* stats, mmn_plan** out);
 void mmn_plan_destroy(mmn_plan* p);
 
-/* multimodn.py:168: nan_flags_out[k] = 1 iff any element of data slot k is NaN (k over the slots
- * named by the sequence).  nan_flags_out: device, MMN_MAX_ENCODERS ints (memset + one launch). */
-int mmn_nan_scan(mmn_plan* p, const mmn_batch* b, int32_t* nan_flags_out, void* stream);
+/* Plan-owned NaN flags (device, MMN_MAX_ENCODERS ints, zero after plan creation).  Put this
+ * pointer into mmn_batch.nan_flags to keep the NaN-skip decision on the device. */
+int32_t* mmn_nan_flags(mmn_plan* p);
+
+/* Per-step preparation, one launch: (a) if b->nan_flags != NULL, multimodn.py:168:
+ * nan_flags[k] = 1 iff any element of data slot k is NaN, for the slots the sequence names (flags
+ * must be zero on entry; mmn_reduce / mmn_train_step / mmn_eval_step re-zero them after their last
+ * reader); (b) if want_grads, transposed copies of the weights the backward chain multiplies by
+ * (a layout transform with no reference counterpart). */
+int mmn_prepare(mmn_plan* p, const mmn_batch* b, int want_grads, void* stream);
+/* (a) alone. */
+int mmn_nan_scan(mmn_plan* p, const mmn_batch* b, void* stream);
 
 /* Forward chain, one launch: init-state broadcast (state.py:29-32), every executed encoder
  * (mlp_encoder.py:74-80), state-change partials (multimodn.py:174), all D decoders on all E+1
@@ -166,7 +175,9 @@ int mmn_reduce(mmn_plan* p, const mmn_batch* b, void* stream);
  * `stats` (call after the all-reduce when data-parallel). */
 int mmn_epoch_accumulate(mmn_plan* p, float err_penalty, float state_change_penalty_x001, void* stream);
 
-/* All five launches above in order: one full multimodn.py:137-203 body (without optimizer.step). */
+/* prepare + chain_fwd + chain_bwd + wgrad + reduce in order: one full multimodn.py:137-203 body
+ * (without optimizer.step).  accumulate_epoch != 0 folds mmn_epoch_accumulate into the reduce
+ * launch (single-GPU); pass 0 when an all-reduce of [grads | stats] must happen first. */
 int mmn_train_step(mmn_plan* p, const mmn_batch* b, float err_penalty, float state_change_penalty_x001,
                    int accumulate_epoch, void* stream);
 

@@ -1,29 +1,32 @@
 // mmn_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the MultiModN sequential-fusion training
 // step and the C ABI declared in include/mmn_hip.h.  Written for wave64 + fp32 MFMA
 // (v_mfma_f32_16x16x4_f32: bit-exact fp32 FMA chains, so fp32 parity with the reference's ATen
-// path holds to rounding-order effects only).  No CUDA names, no dual paths.
+// path holds up to summation order).  No CUDA names, no dual paths.
 //
 // Launch structure of one training step (reference: multimodn/multimodn.py:137-203):
-//   k_nan_scan         any(isnan(x_k)) per data slot                              (:168)
+//   k_prepare          any(isnan(x_k)) per data slot (:168) + transposed weight copies for backward
 //   k_chain_fwd        row-tile parallel: init broadcast, every encoder, state-change partials,
 //                      all D decoders on all E+1 states, CE-over-sigmoid, argmax, confusion counts
 //   k_chain_bwd        row-tile parallel reverse chain: grads wrt states / pre-activations
 //   k_wgrad            grouped split-K "A^T B" GEMM: weight, bias and init-state grads as slabs
 //   k_reduce           fixed-order slab reduction -> grads; tile partials -> stats block
-//   k_epoch_accumulate loss combination + epoch accumulators                      (:194-212)
+//                      (+ loss combination and epoch accumulators, :194-212, when single-GPU)
 //
 // Data layout in HBM (all fp32 row-major, B = batch rows):
 //   states[e][B][S]     output state of encoder e          hid[e][l][B][H_l]  hidden activations
 //   dz[r][B][2D]        d loss / d decoder logits, row r   dS[e][B][S]        d loss / d state_e (+dS0)
 //   dpre[e][l][B][H_l]  d loss / d hidden pre-activation   slabs              split-K partial grads
+//   wT                  W^T copies of every matrix the backward chain multiplies by
 //
-// Tiling: one workgroup = 256 threads = 4 waves owns 32 batch rows; the state tile lives in LDS
-// for the whole chain.  Every Linear is "tile[32 x K] x W[N x K]^T": W is staged through LDS in
-// [<=128 x 64] images (zero padded, row stride 68 floats = 4 mod 64 so that the ds_read_b64
-// fragment reads are bank-conflict free), wave w owns output column tiles {w, w+4} x both 16-row
-// tiles.  K is walked 8 at a time: one 8-byte fragment read feeds two MFMAs (the contraction
-// index is permuted identically for A and B, which is legal because the sum is order-free per
-// MFMA pair and both operands use the same permutation).
+// Tiling.  A workgroup (256 threads = 4 waves) owns 16*RT batch rows (RT = 1 or 2); the state tile
+// stays in LDS for the whole chain.  Every product is "tile[rows x K] x W'[N x K]^T" with the
+// ACTIVATION tile in LDS and the WEIGHT fragments loaded straight from L2 into registers: at 16-32
+// rows per workgroup each weight element is used by exactly one wave, so an LDS round trip (and its
+// barriers) would be pure overhead (guide: "GEMV / M <= 16: load straight to VGPRs").  Wave w owns
+// output column tiles {w, w+4} of every group of 8; the contraction is walked 16 at a time: one
+// 16-byte fragment load per operand feeds four MFMAs (the contraction index is permuted identically
+// for A and B, which is legal because both fragments use the same permutation).  Weight loads run
+// two k-steps ahead of the MFMAs that consume them.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -37,18 +40,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int TB = 32;       // batch rows per workgroup tile
-constexpr int NT = 256;      // threads per workgroup
-constexpr int LDW = 68;      // row stride (floats) of every staged [.. x 64] LDS image
-constexpr int LDZ = 20;      // row stride of the dz tile
-constexpr int WG_TILE = 64;  // wgrad output tile edge
+constexpr int NT = 256;       // threads per workgroup
+constexpr int XCH = 128;      // x columns staged per chunk
+constexpr int LDX = 132;      // row stride of the x chunk image
+constexpr int LDZ = 20;       // row stride of the dz tile (16 + 4)
+constexpr int WT_LD = 16;     // row stride of the transposed decoder matrix
+constexpr int TILE_LD = 65;   // row stride of the wgrad reduction tile
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
-// smallest row stride = 4 (mod 64) that holds round_up(k, 8) floats
+// smallest row stride = 4 (mod 64) floats that holds round_up(k, 16) floats: rows stay 16-byte
+// aligned and the 16-byte fragment reads of 16 consecutive rows spread over all 64 banks
 __host__ __device__ inline int pick_ld(int k) {
-    const int k8 = round_up(k, 8);
+    const int k16 = round_up(k, 16);
     int ld = 68;
-    while (ld < k8) ld += 64;
+    while (ld < k16) ld += 64;
     return ld;
 }
 
@@ -69,7 +74,11 @@ struct WTask {
     int64_t slab_base, pstride;
 };
 
-struct WItem { int32_t task, m0, n0, ks; };
+struct WItem {
+    int32_t task, m0, n0, ks;          // n0 relative to the source `src`
+    int16_t mt, nt;                    // interleave widths (1, 2 or 4): tile = 16*mt x 16*nt
+    int16_t src, bias;                 // src 0: in0, 1: in1, 2: none (bias only)
+};
 
 struct Seg {                            // one gradient tensor
     float* dst;
@@ -78,18 +87,23 @@ struct Seg {                            // one gradient tensor
     int32_t count, n_partials, kdiv, ntot, coff, row_off;
 };
 
+struct TTask { const float* src; float* dst; int32_t rows, cols, ld_src, ld_dst; };
+struct TItem { int32_t task, r0, c0, pad; };
+
 struct DevPlan {
     mmn_model m;
-    int32_t S, E, D, R, S8, ldS, ldAct, maxB, max_tiles, KS;
+    int32_t S, E, D, R, S16, ldS, ldH, maxB, max_tiles, KS, RT, pad1;
     int64_t hid_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];   // float offsets into hid / dpre
+    int64_t wt_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];    // float offsets into wT (layer l of enc e)
     float* states; float* hid; float* dpre; float* dz; float* dS;
+    float* wT; float* wdT;    // transposed weights; decoder matrix transposed [S][16]
     float* lossp; float* scp; int32_t* cntp;
     int32_t* exec_flags;      // [R]   1 if state row r was produced this step
     int32_t* prev_row;        // [E]   state row that fed encoder e this step
-    int32_t* nan_flags;       // [MMN_MAX_ENCODERS] scratch for mmn_nan_scan users
+    int32_t* nan_flags;       // [MMN_MAX_ENCODERS] NaN-found flag per data slot
     float* slabs; float* stats; double* epoch;
-    WTask* tasks; WItem* items; Seg* segs;
-    int32_t n_tasks, n_items, n_segs, pad0;
+    WTask* tasks; WItem* items; Seg* segs; TTask* ttasks; TItem* titems;
+    int32_t n_tasks, n_items, n_segs, n_titems;
     int64_t n_grad_elems;
 };
 
@@ -115,163 +129,247 @@ __device__ __forceinline__ bool slot_present(const mmn_batch& b, int slot) {
     return b.nan_flags == nullptr || b.nan_flags[slot] == 0;
 }
 
-// Cooperative copy of a [nr_valid x nc_valid] global tile (row stride ld_src) into an LDS image
-// [nr_pad x nc_pad] (row stride ld_dst), zero filling the padding.  nc_pad % 4 == 0.
-__device__ __forceinline__ void stage_tile(float* dst, int ld_dst, const float* __restrict__ src,
-                                           int64_t ld_src, int nr_valid, int nr_pad, int nc_valid,
-                                           int nc_pad) {
-    const int c4n = nc_pad >> 2;
-    const bool vec = ((ld_src & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-    const int total = nr_pad * c4n;
-    for (int idx = threadIdx.x; idx < total; idx += NT) {
-        const int r = idx / c4n;
-        const int c = (idx - r * c4n) << 2;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < nr_valid && c < nc_valid) {
-            const float* p = src + (int64_t)r * ld_src + c;
-            if (vec && c + 3 < nc_valid) {
-                v = *reinterpret_cast<const float4*>(p);
-            } else {
-                v.x = p[0];
-                if (c + 1 < nc_valid) v.y = p[1];
-                if (c + 2 < nc_valid) v.z = p[2];
-                if (c + 3 < nc_valid) v.w = p[3];
-            }
-        }
-        *reinterpret_cast<float4*>(dst + r * ld_dst + c) = v;
-    }
-}
-
-// acc[ci][rt] += A[32 x klen8] * Wimg[n][k]^T.  A row stride lda (even), Wimg row stride ldw.
-// Wave w owns image-row tiles {w, w+4} (16 rows each) that lie below n_pad16.
-__device__ __forceinline__ void mma_nt(f32x4 (&acc)[2][2], const float* A, int lda, int kbase,
-                                       int klen8, const float* Wimg, int ldw, int n_pad16) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, q = lane >> 4;
-    if (wave * 16 >= n_pad16) return;
-    const bool t1 = (wave + 4) * 16 < n_pad16;
-    const float* a0p = A + i * lda + kbase + 2 * q;
-    const float* a1p = a0p + 16 * lda;
-    const float* b0p = Wimg + (wave * 16 + i) * ldw + 2 * q;
-    const float* b1p = b0p + 64 * ldw;
-    for (int k = 0; k < klen8; k += 8) {
-        const float2 a0 = *reinterpret_cast<const float2*>(a0p + k);
-        const float2 a1 = *reinterpret_cast<const float2*>(a1p + k);
-        const float2 b0 = *reinterpret_cast<const float2*>(b0p + k);
-        acc[0][0] = mfma4(a0.x, b0.x, acc[0][0]);
-        acc[0][1] = mfma4(a1.x, b0.x, acc[0][1]);
-        acc[0][0] = mfma4(a0.y, b0.y, acc[0][0]);
-        acc[0][1] = mfma4(a1.y, b0.y, acc[0][1]);
-        if (t1) {
-            const float2 b1 = *reinterpret_cast<const float2*>(b1p + k);
-            acc[1][0] = mfma4(a0.x, b1.x, acc[1][0]);
-            acc[1][1] = mfma4(a1.x, b1.x, acc[1][1]);
-            acc[1][0] = mfma4(a0.y, b1.y, acc[1][0]);
-            acc[1][1] = mfma4(a1.y, b1.y, acc[1][1]);
-        }
-    }
-}
-
-// acc[rt] += A[32 x nlen8] * Wimg[n][c0 + 16*wave + j]  (contraction over image ROWS n).
-__device__ __forceinline__ void mma_nn(f32x4 (&acc)[2], const float* A, int lda, int nbase,
-                                       int nlen8, const float* Wimg, int ldw, int c_pad16) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, q = lane >> 4;
-    if (wave * 16 >= c_pad16) return;
-    const float* a0p = A + i * lda + nbase + 2 * q;
-    const float* a1p = a0p + 16 * lda;
-    const float* bp = Wimg + (2 * q) * ldw + wave * 16 + i;
-    for (int n = 0; n < nlen8; n += 8) {
-        const float2 a0 = *reinterpret_cast<const float2*>(a0p + n);
-        const float2 a1 = *reinterpret_cast<const float2*>(a1p + n);
-        const float bx = bp[n * ldw];
-        const float by = bp[(n + 1) * ldw];
-        acc[0] = mfma4(a0.x, bx, acc[0]);
-        acc[1] = mfma4(a1.x, bx, acc[1]);
-        acc[0] = mfma4(a0.y, by, acc[0]);
-        acc[1] = mfma4(a1.y, by, acc[1]);
-    }
-}
-
-struct ASeg {
-    const float* g;     // global source already offset to the tile's first row (nullptr: LDS)
-    int64_t ldg;
-    const float* lds;
-    int ldl;
-    int K;
-    int wcol;           // first W column this segment multiplies
-};
-
-// out[32 x N] = sum_seg A_seg[32 x K_seg] * W[:, wcol_seg : wcol_seg + K_seg]^T, epilogue per element.
-template <class Epi>
-__device__ __forceinline__ void linear_nt(const float* __restrict__ W, int ldw_g, int N,
-                                          const ASeg* seg, int nseg, int nrows, float* sX, float* sW,
-                                          Epi&& epi) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, q = lane >> 4;
-    for (int nc = 0; nc < N; nc += 128) {
-        const int nval = min(128, N - nc), npad = round_up(nval, 16);
-        f32x4 acc[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < nseg; ++s) {
-            for (int kc = 0; kc < seg[s].K; kc += 64) {
-                const int kw = min(64, seg[s].K - kc), kw8 = round_up(kw, 8);
-                stage_tile(sW, LDW, W + (int64_t)nc * ldw_g + seg[s].wcol + kc, ldw_g, nval, npad, kw, kw8);
-                const float* A;
-                int lda, kbase;
-                if (seg[s].g) {
-                    stage_tile(sX, LDW, seg[s].g + kc, seg[s].ldg, nrows, TB, kw, kw8);
-                    A = sX; lda = LDW; kbase = 0;
-                } else {
-                    A = seg[s].lds; lda = seg[s].ldl; kbase = kc;
-                }
-                __syncthreads();
-                mma_nt(acc, A, lda, kbase, kw8, sW, LDW, npad);
-                __syncthreads();
-            }
-        }
-#pragma unroll
-        for (int ci = 0; ci < 2; ++ci) {
-            if ((wave + 4 * ci) * 16 < npad) {
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        epi(rt * 16 + q * 4 + r, nc + (wave + 4 * ci) * 16 + i, acc[ci][rt][r]);
-            }
-        }
-    }
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
     return v;
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_nan_scan: flags[slot] = 1 if any element of data slot `slot` is NaN (flags pre-zeroed)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_nan_scan(mmn_batch b, const mmn_model* __restrict__ m_dev,
-                                                 int32_t* flags, int blocks_per_slot) {
-    const int t = blockIdx.x / blocks_per_slot;          // sequence position
-    const int part = blockIdx.x - t * blocks_per_slot;
-    const int slot = b.seq_data[t];
-    const int F = m_dev->enc[b.seq_enc[t]].n_features;
-    const float* x = b.x[slot];
-    const int64_t ld = b.ldx[slot];
-    const int64_t total = (int64_t)b.batch * F;
-    bool bad = false;
-    for (int64_t idx = (int64_t)part * NT + threadIdx.x; idx < total; idx += (int64_t)blocks_per_slot * NT) {
-        const int64_t r = idx / F;
-        const int c = (int)(idx - r * F);
-        const float v = x[r * ld + c];
-        bad |= (v != v);
+// ---- W' operand description: rows = output features, contraction along (up to two) column ranges
+struct BSrc {
+    const float* w;
+    int ldw;
+    int N;                       // valid rows
+    int len0, len0p, col0;       // kk in [0, len0p): column col0 + kk, valid while kk < len0
+    int len1, len1p, col1;       // kk in [len0p, len0p + len1p): column col1 + (kk - len0p)
+    bool vec;                    // every fragment is a whole, 16-byte aligned float4
+};
+__device__ __forceinline__ BSrc make_bsrc(const float* w, int ldw, int N, int len0, int col0, int len1,
+                                          int col1) {
+    BSrc s;
+    s.w = w; s.ldw = ldw; s.N = N;
+    s.len0 = len0; s.len0p = round_up(len0, 16); s.col0 = col0;
+    s.len1 = len1; s.len1p = round_up(len1, 16); s.col1 = col1;
+    s.vec = ((ldw | col0 | col1 | len0 | len1) & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0;
+    return s;
+}
+// activation operand: LDS images for the two contraction segments (zero/finite padded to 16)
+struct ASrc { const float* a0; int lda0; const float* a1; int lda1; };
+
+template <bool VEC>
+__device__ __forceinline__ float4 load_b(const BSrc& s, int n, int kk) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < s.N) {
+        int col, rem;
+        if (kk < s.len0p) { col = s.col0 + kk; rem = s.len0 - kk; }
+        else { const int k1 = kk - s.len0p; col = s.col1 + k1; rem = s.len1 - k1; }
+        if (rem > 0) {
+            const float* p = s.w + (int64_t)n * s.ldw + col;
+            if (VEC) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                v.x = p[0];
+                if (rem > 1) v.y = p[1];
+                if (rem > 2) v.z = p[2];
+                if (rem > 3) v.w = p[3];
+            }
+        }
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) flags[slot] = 1;
+    return v;
+}
+
+// acc[ct][rt] += A[16*RT x K] * W'[n0[ct] + 0..15][K]^T, K = len0p + len1p walked 16 at a time.
+template <int RT, int CT, bool VEC>
+__device__ __forceinline__ void wave_gemm(f32x4 (&acc)[2][RT], const ASrc& A, const BSrc& B, const int (&n0)[2]) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, q = lane >> 4;
+    const int T = (B.len0p + B.len1p) >> 4;
+    float4 bq[3][CT];
+    auto ldb = [&](float4 (&dst)[CT], int t) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) dst[c] = load_b<VEC>(B, n0[c] + i, 16 * t + 4 * q);
+    };
+    auto comp = [&](const float4 (&b)[CT], int t) {
+        const int kk = 16 * t;
+        const float* ap;
+        int lda;
+        if (kk < B.len0p) { ap = A.a0 + kk + 4 * q; lda = A.lda0; }
+        else { ap = A.a1 + (kk - B.len0p) + 4 * q; lda = A.lda1; }
+        float4 a[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) a[r] = *reinterpret_cast<const float4*>(ap + (r * 16 + i) * lda);
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[c][r] = mfma4(a[r].x, b[c].x, acc[c][r]);
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[c][r] = mfma4(a[r].y, b[c].y, acc[c][r]);
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[c][r] = mfma4(a[r].z, b[c].z, acc[c][r]);
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[c][r] = mfma4(a[r].w, b[c].w, acc[c][r]);
+    };
+    if (T <= 0) return;
+    ldb(bq[0], 0);
+    if (T > 1) ldb(bq[1], 1);
+    for (int t = 0; t < T; t += 3) {
+        if (t + 2 < T) ldb(bq[2], t + 2);
+        comp(bq[0], t);
+        if (t + 1 < T) {
+            if (t + 3 < T) ldb(bq[0], t + 3);
+            comp(bq[1], t + 1);
+        }
+        if (t + 2 < T) {
+            if (t + 4 < T) ldb(bq[1], t + 4);
+            comp(bq[2], t + 2);
+        }
+    }
+}
+
+template <int RT>
+__device__ __forceinline__ void wave_gemm_any(f32x4 (&acc)[2][RT], const ASrc& A, const BSrc& B, const int (&n0)[2]) {
+    const bool two = n0[1] < B.N;
+    if (B.vec) {
+        if (two) wave_gemm<RT, 2, true>(acc, A, B, n0); else wave_gemm<RT, 1, true>(acc, A, B, n0);
+    } else {
+        if (two) wave_gemm<RT, 2, false>(acc, A, B, n0); else wave_gemm<RT, 1, false>(acc, A, B, n0);
+    }
+}
+
+template <int RT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[2][RT]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+template <int RT, class Epi>
+__device__ __forceinline__ void run_epilogue(const f32x4 (&acc)[2][RT], const int (&n0)[2], int N, Epi&& epi) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (n0[c] < N) {
+            const int col = n0[c] + i;
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) epi(r * 16 + q * 4 + k, col, acc[c][r][k]);
+        }
+    }
+}
+
+// out[rows x N] = A * W'^T with A resident in LDS; epilogue per element (col may be >= N: skip there)
+template <int RT, class Epi>
+__device__ __forceinline__ void layer_nt(const ASrc& A, const BSrc& B, Epi&& epi) {
+    const int wave = threadIdx.x >> 6;
+    const int ntiles = (B.N + 15) >> 4;
+    for (int base = 0; base < ntiles; base += 8) {
+        const int n0[2] = {16 * (base + wave), 16 * (base + wave + 4)};
+        if (n0[0] >= B.N) continue;
+        f32x4 acc[2][RT];
+        zero_acc<RT>(acc);
+        wave_gemm_any<RT>(acc, A, B, n0);
+        run_epilogue<RT>(acc, n0, B.N, epi);
+    }
+}
+
+// Copy a [nrows x ncols] global tile (row stride ld_src) into an LDS image whose rows hold
+// round_up(ncols,16) floats (zero filled), rows >= nrows zero filled.  Work split without
+// divisions: a wave takes rows wave, wave+4, ...; lanes take 4 columns each.
+__device__ __forceinline__ void stage_rows(float* dst, int ld_dst, const float* __restrict__ src, int64_t ld_src,
+                                           int nrows, int rows_pad, int ncols) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cpad = round_up(ncols, 16);
+    const bool vec = ((ld_src & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    for (int r = wave; r < rows_pad; r += 4) {
+        for (int c = lane * 4; c < cpad; c += 256) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nrows && c < ncols) {
+                const float* p = src + (int64_t)r * ld_src + c;
+                if (vec && c + 3 < ncols) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    v.x = p[0];
+                    if (c + 1 < ncols) v.y = p[1];
+                    if (c + 2 < ncols) v.z = p[2];
+                    if (c + 3 < ncols) v.w = p[3];
+                }
+            }
+            *reinterpret_cast<float4*>(dst + r * ld_dst + c) = v;
+        }
+    }
+}
+
+// LDS tile [nrows x ncols] -> global (row stride = ncols), coalesced
+__device__ __forceinline__ void store_rows(float* __restrict__ dst, const float* src, int ld_src, int nrows, int ncols) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = ((ncols & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    for (int r = wave; r < nrows; r += 4) {
+        if (vec) {
+            for (int c = lane * 4; c < ncols; c += 256)
+                *reinterpret_cast<float4*>(dst + (int64_t)r * ncols + c) = *reinterpret_cast<const float4*>(src + r * ld_src + c);
+        } else {
+            for (int c = lane; c < ncols; c += 64) dst[(int64_t)r * ncols + c] = src[r * ld_src + c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_prepare: blocks [0, scan_blocks): nan_flags[slot] = 1 if data slot has a NaN (flags are zero
+// on entry: plan creation zeroes them and k_reduce re-zeroes them after their last reader);
+// blocks [scan_blocks, ...): 32x32 tile transposes of the weights the backward chain needs.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_prepare(const DevPlan* __restrict__ P, mmn_batch b, int scan_blocks,
+                                                int blocks_per_slot) {
+    const DevPlan& p = *P;
+    if ((int)blockIdx.x < scan_blocks) {
+        const int t = blockIdx.x / blocks_per_slot;          // sequence position
+        const int part = blockIdx.x - t * blocks_per_slot;
+        const int slot = b.seq_data[t];
+        const int F = p.m.enc[b.seq_enc[t]].n_features;
+        const float* x = b.x[slot];
+        const int64_t ld = b.ldx[slot];
+        const int f4 = (F + 3) >> 2;
+        const int64_t total = (int64_t)b.batch * f4;
+        const bool vec = ((ld & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+        bool bad = false;
+        for (int64_t idx = (int64_t)part * NT + threadIdx.x; idx < total; idx += (int64_t)blocks_per_slot * NT) {
+            const int64_t r = idx / f4;
+            const int c = (int)(idx - r * f4) << 2;
+            const float* q = x + r * ld + c;
+            if (vec) {
+                const float4 v = *reinterpret_cast<const float4*>(q);
+                bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+            } else {
+                for (int k = 0; k < 4 && c + k < F; ++k) bad |= (q[k] != q[k]);
+            }
+        }
+        if (__any(bad) && (threadIdx.x & 63) == 0) const_cast<int32_t*>(b.nan_flags)[slot] = 1;
+        return;
+    }
+    __shared__ float tile[32][33];
+    const TItem it = p.titems[blockIdx.x - scan_blocks];
+    const TTask tk = p.ttasks[it.task];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = it.r0 + ty + 8 * k, c = it.c0 + tx;
+        tile[ty + 8 * k][tx] = (r < tk.rows && c < tk.cols) ? tk.src[(int64_t)r * tk.ld_src + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = it.c0 + ty + 8 * k, r = it.r0 + tx;      // dst[c][r] = src[r][c]
+        if (r < tk.rows && c < tk.cols) tk.dst[(int64_t)c * tk.ld_dst + r] = tile[tx][ty + 8 * k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -280,41 +378,67 @@ __global__ __launch_bounds__(NT) void k_nan_scan(mmn_batch b, const mmn_model* _
 struct DecodeCtx {
     const DevPlan* p;
     const mmn_batch* b;
-    float* sDec; float* sZ;
+    float* sZ;
+    float4 wd[4];          // this wave's decoder-weight fragments (constant for the whole kernel)
     int row0, nrows, tile;
     float cL;
     int want_grads;
 };
 
-__device__ __forceinline__ void decode_state(const DecodeCtx& c, const float* sS, int grid_row) {
-    const DevPlan& p = *c.p;
-    const int S8 = p.S8, ldS = p.ldS, D = p.D, R = p.R;
+__device__ __forceinline__ void load_decoder_frags(const DevPlan& p, float4 (&wd)[4]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    // z[32 x 16] = sS[32 x S] * sDec[16 x S]^T, contraction split over the four waves
-    f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
-    const int kq = (((S8 >> 3) + 3) >> 2) << 3;
-    const int kb = wave * kq, ke = min(S8, kb + kq);
-    const float* a0p = sS + i * ldS + 2 * q;
-    const float* a1p = a0p + 16 * ldS;
-    const float* bp = c.sDec + i * ldS + 2 * q;
-    for (int k = kb; k < ke; k += 8) {
-        const float2 a0 = *reinterpret_cast<const float2*>(a0p + k);
-        const float2 a1 = *reinterpret_cast<const float2*>(a1p + k);
-        const float2 bb = *reinterpret_cast<const float2*>(bp + k);
-        z0 = mfma4(a0.x, bb.x, z0);
-        z1 = mfma4(a1.x, bb.x, z1);
-        z0 = mfma4(a0.y, bb.y, z0);
-        z1 = mfma4(a1.y, bb.y, z1);
+    const int S = p.S, Tdec = p.S16 >> 4, KD = (Tdec + 3) >> 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int t = wave * KD + j;
+        if (j < KD && t < Tdec && i < 2 * p.D) {
+            const float* w = p.m.dec[i >> 1].w + (i & 1) * S;
+            const int k = 16 * t + 4 * q;
+            if (k < S) v.x = w[k];
+            if (k + 1 < S) v.y = w[k + 1];
+            if (k + 2 < S) v.z = w[k + 2];
+            if (k + 3 < S) v.w = w[k + 3];
+        }
+        wd[j] = v;
+    }
+}
+
+template <int RT>
+__device__ __forceinline__ void decode_state(const DecodeCtx& c, const float* sS, int grid_row) {
+    constexpr int TB = 16 * RT;
+    const DevPlan& p = *c.p;
+    const int ldS = p.ldS, D = p.D, R = p.R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int Tdec = p.S16 >> 4, KD = (Tdec + 3) >> 2;
+    // z[TB x 16] = sS[TB x S] * Wdec[16 x S]^T, contraction split over the four waves
+    f32x4 z[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) z[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = wave * KD + j;
+        if (j < KD && t < Tdec) {
+            const float4 bb = c.wd[j];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const float4 a = *reinterpret_cast<const float4*>(sS + (r * 16 + i) * ldS + 16 * t + 4 * q);
+                z[r] = mfma4(a.x, bb.x, z[r]);
+                z[r] = mfma4(a.y, bb.y, z[r]);
+                z[r] = mfma4(a.z, bb.z, z[r]);
+                z[r] = mfma4(a.w, bb.w, z[r]);
+            }
+        }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        c.sZ[(wave * 32 + q * 4 + r) * 16 + i] = z0[r];
-        c.sZ[(wave * 32 + 16 + q * 4 + r) * 16 + i] = z1[r];
-    }
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c.sZ[(wave * TB + r * 16 + q * 4 + k) * 16 + i] = z[r][k];
     __syncthreads();
     const int t = threadIdx.x;
-    const int row = t & 31, d = t >> 5;
+    const int row = t & (TB - 1), d = t / TB;
     float lossv = 0.f;
     int correct = 0, tp = 0, tn = 0, fp = 0, fn = 0;
     if (d < D && row < c.nrows) {
@@ -322,8 +446,8 @@ __device__ __forceinline__ void decode_state(const DecodeCtx& c, const float* sS
         float za = bd[0], zb = bd[1];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            za += c.sZ[(w * 32 + row) * 16 + 2 * d];
-            zb += c.sZ[(w * 32 + row) * 16 + 2 * d + 1];
+            za += c.sZ[(w * TB + row) * 16 + 2 * d];
+            zb += c.sZ[(w * TB + row) * 16 + 2 * d + 1];
         }
         const int64_t grow = (int64_t)c.row0 + row;
         const int y = (int)c.b->y[grow * D + d];
@@ -346,81 +470,68 @@ __device__ __forceinline__ void decode_state(const DecodeCtx& c, const float* sS
         }
     }
 #pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) lossv += __shfl_xor(lossv, off);
+    for (int off = TB / 2; off >= 1; off >>= 1) lossv += __shfl_xor(lossv, off);
     const unsigned long long mc = __ballot(correct), mtp = __ballot(tp), mtn = __ballot(tn),
                              mfp = __ballot(fp), mfn = __ballot(fn);
-    if ((t & 31) == 0 && d < D) {
-        const int sh = (lane >= 32) ? 32 : 0;
+    if (row == 0 && d < D) {
+        const int sh = lane & ~(TB - 1);
+        const unsigned long long msk = (TB == 32) ? 0xFFFFFFFFull : 0xFFFFull;
         const int64_t cell = (int64_t)c.tile * (R * D) + grid_row * D + d;
         p.lossp[cell] = lossv;
         int32_t* cp = p.cntp + cell * 5;
-        cp[0] = __popc((unsigned)(mc >> sh));
-        cp[1] = __popc((unsigned)(mtp >> sh));
-        cp[2] = __popc((unsigned)(mtn >> sh));
-        cp[3] = __popc((unsigned)(mfp >> sh));
-        cp[4] = __popc((unsigned)(mfn >> sh));
+        cp[0] = __popcll((mc >> sh) & msk);
+        cp[1] = __popcll((mtp >> sh) & msk);
+        cp[2] = __popcll((mtn >> sh) & msk);
+        cp[3] = __popcll((mfp >> sh) & msk);
+        cp[4] = __popcll((mfn >> sh) & msk);
     }
     __syncthreads();
 }
 
 // LDS carve of the two chain kernels (floats)
-struct ChainLds {
-    int sS0, sS1, sDiff, sDec, sAct0, sAct1, sX, sW, sZ, sRed, total;
-};
-__host__ __device__ inline ChainLds chain_lds(int ldS, int ldAct) {
+struct ChainLds { int sS0, sS1, sDiff, sH0, sH1, sX, sZ, sRed, total; };
+__host__ __device__ inline ChainLds chain_lds(int TB, int ldS, int ldH) {
     ChainLds L;
     int o = 0;
     L.sS0 = o; o += TB * ldS;
     L.sS1 = o; o += TB * ldS;
     L.sDiff = o; o += TB * ldS;
-    L.sDec = o; o += 16 * ldS;
-    L.sAct0 = o; o += TB * ldAct;
-    L.sAct1 = o; o += TB * ldAct;
-    L.sX = o; o += TB * LDW;
-    L.sW = o; o += 128 * LDW;
-    L.sZ = o; o += 4 * 32 * 16;
+    L.sH0 = o; o += TB * ldH;
+    L.sH1 = o; o += TB * ldH;
+    L.sX = o; o += TB * LDX;
+    L.sZ = o; o += 4 * TB * 16;      // also holds the dz tile (TB x LDZ) in the backward kernel
     L.sRed = o; o += 64;
     L.total = o;
     return L;
 }
 
-__device__ __forceinline__ void fill_decoder_image(const DevPlan& p, float* sDec) {
-    const int S = p.S, ldS = p.ldS, D = p.D;
-    for (int idx = threadIdx.x; idx < 16 * ldS; idx += NT) {
-        const int n = idx / ldS, k = idx - n * ldS;
-        float v = 0.f;
-        if (n < 2 * D && k < S) v = p.m.dec[n >> 1].w[(n & 1) * S + k];
-        sDec[idx] = v;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // k_chain_fwd
 // ------------------------------------------------------------------------------------------------
+template <int RT>
 __global__ __launch_bounds__(NT) void k_chain_fwd(const DevPlan* __restrict__ P, mmn_batch b, float cL,
                                                   int want_grads) {
+    constexpr int TB = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevPlan& p = *P;
-    const int S = p.S, E = p.E, ldS = p.ldS, ldA = p.ldAct;
-    const ChainLds L = chain_lds(ldS, ldA);
-    float* sCur = smem + L.sS0;
-    float* sNext = smem + L.sS1;
-    float* sDec = smem + L.sDec;
-    float* sAct[2] = {smem + L.sAct0, smem + L.sAct1};
+    const int S = p.S, E = p.E, ldS = p.ldS, ldH = p.ldH;
+    const ChainLds L = chain_lds(TB, ldS, ldH);
+    float* sS[2] = {smem + L.sS0, smem + L.sS1};
+    float* sH[2] = {smem + L.sH0, smem + L.sH1};
     float* sX = smem + L.sX;
-    float* sW = smem + L.sW;
     float* sRed = smem + L.sRed;
     const int tile = blockIdx.x;
     const int row0 = tile * TB;
     const int nrows = min(TB, b.batch - row0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    fill_decoder_image(p, sDec);
     for (int idx = threadIdx.x; idx < TB * ldS; idx += NT) {
         const int k = idx % ldS;
-        sCur[idx] = k < S ? p.m.init_state[k] : 0.f;       // state.py:29-32 (tile, never materialised)
-        sNext[idx] = 0.f;
+        sS[0][idx] = k < S ? p.m.init_state[k] : 0.f;       // state.py:29-32 (tile, never materialised)
+        sS[1][idx] = 0.f;
     }
+    for (int idx = threadIdx.x; idx < TB * ldH; idx += NT) { sH[0][idx] = 0.f; sH[1][idx] = 0.f; }
+    for (int idx = threadIdx.x; idx < TB * LDX; idx += NT) sX[idx] = 0.f;
     if (tile == 0 && threadIdx.x == 0) {                   // which state rows exist this step
         p.exec_flags[0] = 1;
         for (int e = 0; e < E; ++e) p.exec_flags[e + 1] = 0;
@@ -433,76 +544,124 @@ __global__ __launch_bounds__(NT) void k_chain_fwd(const DevPlan* __restrict__ P,
             prev = e + 1;
         }
     }
+    DecodeCtx dc;
+    dc.p = P; dc.b = &b; dc.sZ = smem + L.sZ; dc.row0 = row0; dc.nrows = nrows; dc.tile = tile; dc.cL = cL;
+    dc.want_grads = want_grads;
+    load_decoder_frags(p, dc.wd);
     __syncthreads();
 
-    DecodeCtx dc{P, &b, sDec, smem + L.sZ, row0, nrows, tile, cL, want_grads};
-    decode_state(dc, sCur, 0);
+    int cur = 0;
+    decode_state<RT>(dc, sS[cur], 0);
 
     for (int t = 0; t < b.n_seq; ++t) {
         const int slot = b.seq_data[t];
         if (!slot_present(b, slot)) continue;              // multimodn.py:168-169
         const int e = b.seq_enc[t];
         const mmn_encoder& enc = p.m.enc[e];
-        const int nl = enc.n_layers;
+        const int nl = enc.n_layers, Lh = nl - 1;
+        const int F = enc.n_features;
         const float* xg = b.x[slot] + (int64_t)row0 * b.ldx[slot];
+        const int64_t ldx = b.ldx[slot];
+        const int akind = enc.activation;
+
         // hidden layers: h = act(W h + b) on x only (mlp_encoder.py:75-76)
-        for (int l = 0; l + 1 < nl; ++l) {
+        for (int l = 0; l < Lh; ++l) {
             const mmn_linear& lin = enc.layer[l];
-            const int N = lin.out_dim, N8 = round_up(N, 8);
-            ASeg seg[1];
-            if (l == 0) seg[0] = ASeg{xg, b.ldx[slot], nullptr, 0, lin.in_dim, 0};
-            else seg[0] = ASeg{nullptr, 0, sAct[(l - 1) & 1], ldA, lin.in_dim, 0};
-            float* out = sAct[l & 1];
-            float* hid_g = want_grads ? p.hid + p.hid_off[e][l] + (int64_t)row0 * N : nullptr;
+            const int N = lin.out_dim;
+            float* out = sH[(Lh - 1 - l) & 1];
             const float* bias = lin.b;
-            const int akind = enc.activation;
-            linear_nt(lin.w, lin.in_dim, N, seg, 1, nrows, sX, sW, [&](int row, int col, float v) {
-                if (col < N8) {
-                    float h = 0.f;
-                    if (col < N) {
-                        h = act_fwd(v + bias[col], akind);
-                        if (hid_g && row < nrows) hid_g[(int64_t)row * N + col] = h;
+            auto epi = [&](int row, int col, float v) {
+                if (col < N) out[row * ldH + col] = act_fwd(v + bias[col], akind);
+            };
+            if (l == 0) {
+                const int ntiles = (N + 15) >> 4;
+                for (int base = 0; base < ntiles; base += 8) {
+                    const int n0[2] = {16 * (base + wave), 16 * (base + wave + 4)};
+                    f32x4 acc[2][RT];
+                    zero_acc<RT>(acc);
+                    for (int xc = 0; xc < F; xc += XCH) {
+                        const int kw = min(XCH, F - xc);
+                        stage_rows(sX, LDX, xg + xc, ldx, nrows, TB, kw);
+                        __syncthreads();
+                        if (n0[0] < N) {
+                            const ASrc A{sX, LDX, sX, LDX};
+                            const BSrc B = make_bsrc(lin.w, lin.in_dim, N, kw, xc, 0, 0);
+                            wave_gemm_any<RT>(acc, A, B, n0);
+                        }
+                        __syncthreads();
                     }
-                    out[row * ldA + col] = h;
+                    if (n0[0] < N) run_epilogue<RT>(acc, n0, N, epi);
                 }
-            });
+            } else {
+                const float* in = sH[(Lh - l) & 1];
+                const ASrc A{in, ldH, in, ldH};
+                const BSrc B = make_bsrc(lin.w, lin.in_dim, N, lin.in_dim, 0, 0, 0);
+                layer_nt<RT>(A, B, epi);
+            }
             __syncthreads();
+            if (want_grads) store_rows(p.hid + p.hid_off[e][l] + (int64_t)row0 * N, out, ldH, nrows, N);
         }
-        // state update: s' = W [h ; s] + b, no activation (mlp_encoder.py:78)
+        // state update: s' = W [h ; s] + b, no activation (mlp_encoder.py:78); the contraction
+        // runs over the state columns first, then the h columns
         {
             const mmn_linear& lin = enc.layer[nl - 1];
             const int HL = lin.in_dim - S;
-            ASeg seg[2];
-            if (nl == 1) seg[0] = ASeg{xg, b.ldx[slot], nullptr, 0, HL, 0};
-            else seg[0] = ASeg{nullptr, 0, sAct[(nl - 2) & 1], ldA, HL, 0};
-            seg[1] = ASeg{nullptr, 0, sCur, ldS, S, HL};
-            float* st_g = want_grads ? p.states + ((int64_t)e * p.maxB + row0) * S : nullptr;
             const float* bias = lin.b;
+            const float* sC = sS[cur];
+            float* sN = sS[cur ^ 1];
             float scacc = 0.f;
-            linear_nt(lin.w, lin.in_dim, S, seg, 2, nrows, sX, sW, [&](int row, int col, float v) {
+            auto epi = [&](int row, int col, float v) {
                 if (col < S) {
                     const float ns = v + bias[col];
-                    const float dlt = ns - sCur[row * ldS + col];
-                    if (row < nrows) {
-                        scacc += dlt * dlt;                               // multimodn.py:174
-                        if (st_g) st_g[(int64_t)row * S + col] = ns;
-                    }
-                    sNext[row * ldS + col] = ns;
+                    const float dlt = ns - sC[row * ldS + col];
+                    if (row < nrows) scacc += dlt * dlt;              // multimodn.py:174
+                    sN[row * ldS + col] = ns;
                 }
-            });
+            };
+            if (Lh > 0) {
+                const ASrc A{sC, ldS, sH[0], ldH};
+                const BSrc B = make_bsrc(lin.w, lin.in_dim, S, S, HL, HL, 0);
+                layer_nt<RT>(A, B, epi);
+            } else {
+                const int ntiles = (S + 15) >> 4;
+                for (int base = 0; base < ntiles; base += 8) {
+                    const int n0[2] = {16 * (base + wave), 16 * (base + wave + 4)};
+                    f32x4 acc[2][RT];
+                    zero_acc<RT>(acc);
+                    if (n0[0] < S) {
+                        const ASrc A{sC, ldS, sC, ldS};
+                        const BSrc B = make_bsrc(lin.w, lin.in_dim, S, S, HL, 0, 0);
+                        wave_gemm_any<RT>(acc, A, B, n0);
+                    }
+                    for (int xc = 0; xc < F; xc += XCH) {
+                        const int kw = min(XCH, F - xc);
+                        stage_rows(sX, LDX, xg + xc, ldx, nrows, TB, kw);
+                        __syncthreads();
+                        if (n0[0] < S) {
+                            const ASrc A{sX, LDX, sX, LDX};
+                            const BSrc B = make_bsrc(lin.w, lin.in_dim, S, kw, xc, 0, 0);
+                            wave_gemm_any<RT>(acc, A, B, n0);
+                        }
+                        __syncthreads();
+                    }
+                    if (n0[0] < S) run_epilogue<RT>(acc, n0, S, epi);
+                }
+            }
             scacc = wave_sum(scacc);
             if (lane == 0) sRed[wave] = scacc;
             __syncthreads();
             if (threadIdx.x == 0) p.scp[(int64_t)tile * E + e] = sRed[0] + sRed[1] + sRed[2] + sRed[3];
-            float* tmp = sCur; sCur = sNext; sNext = tmp;
+            if (want_grads) store_rows(p.states + ((int64_t)e * p.maxB + row0) * S, sN, ldS, nrows, S);
+            cur ^= 1;
         }
-        decode_state(dc, sCur, e + 1);
+        decode_state<RT>(dc, sS[cur], e + 1);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_chain_bwd
 // ------------------------------------------------------------------------------------------------
+template <int TB>
 __device__ __forceinline__ void load_dz_tile(const DevPlan& p, float* sDz, int grid_row, int row0, int nrows) {
     const int D2 = 2 * p.D;
     for (int idx = threadIdx.x; idx < TB * 16; idx += NT) {
@@ -513,54 +672,46 @@ __device__ __forceinline__ void load_dz_tile(const DevPlan& p, float* sDz, int g
     }
 }
 
-// sG[row][col] += extra(row, col) + sum_n sDz[row][n] * sDec[n][col]
-template <class Extra>
-__device__ __forceinline__ void add_decoder_grad(const DevPlan& p, float* sG, const float* sDz,
-                                                 const float* sDec, Extra&& extra) {
-    const int S = p.S, ldS = p.ldS;
+// dpre = dh .* act'(h): sBuf (raw dh) -> sBuf and global dpre, h read from global hid (coalesced)
+__device__ __forceinline__ void apply_act_grad(float* sBuf, int ld, const float* __restrict__ hid_g,
+                                               float* __restrict__ dpre_g, int nrows, int rows_pad, int H, int akind) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, q = lane >> 4;
-    const int n8 = round_up(2 * p.D, 8);
-    for (int cg = 0; cg < S; cg += 64) {
-        const int cpad = min(64, round_up(S - cg, 16));
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        mma_nn(acc, sDz, LDZ, 0, n8, sDec + cg, ldS, cpad);
-        if (wave * 16 < cpad) {
-            const int col = cg + wave * 16 + i;
-            if (col < S) {
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = rt * 16 + q * 4 + r;
-                        sG[row * ldS + col] += acc[rt][r] + extra(row, col);
-                    }
+    for (int r = wave; r < rows_pad; r += 4) {
+        for (int c = lane; c < H; c += 64) {
+            float dp = 0.f;
+            if (r < nrows) {
+                dp = sBuf[r * ld + c] * act_grad_from_out(hid_g[(int64_t)r * H + c], akind);
+                dpre_g[(int64_t)r * H + c] = dp;
             }
+            sBuf[r * ld + c] = dp;
         }
     }
 }
 
+template <int RT>
 __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P, mmn_batch b, float cS) {
+    constexpr int TB = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevPlan& p = *P;
-    const int S = p.S, E = p.E, ldS = p.ldS, ldA = p.ldAct;
-    const ChainLds L = chain_lds(ldS, ldA);
-    float* sG = smem + L.sS0;
-    float* sG2 = smem + L.sS1;
+    const int S = p.S, E = p.E, ldS = p.ldS, ldH = p.ldH;
+    const ChainLds L = chain_lds(TB, ldS, ldH);
+    float* sG[2] = {smem + L.sS0, smem + L.sS1};
     float* sDiff = smem + L.sDiff;
-    float* sDec = smem + L.sDec;
-    float* sAct[2] = {smem + L.sAct0, smem + L.sAct1};
-    float* sW = smem + L.sW;
+    float* sH[2] = {smem + L.sH0, smem + L.sH1};
     float* sDz = smem + L.sZ;
     const int tile = blockIdx.x;
     const int row0 = tile * TB;
     const int nrows = min(TB, b.batch - row0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, q = lane >> 4;
 
-    fill_decoder_image(p, sDec);
-    for (int idx = threadIdx.x; idx < TB * ldS; idx += NT) { sG[idx] = 0.f; sG2[idx] = 0.f; sDiff[idx] = 0.f; }
+    for (int idx = threadIdx.x; idx < TB * ldS; idx += NT) { sG[0][idx] = 0.f; sG[1][idx] = 0.f; sDiff[idx] = 0.f; }
+    for (int idx = threadIdx.x; idx < TB * ldH; idx += NT) { sH[0][idx] = 0.f; sH[1][idx] = 0.f; }
+    for (int idx = threadIdx.x; idx < TB * LDZ; idx += NT) sDz[idx] = 0.f;
     __syncthreads();
+
+    const ASrc Adz{sDz, LDZ, sDz, LDZ};
+    const BSrc Bdz = make_bsrc(p.wdT, WT_LD, S, 16, 0, 0, 0);          // W' = Wdec^T [S x 16], zero padded
+    int cur = 0;
 
     for (int t = b.n_seq - 1; t >= 0; --t) {
         const int slot = b.seq_data[t];
@@ -574,133 +725,84 @@ __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P,
         const mmn_linear& last = enc.layer[nl - 1];
         const int HL = last.in_dim - S;
         const int akind = enc.activation;
+        float* G = sG[cur];
+        float* Gn = sG[cur ^ 1];
 
-        // diff = s_out - s_in, dz tile of grid row e+1
+        // diff = s_out - s_in (coalesced), dz tile of grid row e+1
         {
             const float* so = p.states + ((int64_t)e * p.maxB + row0) * S;
             const float* si = prev_row ? p.states + ((int64_t)(prev_row - 1) * p.maxB + row0) * S : nullptr;
-            for (int idx = threadIdx.x; idx < TB * S; idx += NT) {
-                const int row = idx / S, col = idx - row * S;
-                float v = 0.f;
-                if (row < nrows) {
-                    const float a = so[(int64_t)row * S + col];
-                    const float c = si ? si[(int64_t)row * S + col] : p.m.init_state[col];
-                    v = a - c;
+            for (int r = wave; r < nrows; r += 4)
+                for (int c = lane; c < S; c += 64) {
+                    const float a = so[(int64_t)r * S + c];
+                    const float d = si ? si[(int64_t)r * S + c] : p.m.init_state[c];
+                    sDiff[r * ldS + c] = a - d;
                 }
-                sDiff[row * ldS + col] = v;
-            }
-            load_dz_tile(p, sDz, e + 1, row0, nrows);
-            for (int idx = threadIdx.x; idx < TB * ldA; idx += NT) { sAct[0][idx] = 0.f; sAct[1][idx] = 0.f; }
+            load_dz_tile<TB>(p, sDz, e + 1, row0, nrows);
         }
         __syncthreads();
         // G_out = carry + decoder grad of row e+1 + cS * diff
-        add_decoder_grad(p, sG, sDz, sDec, [&](int row, int col) { return cS * sDiff[row * ldS + col]; });
+        layer_nt<RT>(Adz, Bdz, [&](int row, int col, float v) {
+            if (col < S) G[row * ldS + col] += v + cS * sDiff[row * ldS + col];
+        });
         __syncthreads();
+        store_rows(p.dS + ((int64_t)e * p.maxB + row0) * S, G, ldS, nrows, S);
+        // [dh | carry] = G_out * W_last : W' = W_last^T [(HL+S) x S]; no grad flows to x (Lh == 0)
         {
-            float* dS = p.dS + ((int64_t)e * p.maxB + row0) * S;
-            for (int idx = threadIdx.x; idx < nrows * S; idx += NT) {
-                const int row = idx / S, col = idx - row * S;
-                dS[(int64_t)row * S + col] = sG[row * ldS + col];
-            }
-        }
-        // dcat = G_out * W_last : columns [0,HL) -> dh, [HL, HL+S) -> carry
-        {
-            const int ldw_g = last.in_dim;
-            const int c_begin = Lh == 0 ? HL : 0;                  // no grad flows to x
-            const float* hid_g = Lh ? p.hid + p.hid_off[e][Lh - 1] + (int64_t)row0 * HL : nullptr;
-            float* dpre_g = Lh ? p.dpre + p.hid_off[e][Lh - 1] + (int64_t)row0 * HL : nullptr;
-            float* dact = sAct[0];
-            for (int kc = c_begin; kc < HL + S; kc += 64) {
-                const int kw = min(64, HL + S - kc), kpad = round_up(kw, 16);
-                f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-                for (int nc = 0; nc < S; nc += 128) {
-                    const int nlen = min(128, S - nc), nlen8 = round_up(nlen, 8);
-                    stage_tile(sW, LDW, last.w + (int64_t)nc * ldw_g + kc, ldw_g, nlen, nlen8, kw, kpad);
-                    __syncthreads();
-                    mma_nn(acc, sG, ldS, nc, nlen8, sW, LDW, kpad);
-                    __syncthreads();
-                }
-                if (wave * 16 < kpad) {
-                    const int col = kc + wave * 16 + i;
-#pragma unroll
-                    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = rt * 16 + q * 4 + r;
-                            const float v = acc[rt][r];
-                            if (col < HL) {
-                                float dp = 0.f;
-                                if (row < nrows) {
-                                    dp = v * act_grad_from_out(hid_g[(int64_t)row * HL + col], akind);
-                                    dpre_g[(int64_t)row * HL + col] = dp;
-                                }
-                                dact[row * ldA + col] = dp;
-                            } else if (col < HL + S) {
-                                const int j = col - HL;
-                                sG2[row * ldS + j] = v - cS * sDiff[row * ldS + j];
-                            }
-                        }
-                }
+            const float* wT = p.wT + p.wt_off[e][nl - 1];
+            const ASrc A{G, ldS, G, ldS};
+            float* dh = sH[0];
+            if (Lh > 0) {
+                const BSrc B = make_bsrc(wT, S, HL + S, S, 0, 0, 0);
+                layer_nt<RT>(A, B, [&](int row, int col, float v) {
+                    if (col < HL) dh[row * ldH + col] = v;
+                    else if (col < HL + S) Gn[row * ldS + (col - HL)] = v - cS * sDiff[row * ldS + (col - HL)];
+                });
+            } else {
+                const BSrc B = make_bsrc(wT + (int64_t)HL * S, S, S, S, 0, 0, 0);
+                layer_nt<RT>(A, B, [&](int row, int col, float v) {
+                    if (col < S) Gn[row * ldS + col] = v - cS * sDiff[row * ldS + col];
+                });
             }
         }
         __syncthreads();
-        // hidden layers, last to first: dpre_{l-1} = (dpre_l * W_l) .* act'(h_{l-1})
-        for (int l = Lh - 1; l >= 1; --l) {
-            const mmn_linear& lin = enc.layer[l];
-            const int Hl = lin.out_dim, Hp = lin.in_dim;
-            const float* cur = sAct[(Lh - 1 - l) & 1];
-            float* nxt = sAct[(Lh - l) & 1];
-            const float* hid_g = p.hid + p.hid_off[e][l - 1] + (int64_t)row0 * Hp;
-            float* dpre_g = p.dpre + p.hid_off[e][l - 1] + (int64_t)row0 * Hp;
-            for (int idx = threadIdx.x; idx < TB * ldA; idx += NT) nxt[idx] = 0.f;
+        // hidden layers, last to first: dpre_l = dh_l .* act'(h_l);  dh_{l-1} = dpre_l * W_l
+        for (int l = Lh - 1; l >= 0; --l) {
+            const int Hl = enc.layer[l].out_dim;
+            float* cbuf = sH[(Lh - 1 - l) & 1];
+            apply_act_grad(cbuf, ldH, p.hid + p.hid_off[e][l] + (int64_t)row0 * Hl,
+                           p.dpre + p.hid_off[e][l] + (int64_t)row0 * Hl, nrows, TB, Hl, akind);
             __syncthreads();
-            for (int kc = 0; kc < Hp; kc += 64) {
-                const int kw = min(64, Hp - kc), kpad = round_up(kw, 16);
-                f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-                for (int nc = 0; nc < Hl; nc += 128) {
-                    const int nlen = min(128, Hl - nc), nlen8 = round_up(nlen, 8);
-                    stage_tile(sW, LDW, lin.w + (int64_t)nc * Hp + kc, Hp, nlen, nlen8, kw, kpad);
-                    __syncthreads();
-                    mma_nn(acc, cur, ldA, nc, nlen8, sW, LDW, kpad);
-                    __syncthreads();
-                }
-                if (wave * 16 < kpad) {
-                    const int col = kc + wave * 16 + i;
-                    if (col < Hp) {
-#pragma unroll
-                        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = rt * 16 + q * 4 + r;
-                                float dp = 0.f;
-                                if (row < nrows) {
-                                    dp = acc[rt][r] * act_grad_from_out(hid_g[(int64_t)row * Hp + col], akind);
-                                    dpre_g[(int64_t)row * Hp + col] = dp;
-                                }
-                                nxt[row * ldA + col] = dp;
-                            }
-                    }
-                }
-            }
+            if (l == 0) break;
+            const int Hp = enc.layer[l].in_dim;
+            float* nbuf = sH[(Lh - l) & 1];
+            const ASrc A{cbuf, ldH, cbuf, ldH};
+            const BSrc B = make_bsrc(p.wT + p.wt_off[e][l], Hl, Hp, Hl, 0, 0, 0);   // W_l^T [Hp x Hl]
+            layer_nt<RT>(A, B, [&](int row, int col, float v) {
+                if (col < Hp) nbuf[row * ldH + col] = v;
+            });
             __syncthreads();
         }
-        float* tmp = sG; sG = sG2; sG2 = tmp;      // carry becomes the incoming gradient
-        __syncthreads();
+        cur ^= 1;
     }
     // row 0: decoders on the init state; dS0 = d loss / d tiled init state
-    load_dz_tile(p, sDz, 0, row0, nrows);
+    float* G = sG[cur];
+    load_dz_tile<TB>(p, sDz, 0, row0, nrows);
     __syncthreads();
-    add_decoder_grad(p, sG, sDz, sDec, [&](int, int) { return 0.f; });
+    layer_nt<RT>(Adz, Bdz, [&](int row, int col, float v) {
+        if (col < S) G[row * ldS + col] += v;
+    });
     __syncthreads();
-    float* dS0 = p.dS + ((int64_t)E * p.maxB + row0) * S;
-    for (int idx = threadIdx.x; idx < nrows * S; idx += NT) {
-        const int row = idx / S, col = idx - row * S;
-        dS0[(int64_t)row * S + col] = sG[row * ldS + col];
-    }
+    store_rows(p.dS + ((int64_t)E * p.maxB + row0) * S, G, ldS, nrows, S);
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_wgrad: C[M x ntot] = A[rows x M]^T * [in0 | in1 | 1][rows x ntot] over a row range -> slab
+// k_wgrad: C[M x ncols] = A[rows x M]^T * In[rows x ncols] over a row range -> partial slab.
+// No LDS in the main loop: lane (i, q) loads MT consecutive A columns and NT consecutive In columns
+// of row r+q, i.e. the 16*MT x 16*NT output tile is made of MT x NT INTERLEAVED 16x16 MFMA tiles
+// (tile (c, c') holds rows m0 + MT*i + c and columns n0 + NT*j + c'), so every load instruction
+// reads 4 rows x up to 256 contiguous bytes.  The 4 waves of a workgroup split the row range and
+// are summed through LDS in a fixed order.
 // ------------------------------------------------------------------------------------------------
 struct SrcRef { const float* p; int64_t ld; };
 
@@ -731,86 +833,194 @@ __device__ __forceinline__ SrcRef resolve_in(const DevPlan& p, const mmn_batch& 
     return s;
 }
 
+template <int V>
+__device__ __forceinline__ void load_frag(float (&dst)[V], const float* __restrict__ base, int64_t off, int first,
+                                          int limit, bool row_ok, bool vec_ok) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) dst[k] = 0.f;
+    if (!row_ok || first >= limit) return;
+    const float* ptr = base + off + first;
+    if (V == 4 && vec_ok && first + 3 < limit) {
+        const float4 v = *reinterpret_cast<const float4*>(ptr);
+        dst[0] = v.x; dst[V > 1 ? 1 : 0] = v.y; dst[V > 2 ? 2 : 0] = v.z; dst[V > 3 ? 3 : 0] = v.w;
+    } else if (V == 2 && vec_ok && first + 1 < limit) {
+        const float2 v = *reinterpret_cast<const float2*>(ptr);
+        dst[0] = v.x; dst[V > 1 ? 1 : 0] = v.y;
+    } else {
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            if (first + k < limit) dst[k] = ptr[k];
+    }
+}
+
+template <int MT, int NTL>
+__device__ __forceinline__ void wgrad_tile(const DevPlan& p, const WTask& tk, const WItem& it, const float* Ap, int64_t lda,
+                                           SrcRef in, int ncols, int rb, int re, float* sTile, float* sBias) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int M = tk.M;
+    const bool has_in = it.src != 2;
+    const bool bias = it.bias != 0;
+    f32x4 acc[MT][NTL];
+    f32x4 accb[MT];
+#pragma unroll
+    for (int c = 0; c < MT; ++c) {
+        accb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < NTL; ++d) acc[c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // this wave's quarter of the row range (multiples of 4 rows)
+    const int rq = round_up((re - rb + 3) / 4, 4);
+    const int wb = rb + wave * rq, we = min(re, wb + rq);
+    const bool a_vec = ((lda % MT) == 0) && ((it.m0 % MT) == 0) && ((reinterpret_cast<uintptr_t>(Ap) & (4 * MT - 1)) == 0);
+    const bool i_vec = has_in && ((in.ld % NTL) == 0) && ((it.n0 % NTL) == 0) &&
+                       ((reinterpret_cast<uintptr_t>(in.p) & (4 * NTL - 1)) == 0);
+    const float ones = (i == 0) ? 1.0f : 0.0f;
+    const int mfirst = it.m0 + MT * i, nfirst = it.n0 + NTL * i;
+
+    float a0[MT], b0[NTL], a1[MT], b1[NTL];
+    auto ld = [&](float (&a)[MT], float (&bb)[NTL], int r) {
+        const int row = r + q;
+        const bool ok = row < we;
+        load_frag<MT>(a, Ap, (int64_t)row * lda, mfirst, M, ok, a_vec);
+        if (has_in) load_frag<NTL>(bb, in.p, (int64_t)row * in.ld, nfirst, ncols, ok, i_vec);
+        else {
+#pragma unroll
+            for (int k = 0; k < NTL; ++k) bb[k] = 0.f;
+        }
+    };
+    auto comp = [&](const float (&a)[MT], const float (&bb)[NTL]) {
+        if (has_in) {
+#pragma unroll
+            for (int c = 0; c < MT; ++c)
+#pragma unroll
+                for (int d = 0; d < NTL; ++d) acc[c][d] = mfma4(a[c], bb[d], acc[c][d]);
+        }
+        if (bias) {
+#pragma unroll
+            for (int c = 0; c < MT; ++c) accb[c] = mfma4(a[c], ones, accb[c]);
+        }
+    };
+    if (wb < we) {
+        ld(a0, b0, wb);
+        for (int r = wb; r < we; r += 8) {
+            if (r + 4 < we) ld(a1, b1, r + 4);
+            comp(a0, b0);
+            if (r + 4 < we) {
+                if (r + 8 < we) ld(a0, b0, r + 8);
+                comp(a1, b1);
+            }
+        }
+    }
+    // fixed-order sum of the four waves' tiles through LDS, then one coalesced slab write
+    float* mine = sTile + wave * (64 * TILE_LD);
+#pragma unroll
+    for (int c = 0; c < MT; ++c)
+#pragma unroll
+        for (int d = 0; d < NTL; ++d)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mine[(MT * (4 * q + k) + c) * TILE_LD + NTL * i + d] = acc[c][d][k];
+    if (bias && i == 0) {
+#pragma unroll
+        for (int c = 0; c < MT; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sBias[wave * 64 + MT * (4 * q + k) + c] = accb[c][k];
+    }
+    __syncthreads();
+    float* slab = p.slabs + tk.slab_base + (int64_t)it.ks * tk.pstride;
+    const int ntot = tk.ntot;
+    const int col_off = (it.src == 1 ? tk.k0 : 0) + it.n0;
+    if (has_in) {
+        constexpr int TW = 16 * NTL, TH = 16 * MT;
+        for (int idx = threadIdx.x; idx < TH * TW; idx += NT) {
+            const int ml = idx / TW, nl = idx - ml * TW;
+            const int m = it.m0 + ml, n = it.n0 + nl;
+            if (m < M && n < ncols) {
+                const float* s = sTile + ml * TILE_LD + nl;
+                slab[(int64_t)m * ntot + col_off + nl] =
+                    ((s[0] + s[64 * TILE_LD]) + s[2 * 64 * TILE_LD]) + s[3 * 64 * TILE_LD];
+            }
+        }
+    }
+    if (bias) {
+        for (int ml = threadIdx.x; ml < 16 * MT; ml += NT) {
+            const int m = it.m0 + ml;
+            if (m < M) slab[(int64_t)m * ntot + (ntot - 1)] = ((sBias[ml] + sBias[64 + ml]) + sBias[128 + ml]) + sBias[192 + ml];
+        }
+    }
+}
+
+constexpr int WGRAD_LDS_FLOATS = 4 * 64 * TILE_LD + 4 * 64;
+
 __global__ __launch_bounds__(NT) void k_wgrad(const DevPlan* __restrict__ P, mmn_batch b, int rows_per_split) {
-    __shared__ __attribute__((aligned(16))) float sA[TB * LDW];
-    __shared__ __attribute__((aligned(16))) float sI[TB * LDW];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sTile = smem;
+    float* sBias = smem + 4 * 64 * TILE_LD;
     const DevPlan& p = *P;
     const WItem it = p.items[blockIdx.x];
     const WTask& tk = p.tasks[it.task];
-    const int M = tk.M, ntot = tk.ntot;
-    const int m0 = it.m0, n0 = it.n0;
-    const int mt = min(WG_TILE, M - m0), nt = min(WG_TILE, ntot - n0);
-    float* slab = p.slabs + tk.slab_base + (int64_t)it.ks * tk.pstride;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, q = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int rb = it.ks * rows_per_split, re = min(b.batch, rb + rows_per_split);
-
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    if (p.exec_flags[tk.gate] && rb < re) {
-        const float* Ap; int64_t lda;
-        if (tk.a_kind == A_DPRE) { Ap = p.dpre + p.hid_off[tk.a_enc][tk.a_idx]; lda = M; }
-        else if (tk.a_kind == A_DS) { Ap = p.dS + (int64_t)tk.a_idx * p.maxB * p.S; lda = p.S; }
-        else { Ap = p.dz + (int64_t)tk.a_idx * p.maxB * (2 * p.D); lda = 2 * p.D; }
-        const SrcRef in0 = resolve_in(p, b, tk.in0_kind, tk.in0_enc, tk.in0_idx);
-        const SrcRef in1 = resolve_in(p, b, tk.in1_kind, tk.in0_enc, 0);
-        const int k0 = tk.k0, k01 = tk.k0 + tk.k1;
-        for (int r = rb; r < re; r += TB) {
-            const int nr = min(TB, re - r);
-            stage_tile(sA, LDW, Ap + (int64_t)r * lda + m0, lda, nr, TB, mt, WG_TILE);
-            for (int idx = threadIdx.x; idx < TB * WG_TILE; idx += NT) {
-                const int rr = idx >> 6, c = idx & 63, n = n0 + c;
-                float v = 0.f;
-                if (rr < nr) {
-                    if (n < k0) v = in0.p[(int64_t)(r + rr) * in0.ld + n];
-                    else if (n < k01) v = in1.p[(int64_t)(r + rr) * in1.ld + (n - k0)];
-                    else if (n == k01 && tk.bias) v = 1.0f;
-                }
-                sI[rr * LDW + c] = v;
-            }
-            __syncthreads();
-            const float* ap = sA + (2 * q) * LDW + 32 * wm + i;
-            const float* ip = sI + (2 * q) * LDW + 32 * wn + i;
-#pragma unroll
-            for (int k = 0; k < TB; k += 8) {
-                const float ax0 = ap[k * LDW], ay0 = ap[(k + 1) * LDW];
-                const float ax1 = ap[k * LDW + 16], ay1 = ap[(k + 1) * LDW + 16];
-                const float bx0 = ip[k * LDW], by0 = ip[(k + 1) * LDW];
-                const float bx1 = ip[k * LDW + 16], by1 = ip[(k + 1) * LDW + 16];
-                acc[0][0] = mfma4(ax0, bx0, acc[0][0]);
-                acc[0][1] = mfma4(ax0, bx1, acc[0][1]);
-                acc[1][0] = mfma4(ax1, bx0, acc[1][0]);
-                acc[1][1] = mfma4(ax1, bx1, acc[1][1]);
-                acc[0][0] = mfma4(ay0, by0, acc[0][0]);
-                acc[0][1] = mfma4(ay0, by1, acc[0][1]);
-                acc[1][0] = mfma4(ay1, by0, acc[1][0]);
-                acc[1][1] = mfma4(ay1, by1, acc[1][1]);
-            }
-            __syncthreads();
-        }
+    int rb = it.ks * rows_per_split, re = min(b.batch, rb + rows_per_split);
+    if (!p.exec_flags[tk.gate] || rb >= re) { rb = 0; re = 0; }       // writes zeros
+    const float* Ap; int64_t lda;
+    if (tk.a_kind == A_DPRE) { Ap = p.dpre + p.hid_off[tk.a_enc][tk.a_idx]; lda = tk.M; }
+    else if (tk.a_kind == A_DS) { Ap = p.dS + (int64_t)tk.a_idx * p.maxB * p.S; lda = p.S; }
+    else { Ap = p.dz + (int64_t)tk.a_idx * p.maxB * (2 * p.D); lda = 2 * p.D; }
+    SrcRef in{nullptr, 0};
+    int ncols = 0;
+    if (it.src == 0) { in = resolve_in(p, b, tk.in0_kind, tk.in0_enc, tk.in0_idx); ncols = tk.k0; }
+    else if (it.src == 1) { in = resolve_in(p, b, tk.in1_kind, tk.in0_enc, 0); ncols = tk.k1; }
+    const int key = it.mt * 8 + it.nt;
+    switch (key) {
+        case 4 * 8 + 4: wgrad_tile<4, 4>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        case 4 * 8 + 2: wgrad_tile<4, 2>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        case 4 * 8 + 1: wgrad_tile<4, 1>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        case 2 * 8 + 4: wgrad_tile<2, 4>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        case 2 * 8 + 2: wgrad_tile<2, 2>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        case 2 * 8 + 1: wgrad_tile<2, 1>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        case 1 * 8 + 4: wgrad_tile<1, 4>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        case 1 * 8 + 2: wgrad_tile<1, 2>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        default:        wgrad_tile<1, 1>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
     }
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 32 * wm + 16 * rt + 4 * q + r;
-                const int n = n0 + 32 * wn + 16 * ct + i;
-                if (m < M && n < ntot) slab[(int64_t)m * ntot + n] = acc[rt][ct][r];
-            }
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_reduce: slabs -> gradient tensors (one thread per element); last block: tile partials -> stats
+// (+ optional loss combination / epoch accumulation, + re-zeroing of the NaN flags)
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void epoch_accumulate_block(const DevPlan& p, float alpha, float beta) {
+    const int R = p.R, D = p.D, E = p.E, RD = R * D;
+    float* st = p.stats;
+    double* ep = p.epoch;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {                                       // fixed-order sums of grid and state change
+        float se = 0.f, ss = 0.f;
+        for (int c = lane; c < RD; c += 64) se += st[c];
+        for (int e = lane; e < E; e += 64) ss += st[RD + e];
+        se = wave_sum(se); ss = wave_sum(ss);
+        if (lane == 0) {
+            const float ge = se / (float)(D * R);          // multimodn.py:194
+            const float gs = ss / (float)E;                // multimodn.py:196
+            float* tail = st + RD + E + 5 * RD + R;
+            tail[0] = ge * alpha + gs * beta;              // multimodn.py:199-202
+            tail[1] = ge; tail[2] = gs; tail[3] = 0.f;
+            ep[RD + E + 5 * RD + R] += 1.0;                // n_steps
+        }
+    }
+    for (int c = threadIdx.x; c < RD; c += NT) {
+        ep[c] += (double)st[c];                                            // err_loss_epoch (f64 += f32)
+        ep[RD + E + c] += (double)st[RD + E + c];                          // n_correct
+        for (int k = 1; k < 5; ++k) {                                      // tp/tn/fp/fn kept in fp32
+            double* a = ep + RD + E + k * RD + c;
+            *a = (double)((float)*a + st[RD + E + k * RD + c]);
+        }
+    }
+    for (int e = threadIdx.x; e < E; e += NT) ep[RD + e] += (double)st[RD + e];
+    for (int r = threadIdx.x; r < R; r += NT) ep[RD + E + 5 * RD + r] += (double)st[RD + E + 5 * RD + r];
+}
+
 __global__ __launch_bounds__(NT) void k_reduce(const DevPlan* __restrict__ P, int batch, int batch_global,
-                                               int n_tiles, int grad_blocks, int want_grads) {
+                                               int n_tiles, int grad_blocks, int want_grads, int accumulate,
+                                               float alpha, float beta, int32_t* nan_flags) {
     const DevPlan& p = *P;
     if ((int)blockIdx.x < grad_blocks) {
         if (!want_grads) return;
@@ -830,69 +1040,45 @@ __global__ __launch_bounds__(NT) void k_reduce(const DevPlan* __restrict__ P, in
         sg.dst[local] = sum;
         return;
     }
-    // stats block
+    // stats block: one wave per quantity, lanes over tiles, butterfly sum (fixed order)
     const int R = p.R, D = p.D, E = p.E, S = p.S;
     const int RD = R * D;
     float* st = p.stats;
     const float Bg = (float)batch_global;
-    for (int cell = threadIdx.x; cell < RD; cell += NT) {
-        const int r = cell / D;
-        float ls = 0.f;
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
-        if (p.exec_flags[r]) {
-            for (int t = 0; t < n_tiles; ++t) {
-                ls += p.lossp[(int64_t)t * RD + cell];
-                const int32_t* cp = p.cntp + ((int64_t)t * RD + cell) * 5;
-                c0 += cp[0]; c1 += cp[1]; c2 += cp[2]; c3 += cp[3]; c4 += cp[4];
-            }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = RD + E + 5 * RD;                        // loss cells, state-change, 5 counters per cell
+    for (int qd = wave; qd < nq; qd += 4) {
+        float fs = 0.f;
+        int is = 0;
+        if (qd < RD) {
+            if (p.exec_flags[qd / D]) for (int t = lane; t < n_tiles; t += 64) fs += p.lossp[(int64_t)t * RD + qd];
+        } else if (qd < RD + E) {
+            const int e = qd - RD;
+            if (p.exec_flags[e + 1]) for (int t = lane; t < n_tiles; t += 64) fs += p.scp[(int64_t)t * E + e];
+        } else {
+            const int k = (qd - RD - E) / RD, cell = (qd - RD - E) - k * RD;
+            if (p.exec_flags[cell / D]) for (int t = lane; t < n_tiles; t += 64) is += p.cntp[((int64_t)t * RD + cell) * 5 + k];
         }
-        st[cell] = ls / Bg;
-        st[RD + E + 0 * RD + cell] = (float)c0;
-        st[RD + E + 1 * RD + cell] = (float)c1;
-        st[RD + E + 2 * RD + cell] = (float)c2;
-        st[RD + E + 3 * RD + cell] = (float)c3;
-        st[RD + E + 4 * RD + cell] = (float)c4;
-    }
-    for (int e = threadIdx.x; e < E; e += NT) {
-        float s = 0.f;
-        if (p.exec_flags[e + 1])
-            for (int t = 0; t < n_tiles; ++t) s += p.scp[(int64_t)t * E + e];
-        st[RD + e] = s / ((float)batch_global * (float)S);
+        fs = wave_sum(fs);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) is += __shfl_xor(is, off);
+        if (lane == 0) {
+            if (qd < RD) st[qd] = fs / Bg;
+            else if (qd < RD + E) st[qd] = fs / (Bg * (float)S);
+            else st[qd] = (float)is;
+        }
     }
     for (int r = threadIdx.x; r < R; r += NT) st[RD + E + 5 * RD + r] = p.exec_flags[r] ? (float)batch : 0.f;
+    if (nan_flags && threadIdx.x < MMN_MAX_ENCODERS) nan_flags[threadIdx.x] = 0;
+    if (accumulate) {
+        __threadfence_block();
+        __syncthreads();
+        epoch_accumulate_block(p, alpha, beta);
+    }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_epoch_accumulate (one workgroup)
-// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_epoch_accumulate(const DevPlan* __restrict__ P, float alpha, float beta) {
-    const DevPlan& p = *P;
-    const int R = p.R, D = p.D, E = p.E, RD = R * D;
-    float* st = p.stats;
-    double* ep = p.epoch;
-    __shared__ float sred[2];
-    if (threadIdx.x == 0) {
-        float se = 0.f, ss = 0.f;
-        for (int c = 0; c < RD; ++c) se += st[c];
-        for (int e = 0; e < E; ++e) ss += st[RD + e];
-        const float ge = se / (float)(D * R);              // multimodn.py:194
-        const float gs = ss / (float)E;                    // multimodn.py:196
-        float* tail = st + RD + E + 5 * RD + R;
-        tail[0] = ge * alpha + gs * beta;                  // multimodn.py:199-202
-        tail[1] = ge; tail[2] = gs; tail[3] = 0.f;
-        ep[RD + E + 5 * RD + R] += 1.0;                    // n_steps
-    }
-    for (int c = threadIdx.x; c < RD; c += NT) {
-        ep[c] += (double)st[c];                                            // err_loss_epoch (f64 += f32)
-        ep[RD + E + c] += (double)st[RD + E + c];                          // n_correct
-        for (int k = 1; k < 5; ++k) {                                      // tp/tn/fp/fn kept in fp32
-            double* a = ep + RD + E + k * RD + c;
-            *a = (double)((float)*a + st[RD + E + k * RD + c]);
-        }
-    }
-    for (int e = threadIdx.x; e < E; e += NT) ep[RD + e] += (double)st[RD + e];
-    for (int r = threadIdx.x; r < R; r += NT) ep[RD + E + 5 * RD + r] += (double)st[RD + E + 5 * RD + r];
-    (void)sred;
+    epoch_accumulate_block(*P, alpha, beta);
 }
 
 }  // namespace
@@ -905,8 +1091,9 @@ struct mmn_plan {
     DevPlan host;            // host copy of the device plan
     DevPlan* dev;            // device address (start of workspace)
     int max_batch;
-    size_t lds_bytes;
+    size_t lds_bytes[3];     // by RT
     int grad_blocks;
+    int rt_override;
 };
 
 static thread_local int g_last_hip = 0;
@@ -930,7 +1117,7 @@ static int validate_model(const mmn_model* m) {
             const mmn_linear& lin = enc.layer[l];
             const bool last = l == enc.n_layers - 1;
             if (lin.in_dim != in + (last ? m->state_size : 0)) return MMN_ERR_ARG;
-            if (lin.out_dim != (last ? m->state_size : lin.out_dim) || lin.out_dim < 1) return MMN_ERR_ARG;
+            if (lin.out_dim < 1 || (last && lin.out_dim != m->state_size)) return MMN_ERR_ARG;
             if (!last && lin.out_dim > MMN_MAX_DIM) return MMN_ERR_UNSUPPORTED;
             in = lin.out_dim;
         }
@@ -940,40 +1127,91 @@ static int validate_model(const mmn_model* m) {
 
 namespace {
 struct Layout {
-    size_t off_plan, off_states, off_hid, off_dpre, off_dz, off_dS, off_lossp, off_scp, off_cntp, off_flags,
-        off_slabs, off_epoch, off_tasks, off_items, off_segs, total;
+    size_t off_plan, off_states, off_hid, off_dpre, off_dz, off_dS, off_wT, off_wdT, off_lossp, off_scp, off_cntp,
+        off_flags, off_slabs, off_epoch, off_tasks, off_items, off_segs, off_ttasks, off_titems, total;
     int64_t hid_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
-    int64_t hid_floats;
+    int64_t wt_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
+    int64_t hid_floats, wt_floats;
     std::vector<WTask> tasks;
     std::vector<WItem> items;
     std::vector<Seg> segs;
+    std::vector<TTask> ttasks;      // dst filled at plan creation (needs workspace addresses)
+    std::vector<TItem> titems;
     int64_t slab_floats, n_grad_elems;
-    int KS, max_tiles;
+    int KS, max_tiles, ldS, ldH;
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+int pick_width(int n) { return n >= 64 ? 4 : (n >= 32 ? 2 : 1); }
+
 void build_layout(const mmn_model& m, int maxB, Layout& L) {
     const int S = m.state_size, E = m.n_encoders, D = m.n_decoders, R = E + 1;
-    L.max_tiles = (maxB + TB - 1) / TB;
-    int ks = (maxB + 511) / 512;
+    L.max_tiles = (maxB + 15) / 16;
+    int ks = (maxB + 255) / 256;
     if (ks < 1) ks = 1;
     if (ks > 16) ks = 16;
     L.KS = ks;
-    int64_t ho = 0;
-    for (int e = 0; e < E; ++e)
-        for (int l = 0; l + 1 < m.enc[e].n_layers; ++l) {
-            L.hid_off[e][l] = ho;
-            ho += (int64_t)maxB * m.enc[e].layer[l].out_dim;
+    L.ldS = pick_ld(S);
+    int maxh = 16;
+    int64_t ho = 0, wo = 0;
+    memset(L.hid_off, 0, sizeof(L.hid_off));
+    memset(L.wt_off, 0, sizeof(L.wt_off));
+    for (int e = 0; e < E; ++e) {
+        const int nl = m.enc[e].n_layers;
+        for (int l = 0; l < nl; ++l) {
+            const mmn_linear& lin = m.enc[e].layer[l];
+            if (l + 1 < nl) {
+                L.hid_off[e][l] = ho;
+                ho += (int64_t)maxB * lin.out_dim;
+                maxh = maxh > lin.out_dim ? maxh : lin.out_dim;
+            }
+            if (l >= 1 || l == nl - 1) {                 // backward multiplies by W_l for l >= 1 and by W_last
+                L.wt_off[e][l] = wo;
+                wo += (int64_t)align_up((size_t)lin.out_dim * lin.in_dim, 4);
+            } else {
+                L.wt_off[e][l] = -1;
+            }
         }
+    }
     L.hid_floats = ho;
+    L.wt_floats = wo;
+    L.ldH = pick_ld(maxh);
 
-    // ---- wgrad tasks, slabs, gradient segments
+    // ---- transposes (destinations patched in by plan_create)
+    for (int e = 0; e < E; ++e)
+        for (int l = 0; l < m.enc[e].n_layers; ++l) {
+            if (L.wt_off[e][l] < 0) continue;
+            const mmn_linear& lin = m.enc[e].layer[l];
+            const int id = (int)L.ttasks.size();
+            L.ttasks.push_back(TTask{lin.w, nullptr, lin.out_dim, lin.in_dim, lin.in_dim, lin.out_dim});
+            for (int r0 = 0; r0 < lin.out_dim; r0 += 32)
+                for (int c0 = 0; c0 < lin.in_dim; c0 += 32) L.titems.push_back(TItem{id, r0, c0, 0});
+        }
+    for (int d = 0; d < D; ++d) {
+        const int id = (int)L.ttasks.size();
+        L.ttasks.push_back(TTask{m.dec[d].w, nullptr, 2, S, S, WT_LD});
+        for (int c0 = 0; c0 < S; c0 += 32) L.titems.push_back(TItem{id, 0, c0, 0});
+    }
+
+    // ---- wgrad tasks, work items, slabs, gradient segments
     int64_t slab = 0, gstart = 0;
-    auto add_items = [&](int task, int M, int ntot) {
-        for (int m0 = 0; m0 < M; m0 += WG_TILE)
-            for (int n0 = 0; n0 < ntot; n0 += WG_TILE)
-                for (int k = 0; k < ks; ++k) L.items.push_back(WItem{task, m0, n0, k});
+    auto add_items = [&](int task, int M, int src, int ncols, bool bias_here) {
+        // tile the [M x ncols] block of one source with interleave widths matched to what is left
+        for (int m0 = 0; m0 < M;) {
+            const int mt = pick_width(M - m0);
+            bool first_n = true;
+            int n0 = 0;
+            do {
+                const int nt = src == 2 ? 1 : pick_width(ncols - n0);
+                for (int k = 0; k < ks; ++k)
+                    L.items.push_back(WItem{task, m0, n0, k, (int16_t)mt, (int16_t)nt, (int16_t)src,
+                                            (int16_t)(bias_here && first_n ? 1 : 0)});
+                first_n = false;
+                n0 += 16 * nt;
+            } while (src != 2 && n0 < ncols);
+            m0 += 16 * mt;
+        }
     };
     auto add_seg = [&](float* dst, int count, int64_t base, int64_t pstride, int nparts, int kdiv, int ntot,
                        int coff, int row_off) {
@@ -981,7 +1219,7 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
         L.segs.push_back(Seg{dst, gstart, base, pstride, count, nparts, kdiv, ntot, coff, row_off});
         gstart += count;
     };
-    // init state: colsum of dS0
+    // init state: column sums of dS0
     {
         WTask t{};
         t.a_kind = A_DS; t.a_idx = E; t.M = S;
@@ -989,7 +1227,7 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
         t.slab_base = slab; t.pstride = (int64_t)S;
         const int id = (int)L.tasks.size();
         L.tasks.push_back(t);
-        add_items(id, S, 1);
+        add_items(id, S, 2, 0, true);
         add_seg(m.g_init_state, S, slab, t.pstride, ks, 1, 1, 0, 0);
         slab += (int64_t)ks * t.pstride;
     }
@@ -1011,7 +1249,8 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
             t.slab_base = slab; t.pstride = (int64_t)t.M * t.ntot;
             const int id = (int)L.tasks.size();
             L.tasks.push_back(t);
-            add_items(id, t.M, t.ntot);
+            add_items(id, t.M, 0, t.k0, true);
+            if (last) add_items(id, t.M, 1, t.k1, false);
             add_seg(lin.gw, lin.out_dim * lin.in_dim, slab, t.pstride, ks, lin.in_dim, t.ntot, 0, 0);
             add_seg(lin.gb, lin.out_dim, slab, t.pstride, ks, 1, t.ntot, lin.in_dim, 0);
             slab += (int64_t)ks * t.pstride;
@@ -1029,7 +1268,7 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
             t.slab_base = base + (int64_t)r * ks * pstride; t.pstride = pstride;
             const int id = (int)L.tasks.size();
             L.tasks.push_back(t);
-            add_items(id, t.M, t.ntot);
+            add_items(id, t.M, 0, S, true);
         }
         for (int d = 0; d < D; ++d) {
             add_seg(m.dec[d].gw, 2 * S, base, pstride, R * ks, S, S + 1, 0, 2 * d);
@@ -1041,13 +1280,15 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     L.n_grad_elems = gstart;
 
     size_t o = 0;
-    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + (bytes ? bytes : 4), 256); return at; };
     L.off_plan = take(sizeof(DevPlan));
     L.off_states = take(sizeof(float) * (size_t)E * maxB * S);
-    L.off_hid = take(sizeof(float) * (size_t)(L.hid_floats ? L.hid_floats : 1));
-    L.off_dpre = take(sizeof(float) * (size_t)(L.hid_floats ? L.hid_floats : 1));
+    L.off_hid = take(sizeof(float) * (size_t)L.hid_floats);
+    L.off_dpre = take(sizeof(float) * (size_t)L.hid_floats);
     L.off_dz = take(sizeof(float) * (size_t)R * maxB * 2 * D);
     L.off_dS = take(sizeof(float) * (size_t)(E + 1) * maxB * S);
+    L.off_wT = take(sizeof(float) * (size_t)L.wt_floats);
+    L.off_wdT = take(sizeof(float) * (size_t)S * WT_LD);
     L.off_lossp = take(sizeof(float) * (size_t)L.max_tiles * R * D);
     L.off_scp = take(sizeof(float) * (size_t)L.max_tiles * E);
     L.off_cntp = take(sizeof(int32_t) * (size_t)L.max_tiles * R * D * 5);
@@ -1057,7 +1298,14 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     L.off_tasks = take(sizeof(WTask) * L.tasks.size());
     L.off_items = take(sizeof(WItem) * L.items.size());
     L.off_segs = take(sizeof(Seg) * L.segs.size());
+    L.off_ttasks = take(sizeof(TTask) * L.ttasks.size());
+    L.off_titems = take(sizeof(TItem) * L.titems.size());
     L.total = o;
+}
+
+int choose_rt(const mmn_plan* p, int batch) {
+    if (p->rt_override == 1 || p->rt_override == 2) return p->rt_override;
+    return batch <= 16 * 320 ? 1 : 2;        // keep >= one workgroup per CU busy as long as possible
 }
 }  // namespace
 
@@ -1095,6 +1343,8 @@ size_t mmn_workspace_bytes(const mmn_model* m, int max_batch) {
     if (validate_model(m) != MMN_OK || max_batch < 1) return 0;
     Layout L;
     build_layout(*m, max_batch, L);
+    const ChainLds cl = chain_lds(16, L.ldS, L.ldH);
+    if (sizeof(float) * (size_t)cl.total > 160 * 1024) return 0;
     return L.total;
 }
 
@@ -1114,24 +1364,25 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     if (!pl) return MMN_ERR_ARG;
     pl->m = *m;
     pl->max_batch = max_batch;
+    const char* env = getenv("MMN_RT");
+    pl->rt_override = env ? atoi(env) : 0;
     char* ws = static_cast<char*>(workspace);
     DevPlan& h = pl->host;
     memset(&h, 0, sizeof(h));
     h.m = *m;
     h.S = m->state_size; h.E = m->n_encoders; h.D = m->n_decoders; h.R = h.E + 1;
-    h.S8 = round_up(h.S, 8);
-    h.ldS = pick_ld(h.S);
-    int maxh = 8;
-    for (int e = 0; e < h.E; ++e)
-        for (int l = 0; l + 1 < m->enc[e].n_layers; ++l) maxh = maxh > m->enc[e].layer[l].out_dim ? maxh : m->enc[e].layer[l].out_dim;
-    h.ldAct = pick_ld(maxh);
-    h.maxB = max_batch; h.max_tiles = L.max_tiles; h.KS = L.KS;
+    h.S16 = round_up(h.S, 16);
+    h.ldS = L.ldS; h.ldH = L.ldH;
+    h.maxB = max_batch; h.max_tiles = L.max_tiles; h.KS = L.KS; h.RT = 0;
     memcpy(h.hid_off, L.hid_off, sizeof(h.hid_off));
+    memcpy(h.wt_off, L.wt_off, sizeof(h.wt_off));
     h.states = reinterpret_cast<float*>(ws + L.off_states);
     h.hid = reinterpret_cast<float*>(ws + L.off_hid);
     h.dpre = reinterpret_cast<float*>(ws + L.off_dpre);
     h.dz = reinterpret_cast<float*>(ws + L.off_dz);
     h.dS = reinterpret_cast<float*>(ws + L.off_dS);
+    h.wT = reinterpret_cast<float*>(ws + L.off_wT);
+    h.wdT = reinterpret_cast<float*>(ws + L.off_wdT);
     h.lossp = reinterpret_cast<float*>(ws + L.off_lossp);
     h.scp = reinterpret_cast<float*>(ws + L.off_scp);
     h.cntp = reinterpret_cast<int32_t*>(ws + L.off_cntp);
@@ -1144,14 +1395,24 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     h.tasks = reinterpret_cast<WTask*>(ws + L.off_tasks);
     h.items = reinterpret_cast<WItem*>(ws + L.off_items);
     h.segs = reinterpret_cast<Seg*>(ws + L.off_segs);
+    h.ttasks = reinterpret_cast<TTask*>(ws + L.off_ttasks);
+    h.titems = reinterpret_cast<TItem*>(ws + L.off_titems);
     h.n_tasks = (int)L.tasks.size(); h.n_items = (int)L.items.size(); h.n_segs = (int)L.segs.size();
+    h.n_titems = (int)L.titems.size();
     h.n_grad_elems = L.n_grad_elems;
     pl->dev = reinterpret_cast<DevPlan*>(ws + L.off_plan);
     pl->grad_blocks = (int)((L.n_grad_elems + NT - 1) / NT);
-
-    const ChainLds cl = chain_lds(h.ldS, h.ldAct);
-    pl->lds_bytes = sizeof(float) * (size_t)cl.total;
-    if (pl->lds_bytes > 160 * 1024) { delete pl; return MMN_ERR_UNSUPPORTED; }
+    // transposed-weight destinations
+    {
+        size_t ti = 0;
+        for (int e = 0; e < h.E; ++e)
+            for (int l = 0; l < m->enc[e].n_layers; ++l)
+                if (L.wt_off[e][l] >= 0) L.ttasks[ti++].dst = h.wT + L.wt_off[e][l];
+        for (int d = 0; d < h.D; ++d) L.ttasks[ti++].dst = h.wdT + 2 * d;
+    }
+    pl->lds_bytes[0] = 0;
+    for (int rt = 1; rt <= 2; ++rt) pl->lds_bytes[rt] = sizeof(float) * (size_t)chain_lds(16 * rt, h.ldS, h.ldH).total;
+    if (pl->lds_bytes[1] > 160 * 1024) { delete pl; return MMN_ERR_UNSUPPORTED; }
 
     auto fail = [&](hipError_t e) { g_last_hip = (int)e; delete pl; return MMN_ERR_HIP; };
     hipError_t e;
@@ -1159,15 +1420,28 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     if ((e = hipMemcpy(h.tasks, L.tasks.data(), sizeof(WTask) * L.tasks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h.items, L.items.data(), sizeof(WItem) * L.items.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h.segs, L.segs.data(), sizeof(Seg) * L.segs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(h.ttasks, L.ttasks.data(), sizeof(TTask) * L.ttasks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(h.titems, L.titems.data(), sizeof(TItem) * L.titems.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemset(h.epoch, 0, sizeof(double) * mmn_epoch_doubles(m))) != hipSuccess) return fail(e);
     if ((e = hipMemset(h.exec_flags, 0, sizeof(int32_t) * (h.R + h.E + MMN_MAX_ENCODERS))) != hipSuccess) return fail(e);
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes)) != hipSuccess) return fail(e);
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(h.wdT, 0, sizeof(float) * (size_t)h.S * WT_LD)) != hipSuccess) return fail(e);
+    const void* fns[4] = {reinterpret_cast<const void*>(k_chain_fwd<1>), reinterpret_cast<const void*>(k_chain_fwd<2>),
+                          reinterpret_cast<const void*>(k_chain_bwd<1>), reinterpret_cast<const void*>(k_chain_bwd<2>)};
+    for (int k = 0; k < 4; ++k) {
+        const size_t need = pl->lds_bytes[1 + (k & 1)];
+        if (need <= 160 * 1024 &&
+            (e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)) != hipSuccess)
+            return fail(e);
+    }
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(sizeof(float) * WGRAD_LDS_FLOATS))) != hipSuccess) return fail(e);
     *out = pl;
     return MMN_OK;
 }
 
 void mmn_plan_destroy(mmn_plan* p) { delete p; }
+
+int32_t* mmn_nan_flags(mmn_plan* p) { return p ? p->host.nan_flags : nullptr; }
 
 static int check_batch(const mmn_plan* p, const mmn_batch* b) {
     if (!p || !b) return MMN_ERR_ARG;
@@ -1185,31 +1459,45 @@ static int check_batch(const mmn_plan* p, const mmn_batch* b) {
     return MMN_OK;
 }
 
-int mmn_nan_scan(mmn_plan* p, const mmn_batch* b, int32_t* nan_flags_out, void* stream) {
+static int rt_for(const mmn_plan* p, const mmn_batch* b) {
+    int rt = choose_rt(p, b->batch);
+    if (p->lds_bytes[rt] > 160 * 1024) rt = 1;
+    return rt;
+}
+
+int mmn_prepare(mmn_plan* p, const mmn_batch* b, int want_grads, void* stream) {
     int rc = check_batch(p, b);
     if (rc != MMN_OK) return rc;
-    if (!nan_flags_out) return MMN_ERR_ARG;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipMemsetAsync(nan_flags_out, 0, sizeof(int32_t) * MMN_MAX_ENCODERS, st));
-    if (b->n_seq == 0) return MMN_OK;
-    int bps = 256 / b->n_seq;
-    if (bps < 1) bps = 1;
+    const bool scan = b->nan_flags != nullptr && b->n_seq > 0;
+    int bps = 0, scan_blocks = 0;
+    if (scan) {
+        bps = 256 / b->n_seq;
+        if (bps < 1) bps = 1;
+        scan_blocks = b->n_seq * bps;
+    }
+    const int tblocks = want_grads ? p->host.n_titems : 0;
+    if (scan_blocks + tblocks == 0) return MMN_OK;
     mmn_batch bb = *b;
-    hipLaunchKernelGGL(k_nan_scan, dim3(b->n_seq * bps), dim3(NT), 0, st, bb, &p->dev->m, nan_flags_out, bps);
+    hipLaunchKernelGGL(k_prepare, dim3(scan_blocks + tblocks), dim3(NT), 0, static_cast<hipStream_t>(stream), p->dev, bb,
+                       scan_blocks, bps > 0 ? bps : 1);
     HIP_TRY(hipGetLastError());
     return MMN_OK;
 }
+
+int mmn_nan_scan(mmn_plan* p, const mmn_batch* b, void* stream) { return mmn_prepare(p, b, 0, stream); }
 
 int mmn_chain_fwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float sc_pen_x001, int want_grads,
                   void* stream) {
     (void)sc_pen_x001;
     int rc = check_batch(p, b);
     if (rc != MMN_OK) return rc;
-    const int tiles = (b->batch + TB - 1) / TB;
+    const int rt = rt_for(p, b);
+    const int tiles = (b->batch + 16 * rt - 1) / (16 * rt);
     const float cL = err_penalty / ((float)p->m.n_decoders * (float)(p->m.n_encoders + 1) * (float)b->batch_global);
     mmn_batch bb = *b;
-    hipLaunchKernelGGL(k_chain_fwd, dim3(tiles), dim3(NT), p->lds_bytes, static_cast<hipStream_t>(stream), p->dev, bb, cL,
-                       want_grads);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (rt == 1) hipLaunchKernelGGL(k_chain_fwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cL, want_grads);
+    else hipLaunchKernelGGL(k_chain_fwd<2>, dim3(tiles), dim3(NT), p->lds_bytes[2], st, p->dev, bb, cL, want_grads);
     HIP_TRY(hipGetLastError());
     return MMN_OK;
 }
@@ -1221,10 +1509,13 @@ static float sc_coeff(const mmn_plan* p, const mmn_batch* b, float beta) {
 int mmn_chain_bwd(mmn_plan* p, const mmn_batch* b, float sc_pen_x001, void* stream) {
     int rc = check_batch(p, b);
     if (rc != MMN_OK) return rc;
-    const int tiles = (b->batch + TB - 1) / TB;
+    const int rt = rt_for(p, b);
+    const int tiles = (b->batch + 16 * rt - 1) / (16 * rt);
     mmn_batch bb = *b;
-    hipLaunchKernelGGL(k_chain_bwd, dim3(tiles), dim3(NT), p->lds_bytes, static_cast<hipStream_t>(stream), p->dev, bb,
-                       sc_coeff(p, b, sc_pen_x001));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float cS = sc_coeff(p, b, sc_pen_x001);
+    if (rt == 1) hipLaunchKernelGGL(k_chain_bwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cS);
+    else hipLaunchKernelGGL(k_chain_bwd<2>, dim3(tiles), dim3(NT), p->lds_bytes[2], st, p->dev, bb, cS);
     HIP_TRY(hipGetLastError());
     return MMN_OK;
 }
@@ -1233,17 +1524,21 @@ int mmn_wgrad(mmn_plan* p, const mmn_batch* b, void* stream) {
     int rc = check_batch(p, b);
     if (rc != MMN_OK) return rc;
     const int ks = p->host.KS;
-    const int rps = round_up((b->batch + ks - 1) / ks, TB);
+    const int rps = round_up((b->batch + ks - 1) / ks, 16);
     mmn_batch bb = *b;
-    hipLaunchKernelGGL(k_wgrad, dim3(p->host.n_items), dim3(NT), 0, static_cast<hipStream_t>(stream), p->dev, bb, rps);
+    hipLaunchKernelGGL(k_wgrad, dim3(p->host.n_items), dim3(NT), sizeof(float) * WGRAD_LDS_FLOATS,
+                       static_cast<hipStream_t>(stream), p->dev, bb, rps);
     HIP_TRY(hipGetLastError());
     return MMN_OK;
 }
 
-static int launch_reduce(mmn_plan* p, const mmn_batch* b, int want_grads, void* stream) {
-    const int tiles = (b->batch + TB - 1) / TB;
+static int launch_reduce(mmn_plan* p, const mmn_batch* b, int want_grads, int accumulate, float alpha, float beta,
+                         void* stream) {
+    const int rt = rt_for(p, b);
+    const int tiles = (b->batch + 16 * rt - 1) / (16 * rt);
     hipLaunchKernelGGL(k_reduce, dim3(p->grad_blocks + 1), dim3(NT), 0, static_cast<hipStream_t>(stream), p->dev, b->batch,
-                       b->batch_global, tiles, p->grad_blocks, want_grads);
+                       b->batch_global, tiles, p->grad_blocks, want_grads, accumulate, alpha, beta,
+                       const_cast<int32_t*>(b->nan_flags));
     HIP_TRY(hipGetLastError());
     return MMN_OK;
 }
@@ -1251,7 +1546,7 @@ static int launch_reduce(mmn_plan* p, const mmn_batch* b, int want_grads, void* 
 int mmn_reduce(mmn_plan* p, const mmn_batch* b, void* stream) {
     int rc = check_batch(p, b);
     if (rc != MMN_OK) return rc;
-    return launch_reduce(p, b, 1, stream);
+    return launch_reduce(p, b, 1, 0, 0.f, 0.f, stream);
 }
 
 int mmn_epoch_accumulate(mmn_plan* p, float err_penalty, float sc_pen_x001, void* stream) {
@@ -1264,21 +1559,19 @@ int mmn_epoch_accumulate(mmn_plan* p, float err_penalty, float sc_pen_x001, void
 
 int mmn_train_step(mmn_plan* p, const mmn_batch* b, float err_penalty, float sc_pen_x001, int accumulate_epoch,
                    void* stream) {
-    int rc = mmn_chain_fwd(p, b, err_penalty, sc_pen_x001, 1, stream);
+    int rc = mmn_prepare(p, b, 1, stream);
     if (rc != MMN_OK) return rc;
+    if ((rc = mmn_chain_fwd(p, b, err_penalty, sc_pen_x001, 1, stream)) != MMN_OK) return rc;
     if ((rc = mmn_chain_bwd(p, b, sc_pen_x001, stream)) != MMN_OK) return rc;
     if ((rc = mmn_wgrad(p, b, stream)) != MMN_OK) return rc;
-    if ((rc = launch_reduce(p, b, 1, stream)) != MMN_OK) return rc;
-    if (accumulate_epoch) rc = mmn_epoch_accumulate(p, err_penalty, sc_pen_x001, stream);
-    return rc;
+    return launch_reduce(p, b, 1, accumulate_epoch, err_penalty, sc_pen_x001, stream);
 }
 
 int mmn_eval_step(mmn_plan* p, const mmn_batch* b, int accumulate_epoch, void* stream) {
-    int rc = mmn_chain_fwd(p, b, 1.0f, 0.0f, 0, stream);
+    int rc = mmn_prepare(p, b, 0, stream);
     if (rc != MMN_OK) return rc;
-    if ((rc = launch_reduce(p, b, 0, stream)) != MMN_OK) return rc;
-    if (accumulate_epoch) rc = mmn_epoch_accumulate(p, 1.0f, 0.0f, stream);
-    return rc;
+    if ((rc = mmn_chain_fwd(p, b, 1.0f, 0.0f, 0, stream)) != MMN_OK) return rc;
+    return launch_reduce(p, b, 0, accumulate_epoch, 1.0f, 0.0f, stream);
 }
 
 int mmn_epoch_reset(mmn_plan* p, void* stream) {

@@ -158,7 +158,7 @@ class HipChainEngine:
         hip.check(lib.mmn_plan_create(C.byref(m), self.max_batch, self._ws_ptr, ws_bytes,
                                       self.stats.data_ptr(), C.byref(plan)), "mmn_plan_create")
         self._plan = plan
-        self.nan_flags = torch.zeros(hip.MAX_ENCODERS, dtype=torch.int32, device=self.device)
+        self._nan_flags_ptr = lib.mmn_nan_flags(plan)      # plan-owned device flags
         self.n_epoch = int(lib.mmn_epoch_doubles(C.byref(m)))
         self._sig = tuple(p.data_ptr() for p in self.params)
         self.E, self.D, self.S = m.n_encoders, m.n_decoders, m.state_size
@@ -200,7 +200,7 @@ class HipChainEngine:
         if y.dtype != torch.int64 or not y.is_contiguous() or y.device != self.device:
             raise ValueError("targets must be a contiguous int64 [B, D] tensor on the model's device")
         b.y = y.data_ptr()
-        b.nan_flags = self.nan_flags.data_ptr() if device_nan_flags else None
+        b.nan_flags = self._nan_flags_ptr if device_nan_flags else None
         b.batch = B
         b.batch_global = int(batch_global) if batch_global else B
         b.n_seq = len(pairs)
@@ -209,17 +209,16 @@ class HipChainEngine:
             b.seq_enc[t] = e
         return b
 
-    def nan_scan(self, b: hip.Batch) -> None:
-        hip.check(self.lib.mmn_nan_scan(self._plan, C.byref(b), self.nan_flags.data_ptr(), self._stream()), "mmn_nan_scan")
+    def local_step(self, b: hip.Batch, err_penalty: float, sc_penalty_x001: float, accumulate: bool = False) -> None:
+        """prepare (NaN scan when the batch carries device flags, weight transposes) + fwd + bwd +
+        wgrad + reduce: afterwards reduce_buf = [grads | stats] holds this rank's sums (already
+        divided by batch_global).  accumulate=True also folds the loss combination / epoch
+        accumulation into the last launch (single-GPU)."""
+        hip.check(self.lib.mmn_train_step(self._plan, C.byref(b), err_penalty, sc_penalty_x001,
+                                          1 if accumulate else 0, self._stream()), "mmn_train_step")
 
-    def local_step(self, b: hip.Batch, err_penalty: float, sc_penalty_x001: float) -> None:
-        """fwd + bwd + wgrad + reduce: afterwards reduce_buf = [grads | stats] holds this rank's
-        sums (already divided by batch_global)."""
-        hip.check(self.lib.mmn_train_step(self._plan, C.byref(b), err_penalty, sc_penalty_x001, 0, self._stream()),
-                  "mmn_train_step")
-
-    def eval_step(self, b: hip.Batch) -> None:
-        hip.check(self.lib.mmn_eval_step(self._plan, C.byref(b), 0, self._stream()), "mmn_eval_step")
+    def eval_step(self, b: hip.Batch, accumulate: bool = False) -> None:
+        hip.check(self.lib.mmn_eval_step(self._plan, C.byref(b), 1 if accumulate else 0, self._stream()), "mmn_eval_step")
 
     def accumulate(self, err_penalty: float, sc_penalty_x001: float) -> None:
         hip.check(self.lib.mmn_epoch_accumulate(self._plan, err_penalty, sc_penalty_x001, self._stream()),

@@ -25,7 +25,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 #: every symbol include/mmn_hip.h declares
 ABI_SYMBOLS = (
     "mmn_version", "mmn_error_string", "mmn_last_hip_error", "mmn_stats_floats", "mmn_epoch_doubles",
-    "mmn_workspace_bytes", "mmn_plan_create", "mmn_plan_destroy", "mmn_nan_scan", "mmn_chain_fwd",
+    "mmn_workspace_bytes", "mmn_plan_create", "mmn_plan_destroy", "mmn_nan_flags", "mmn_prepare",
+    "mmn_nan_scan", "mmn_chain_fwd",
     "mmn_chain_bwd", "mmn_wgrad", "mmn_reduce", "mmn_epoch_accumulate", "mmn_train_step",
     "mmn_eval_step", "mmn_epoch_reset", "mmn_epoch_read", "mmn_debug_buffer",
 )
@@ -96,8 +97,12 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_plan_create.argtypes = [C.POINTER(Model), i32, vp, C.c_size_t, vp, C.POINTER(vp)]
     lib.mmn_plan_destroy.restype = None
     lib.mmn_plan_destroy.argtypes = [vp]
+    lib.mmn_nan_flags.restype = vp
+    lib.mmn_nan_flags.argtypes = [vp]
+    lib.mmn_prepare.restype = i32
+    lib.mmn_prepare.argtypes = [vp, C.POINTER(Batch), i32, vp]
     lib.mmn_nan_scan.restype = i32
-    lib.mmn_nan_scan.argtypes = [vp, C.POINTER(Batch), vp, vp]
+    lib.mmn_nan_scan.argtypes = [vp, C.POINTER(Batch), vp]
     lib.mmn_chain_fwd.restype = i32
     lib.mmn_chain_fwd.argtypes = [vp, C.POINTER(Batch), f32, f32, i32, vp]
     lib.mmn_chain_bwd.restype = i32

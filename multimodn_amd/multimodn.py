@@ -133,16 +133,15 @@ class MultiModN(nn.Module):
         B = int(y.shape[0])
         b = eng.make_batch(xs, y, exec_pairs, batch_global=batch_global or B * self._dp_world,
                            device_nan_flags=executed is None)
-        if executed is None:
-            eng.nan_scan(b)
+        dp = self._dp_group is not None
         if train:
-            eng.local_step(b, float(self.err_penalty), float(self.state_change_penalty))
+            eng.local_step(b, float(self.err_penalty), float(self.state_change_penalty), accumulate=not dp)
         else:
-            eng.eval_step(b)
-        if self._dp_group is not None:
+            eng.eval_step(b, accumulate=not dp)
+        if dp:
             import torch.distributed as dist
             dist.all_reduce(eng.reduce_buf if train else eng.stats, group=self._dp_group)
-        eng.accumulate(float(self.err_penalty) if train else 1.0, float(self.state_change_penalty) if train else 0.0)
+            eng.accumulate(float(self.err_penalty) if train else 1.0, float(self.state_change_penalty) if train else 0.0)
         return executed, (xs, y)
 
     def train_epoch(

@@ -55,9 +55,6 @@ class OracleEngine:
         b.device_nan = device_nan_flags
         return b
 
-    def nan_scan(self, b):
-        pass
-
     def _run(self, b, want_grads):
         params = {n: p.detach().numpy() for n, p in zip(self.names, self.params)}
         n_slots = max(k for k, _ in b.pairs) + 1 if b.pairs else 0
@@ -91,16 +88,20 @@ class OracleEngine:
                                    for n, p in zip(self.names, self.params)])
             self.flat_grads.copy_(torch.from_numpy(flat))
 
-    def local_step(self, b, alpha, beta):
+    def local_step(self, b, alpha, beta, accumulate=False):
         self._run(b, True)
+        if accumulate:
+            self.accumulate(alpha, beta)
 
-    def eval_step(self, b):
+    def eval_step(self, b, accumulate=False):
         spec = self.spec
         self.spec = O.ModelSpec(spec.state_size, spec.encoders, spec.D, 1.0, 0.0)
         try:
             self._run(b, False)
         finally:
             self.spec = spec
+        if accumulate:
+            self.accumulate(1.0, 0.0)
 
     def accumulate(self, alpha, beta):
         """numpy twin of k_epoch_accumulate."""

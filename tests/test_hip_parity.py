@@ -118,8 +118,10 @@ def test_training_matches_reference_golden(lib, name):
         assert rel_err(sd[n], w) < tol, (n, rel_err(sd[n], w))
 
 
-@pytest.mark.parametrize("B", [1, 31, 32, 33, 257])
-def test_ragged_batches_match_oracle(lib, B):
+@pytest.mark.parametrize("rt", ["1", "2"])
+@pytest.mark.parametrize("B", [1, 15, 16, 17, 31, 32, 33, 257])
+def test_ragged_batches_match_oracle(lib, B, rt, monkeypatch):
+    monkeypatch.setenv("MMN_RT", rt)          # 16- and 32-row workgroup tiles (read at plan creation)
     spec = O.ModelSpec(20, [O.EncoderSpec(7, (9, 6), O.ACT_RELU), O.EncoderSpec(3, (), O.ACT_RELU),
                             O.EncoderSpec(70, (33,), O.ACT_SIGMOID)], 3, 1.0, 0.7)
     params = O.init_params(spec, 3)
@@ -146,7 +148,9 @@ def c3_spec():
     return O.ModelSpec(128, [O.EncoderSpec(64, (32, 32), O.ACT_RELU) for _ in range(4)], 3, 1.0, 0.3)
 
 
-def test_full_size_c3_step_matches_oracle(lib):
+@pytest.mark.parametrize("rt", ["1", "2"])
+def test_full_size_c3_step_matches_oracle(lib, rt, monkeypatch):
+    monkeypatch.setenv("MMN_RT", rt)
     spec = c3_spec()
     params = O.init_params(spec, 0)
     batch = O.synthetic_batches(spec, 4096, 4096, seed=1)[0]

@@ -102,6 +102,7 @@ struct DevPlan {
     int32_t* prev_row;        // [E]   state row that fed encoder e this step
     int32_t* nan_flags;       // [MMN_MAX_ENCODERS] NaN-found flag per data slot
     float* slabs; float* stats; double* epoch;
+    long long* stamps;        // diagnostic phase timestamps (MMN_STAMPS=1), else nullptr
     WTask* tasks; WItem* items; Seg* segs; TTask* ttasks; TItem* titems;
     int32_t n_tasks, n_items, n_segs, n_titems;
     int64_t n_grad_elems;
@@ -113,6 +114,35 @@ struct DevPlan {
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+// Explicit address spaces.  Pointers reach the hot loops through structs, so the compiler cannot
+// prove LDS vs global and would emit flat_* accesses whose waits (vmcnt(0) & lgkmcnt(0)) drain the
+// weight prefetch at every k-step.  Every hot access goes through these helpers instead.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define MMN_AS3 __attribute__((address_space(3)))
+#define MMN_AS1 __attribute__((address_space(1)))
+__device__ __forceinline__ float lds_ld(const float* p) { return *(const MMN_AS3 float*)p; }
+__device__ __forceinline__ f32x4 lds_ld4(const float* p) { return *(const MMN_AS3 f32x4*)p; }
+__device__ __forceinline__ void lds_st(float* p, float v) { *(MMN_AS3 float*)p = v; }
+__device__ __forceinline__ void lds_st4(float* p, f32x4 v) { *(MMN_AS3 f32x4*)p = v; }
+__device__ __forceinline__ float g_ld(const float* p) { return *(const MMN_AS1 float*)p; }
+__device__ __forceinline__ int g_ldi(const int32_t* p) { return *(const MMN_AS1 int32_t*)p; }
+__device__ __forceinline__ f32x2 g_ld2(const float* p) { return *(const MMN_AS1 f32x2*)p; }
+__device__ __forceinline__ f32x4 g_ld4(const float* p) { return *(const MMN_AS1 f32x4*)p; }
+__device__ __forceinline__ void g_st(float* p, float v) { *(MMN_AS1 float*)p = v; }
+__device__ __forceinline__ void g_st2(float* p, f32x2 v) { *(MMN_AS1 f32x2*)p = v; }
+__device__ __forceinline__ void g_st4(float* p, f32x4 v) { *(MMN_AS1 f32x4*)p = v; }
+__device__ __forceinline__ void g_sti(int32_t* p, int v) { *(MMN_AS1 int32_t*)p = v; }
+
+// Diagnostic only (MMN_STAMPS=1): 100 MHz timestamps of one workgroup's phases, written to a
+// buffer nothing else reads.  With stamps == nullptr (always, outside diagnosis) this is one
+// scalar compare per phase.
+__device__ __forceinline__ void stamp(const long long* const* dummy, long long* stamps, int& k, int block) {
+    (void)dummy;
+    if (stamps && (int)blockIdx.x == block && threadIdx.x == 0 && k < 250) stamps[k] = (long long)wall_clock64();
+    ++k;
+}
+#define STAMP() stamp(nullptr, p.stamps, stamp_k, stamp_block)
 
 __device__ __forceinline__ float act_fwd(float v, int kind) {
     if (kind == MMN_ACT_RELU) return fmaxf(v, 0.0f);
@@ -126,7 +156,7 @@ __device__ __forceinline__ float act_grad_from_out(float h, int kind) {
 }
 
 __device__ __forceinline__ bool slot_present(const mmn_batch& b, int slot) {
-    return b.nan_flags == nullptr || b.nan_flags[slot] == 0;
+    return b.nan_flags == nullptr || g_ldi(b.nan_flags + slot) == 0;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -153,92 +183,101 @@ __device__ __forceinline__ BSrc make_bsrc(const float* w, int ldw, int N, int le
     s.vec = ((ldw | col0 | col1 | len0 | len1) & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0;
     return s;
 }
+__device__ __forceinline__ int bsrc_steps(const BSrc& B) { return (B.len0p + B.len1p) >> 4; }
 // activation operand: LDS images for the two contraction segments (zero/finite padded to 16)
 struct ASrc { const float* a0; int lda0; const float* a1; int lda1; };
 
+// One weight fragment (4 consecutive contraction elements of row n).  Branch-free on the vector
+// path: out-of-range lanes read a clamped (valid) address and are zeroed by a select, because a
+// branch around a load makes hipcc fall back to s_waitcnt vmcnt(0) and serialises the prefetch.
 template <bool VEC>
-__device__ __forceinline__ float4 load_b(const BSrc& s, int n, int kk) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n < s.N) {
-        int col, rem;
-        if (kk < s.len0p) { col = s.col0 + kk; rem = s.len0 - kk; }
-        else { const int k1 = kk - s.len0p; col = s.col1 + k1; rem = s.len1 - k1; }
-        if (rem > 0) {
+__device__ __forceinline__ f32x4 load_b(const BSrc& s, int n, int kk) {
+    int col, rem;
+    if (kk < s.len0p) { col = s.col0 + kk; rem = s.len0 - kk; }
+    else { const int k1 = kk - s.len0p; col = s.col1 + k1; rem = s.len1 - k1; }
+    const bool ok = (n < s.N) && (rem > 0);
+    if (VEC) {
+        const int nn = min(n, s.N - 1);
+        const int cc = rem > 0 ? col : 0;
+        f32x4 v = g_ld4(s.w + (int64_t)nn * s.ldw + cc);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        return ok ? v : z;
+    } else {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
             const float* p = s.w + (int64_t)n * s.ldw + col;
-            if (VEC) {
-                v = *reinterpret_cast<const float4*>(p);
+            v.x = g_ld(p);
+            if (rem > 1) v.y = g_ld(p + 1);
+            if (rem > 2) v.z = g_ld(p + 2);
+            if (rem > 3) v.w = g_ld(p + 3);
+        }
+        return v;
+    }
+}
+
+// The GEMM of one layer is split into ISSUE (request NS k-steps of weight fragments for this
+// wave's two column tiles) and CONSUME (LDS activation fragments x those registers -> MFMA), so a
+// caller can put unrelated work -- or a whole earlier layer -- between the two: global latency
+// (~0.7 us per dependent round trip on a busy chip) is what bounds this kernel, not the MFMAs.
+constexpr int TQ = 12;
+template <int NS, bool VEC>
+__device__ __forceinline__ void issue_b(f32x4 (&bq)[NS][2], const BSrc& B, const int (&n0)[2], int t_begin) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, q = lane >> 4;
+    const int T = bsrc_steps(B);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int t = min(t_begin + j, T - 1);     // clamp, never branch: surplus slots re-read a hot line
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bq[j][c] = load_b<VEC>(B, n0[c] + i, 16 * t + 4 * q);
+    }
+}
+
+template <int RT, int NS>
+__device__ __forceinline__ void consume_b(f32x4 (&acc)[2][RT], const ASrc& A, const BSrc& B, const f32x4 (&bq)[NS][2],
+                                          int t_begin, bool two) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, q = lane >> 4;
+    const int T = bsrc_steps(B);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int t = t_begin + j;
+        if (t < T) {
+            const int kk = 16 * t;
+            const float* ap;
+            int lda;
+            if (kk < B.len0p) { ap = A.a0 + kk + 4 * q; lda = A.lda0; }
+            else { ap = A.a1 + (kk - B.len0p) + 4 * q; lda = A.lda1; }
+            f32x4 a[RT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) a[r] = lds_ld4(ap + (r * 16 + i) * lda);
+            if (two) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int r = 0; r < RT; ++r) acc[c][r] = mfma4(a[r][e], bq[j][c][e], acc[c][r]);
             } else {
-                v.x = p[0];
-                if (rem > 1) v.y = p[1];
-                if (rem > 2) v.z = p[2];
-                if (rem > 3) v.w = p[3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) acc[0][r] = mfma4(a[r][e], bq[j][0][e], acc[0][r]);
             }
         }
     }
-    return v;
 }
 
-// acc[ct][rt] += A[16*RT x K] * W'[n0[ct] + 0..15][K]^T, K = len0p + len1p walked 16 at a time.
-template <int RT, int CT, bool VEC>
-__device__ __forceinline__ void wave_gemm(f32x4 (&acc)[2][RT], const ASrc& A, const BSrc& B, const int (&n0)[2]) {
-    const int lane = threadIdx.x & 63;
-    const int i = lane & 15, q = lane >> 4;
-    const int T = (B.len0p + B.len1p) >> 4;
-    float4 bq[3][CT];
-    auto ldb = [&](float4 (&dst)[CT], int t) {
-#pragma unroll
-        for (int c = 0; c < CT; ++c) dst[c] = load_b<VEC>(B, n0[c] + i, 16 * t + 4 * q);
-    };
-    auto comp = [&](const float4 (&b)[CT], int t) {
-        const int kk = 16 * t;
-        const float* ap;
-        int lda;
-        if (kk < B.len0p) { ap = A.a0 + kk + 4 * q; lda = A.lda0; }
-        else { ap = A.a1 + (kk - B.len0p) + 4 * q; lda = A.lda1; }
-        float4 a[RT];
-#pragma unroll
-        for (int r = 0; r < RT; ++r) a[r] = *reinterpret_cast<const float4*>(ap + (r * 16 + i) * lda);
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-            for (int r = 0; r < RT; ++r) acc[c][r] = mfma4(a[r].x, b[c].x, acc[c][r]);
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-            for (int r = 0; r < RT; ++r) acc[c][r] = mfma4(a[r].y, b[c].y, acc[c][r]);
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-            for (int r = 0; r < RT; ++r) acc[c][r] = mfma4(a[r].z, b[c].z, acc[c][r]);
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-            for (int r = 0; r < RT; ++r) acc[c][r] = mfma4(a[r].w, b[c].w, acc[c][r]);
-    };
-    if (T <= 0) return;
-    ldb(bq[0], 0);
-    if (T > 1) ldb(bq[1], 1);
-    for (int t = 0; t < T; t += 3) {
-        if (t + 2 < T) ldb(bq[2], t + 2);
-        comp(bq[0], t);
-        if (t + 1 < T) {
-            if (t + 3 < T) ldb(bq[0], t + 3);
-            comp(bq[1], t + 1);
-        }
-        if (t + 2 < T) {
-            if (t + 4 < T) ldb(bq[1], t + 4);
-            comp(bq[2], t + 2);
-        }
-    }
-}
-
+// acc[ct][rt] += A[16*RT x K] * W'[n0[ct] + 0..15][K]^T, just-in-time form (issue + consume).
 template <int RT>
-__device__ __forceinline__ void wave_gemm_any(f32x4 (&acc)[2][RT], const ASrc& A, const BSrc& B, const int (&n0)[2]) {
+__device__ __forceinline__ void wave_gemm_any(f32x4 (&acc)[2][RT], const ASrc& A, const BSrc& B, const int (&n0)[2],
+                                              int t_begin = 0) {
     const bool two = n0[1] < B.N;
-    if (B.vec) {
-        if (two) wave_gemm<RT, 2, true>(acc, A, B, n0); else wave_gemm<RT, 1, true>(acc, A, B, n0);
-    } else {
-        if (two) wave_gemm<RT, 2, false>(acc, A, B, n0); else wave_gemm<RT, 1, false>(acc, A, B, n0);
+    const int T = bsrc_steps(B);
+    for (int tb = t_begin; tb < T; tb += TQ) {
+        f32x4 bq[TQ][2];
+        if (B.vec) issue_b<TQ, true>(bq, B, n0, tb); else issue_b<TQ, false>(bq, B, n0, tb);
+        consume_b<RT, TQ>(acc, A, B, bq, tb, two);
     }
 }
 
@@ -261,7 +300,7 @@ __device__ __forceinline__ void run_epilogue(const f32x4 (&acc)[2][RT], const in
 #pragma unroll
             for (int r = 0; r < RT; ++r)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) epi(r * 16 + q * 4 + k, col, acc[c][r][k]);
+                for (int k = 0; k < 4; ++k) epi(r * 16 + q * 4 + k, col, c, acc[c][r][k]);
         }
     }
 }
@@ -277,7 +316,7 @@ __device__ __forceinline__ void layer_nt(const ASrc& A, const BSrc& B, Epi&& epi
         f32x4 acc[2][RT];
         zero_acc<RT>(acc);
         wave_gemm_any<RT>(acc, A, B, n0);
-        run_epilogue<RT>(acc, n0, B.N, epi);
+        run_epilogue<RT>(acc, n0, B.N, [&](int row, int col, int, float v) { epi(row, col, v); });
     }
 }
 
@@ -291,19 +330,19 @@ __device__ __forceinline__ void stage_rows(float* dst, int ld_dst, const float* 
     const bool vec = ((ld_src & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
     for (int r = wave; r < rows_pad; r += 4) {
         for (int c = lane * 4; c < cpad; c += 256) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (r < nrows && c < ncols) {
                 const float* p = src + (int64_t)r * ld_src + c;
                 if (vec && c + 3 < ncols) {
-                    v = *reinterpret_cast<const float4*>(p);
+                    v = g_ld4(p);
                 } else {
-                    v.x = p[0];
-                    if (c + 1 < ncols) v.y = p[1];
-                    if (c + 2 < ncols) v.z = p[2];
-                    if (c + 3 < ncols) v.w = p[3];
+                    v.x = g_ld(p);
+                    if (c + 1 < ncols) v.y = g_ld(p + 1);
+                    if (c + 2 < ncols) v.z = g_ld(p + 2);
+                    if (c + 3 < ncols) v.w = g_ld(p + 3);
                 }
             }
-            *reinterpret_cast<float4*>(dst + r * ld_dst + c) = v;
+            lds_st4(dst + r * ld_dst + c, v);
         }
     }
 }
@@ -314,10 +353,9 @@ __device__ __forceinline__ void store_rows(float* __restrict__ dst, const float*
     const bool vec = ((ncols & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
     for (int r = wave; r < nrows; r += 4) {
         if (vec) {
-            for (int c = lane * 4; c < ncols; c += 256)
-                *reinterpret_cast<float4*>(dst + (int64_t)r * ncols + c) = *reinterpret_cast<const float4*>(src + r * ld_src + c);
+            for (int c = lane * 4; c < ncols; c += 256) g_st4(dst + (int64_t)r * ncols + c, lds_ld4(src + r * ld_src + c));
         } else {
-            for (int c = lane; c < ncols; c += 64) dst[(int64_t)r * ncols + c] = src[r * ld_src + c];
+            for (int c = lane; c < ncols; c += 64) g_st(dst + (int64_t)r * ncols + c, lds_ld(src + r * ld_src + c));
         }
     }
 }
@@ -346,10 +384,10 @@ __global__ __launch_bounds__(NT) void k_prepare(const DevPlan* __restrict__ P, m
             const int c = (int)(idx - r * f4) << 2;
             const float* q = x + r * ld + c;
             if (vec) {
-                const float4 v = *reinterpret_cast<const float4*>(q);
+                const f32x4 v = g_ld4(q);
                 bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
             } else {
-                for (int k = 0; k < 4 && c + k < F; ++k) bad |= (q[k] != q[k]);
+                for (int k = 0; k < 4 && c + k < F; ++k) { const float v = g_ld(q + k); bad |= (v != v); }
             }
         }
         if (__any(bad) && (threadIdx.x & 63) == 0) const_cast<int32_t*>(b.nan_flags)[slot] = 1;
@@ -362,44 +400,58 @@ __global__ __launch_bounds__(NT) void k_prepare(const DevPlan* __restrict__ P, m
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = it.r0 + ty + 8 * k, c = it.c0 + tx;
-        tile[ty + 8 * k][tx] = (r < tk.rows && c < tk.cols) ? tk.src[(int64_t)r * tk.ld_src + c] : 0.f;
+        tile[ty + 8 * k][tx] = (r < tk.rows && c < tk.cols) ? g_ld(tk.src + (int64_t)r * tk.ld_src + c) : 0.f;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = it.c0 + ty + 8 * k, r = it.r0 + tx;      // dst[c][r] = src[r][c]
-        if (r < tk.rows && c < tk.cols) tk.dst[(int64_t)c * tk.ld_dst + r] = tile[tx][ty + 8 * k];
+        if (r < tk.rows && c < tk.cols) g_st(tk.dst + (int64_t)c * tk.ld_dst + r, tile[tx][ty + 8 * k]);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The chain kernels read the plan (model descriptor, buffer pointers, offsets) from an LDS copy:
+// one coalesced global read at kernel start instead of a dependent global round trip at every
+// "p.m.enc[e].layer[l].w" (pointer chase -> weights -> bias was 3 serial round trips per layer).
+// ------------------------------------------------------------------------------------------------
+typedef const MMN_AS3 DevPlan LPlan;
+constexpr int PLAN_FLOATS = (int)((sizeof(DevPlan) + 15) / 16) * 4;
+
+__device__ __forceinline__ void copy_plan_to_lds(const DevPlan* P, float* sPlan) {
+    for (int idx = threadIdx.x; idx < PLAN_FLOATS / 4; idx += NT)
+        lds_st4(sPlan + 4 * idx, g_ld4(reinterpret_cast<const float*>(P) + 4 * idx));
 }
 
 // ------------------------------------------------------------------------------------------------
 // decoder evaluation of one state tile (used by k_chain_fwd)
 // ------------------------------------------------------------------------------------------------
 struct DecodeCtx {
-    const DevPlan* p;
-    const mmn_batch* b;
+    LPlan* p;
     float* sZ;
-    float4 wd[4];          // this wave's decoder-weight fragments (constant for the whole kernel)
+    f32x4 wd[4];           // this wave's decoder-weight fragments (constant for the whole kernel)
+    float bd0, bd1;        // this thread's decoder bias pair
+    int y;                 // this thread's target (row, d)
     int row0, nrows, tile;
     float cL;
     int want_grads;
 };
 
-__device__ __forceinline__ void load_decoder_frags(const DevPlan& p, float4 (&wd)[4]) {
+__device__ __forceinline__ void load_decoder_frags(LPlan& p, f32x4 (&wd)[4]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int S = p.S, Tdec = p.S16 >> 4, KD = (Tdec + 3) >> 2;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int t = wave * KD + j;
         if (j < KD && t < Tdec && i < 2 * p.D) {
             const float* w = p.m.dec[i >> 1].w + (i & 1) * S;
             const int k = 16 * t + 4 * q;
-            if (k < S) v.x = w[k];
-            if (k + 1 < S) v.y = w[k + 1];
-            if (k + 2 < S) v.z = w[k + 2];
-            if (k + 3 < S) v.w = w[k + 3];
+            if (k < S) v.x = g_ld(w + k);
+            if (k + 1 < S) v.y = g_ld(w + k + 1);
+            if (k + 2 < S) v.z = g_ld(w + k + 2);
+            if (k + 3 < S) v.w = g_ld(w + k + 3);
         }
         wd[j] = v;
     }
@@ -408,7 +460,7 @@ __device__ __forceinline__ void load_decoder_frags(const DevPlan& p, float4 (&wd
 template <int RT>
 __device__ __forceinline__ void decode_state(const DecodeCtx& c, const float* sS, int grid_row) {
     constexpr int TB = 16 * RT;
-    const DevPlan& p = *c.p;
+    LPlan& p = *c.p;
     const int ldS = p.ldS, D = p.D, R = p.R;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -421,10 +473,10 @@ __device__ __forceinline__ void decode_state(const DecodeCtx& c, const float* sS
     for (int j = 0; j < 4; ++j) {
         const int t = wave * KD + j;
         if (j < KD && t < Tdec) {
-            const float4 bb = c.wd[j];
+            const f32x4 bb = c.wd[j];
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
-                const float4 a = *reinterpret_cast<const float4*>(sS + (r * 16 + i) * ldS + 16 * t + 4 * q);
+                const f32x4 a = lds_ld4(sS + (r * 16 + i) * ldS + 16 * t + 4 * q);
                 z[r] = mfma4(a.x, bb.x, z[r]);
                 z[r] = mfma4(a.y, bb.y, z[r]);
                 z[r] = mfma4(a.z, bb.z, z[r]);
@@ -435,22 +487,21 @@ __device__ __forceinline__ void decode_state(const DecodeCtx& c, const float* sS
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) c.sZ[(wave * TB + r * 16 + q * 4 + k) * 16 + i] = z[r][k];
+        for (int k = 0; k < 4; ++k) lds_st(c.sZ + (wave * TB + r * 16 + q * 4 + k) * 16 + i, z[r][k]);
     __syncthreads();
     const int t = threadIdx.x;
     const int row = t & (TB - 1), d = t / TB;
     float lossv = 0.f;
     int correct = 0, tp = 0, tn = 0, fp = 0, fn = 0;
     if (d < D && row < c.nrows) {
-        const float* bd = p.m.dec[d].b;
-        float za = bd[0], zb = bd[1];
+        float za = c.bd0, zb = c.bd1;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            za += c.sZ[(w * TB + row) * 16 + 2 * d];
-            zb += c.sZ[(w * TB + row) * 16 + 2 * d + 1];
+            za += lds_ld(c.sZ + (w * TB + row) * 16 + 2 * d);
+            zb += lds_ld(c.sZ + (w * TB + row) * 16 + 2 * d + 1);
         }
         const int64_t grow = (int64_t)c.row0 + row;
-        const int y = (int)c.b->y[grow * D + d];
+        const int y = c.y;
         const float o0 = 1.0f / (1.0f + expf(-za));
         const float o1 = 1.0f / (1.0f + expf(-zb));
         const float mx = fmaxf(o0, o1);
@@ -462,11 +513,10 @@ __device__ __forceinline__ void decode_state(const DecodeCtx& c, const float* sS
         if (c.want_grads) {
             const float g0 = expf(o0 - lse) - (y == 0 ? 1.0f : 0.0f);
             const float g1 = expf(o1 - lse) - (y == 1 ? 1.0f : 0.0f);
-            float2 dzv;
+            f32x2 dzv;
             dzv.x = c.cL * g0 * o0 * (1.0f - o0);
             dzv.y = c.cL * g1 * o1 * (1.0f - o1);
-            float* dz = p.dz + ((int64_t)grid_row * p.maxB + grow) * (2 * D) + 2 * d;
-            *reinterpret_cast<float2*>(dz) = dzv;
+            g_st2(p.dz + ((int64_t)grid_row * p.maxB + grow) * (2 * D) + 2 * d, dzv);
         }
     }
 #pragma unroll
@@ -477,22 +527,23 @@ __device__ __forceinline__ void decode_state(const DecodeCtx& c, const float* sS
         const int sh = lane & ~(TB - 1);
         const unsigned long long msk = (TB == 32) ? 0xFFFFFFFFull : 0xFFFFull;
         const int64_t cell = (int64_t)c.tile * (R * D) + grid_row * D + d;
-        p.lossp[cell] = lossv;
+        g_st(p.lossp + cell, lossv);
         int32_t* cp = p.cntp + cell * 5;
-        cp[0] = __popcll((mc >> sh) & msk);
-        cp[1] = __popcll((mtp >> sh) & msk);
-        cp[2] = __popcll((mtn >> sh) & msk);
-        cp[3] = __popcll((mfp >> sh) & msk);
-        cp[4] = __popcll((mfn >> sh) & msk);
+        g_sti(cp + 0, __popcll((mc >> sh) & msk));
+        g_sti(cp + 1, __popcll((mtp >> sh) & msk));
+        g_sti(cp + 2, __popcll((mtn >> sh) & msk));
+        g_sti(cp + 3, __popcll((mfp >> sh) & msk));
+        g_sti(cp + 4, __popcll((mfn >> sh) & msk));
     }
     __syncthreads();
 }
 
 // LDS carve of the two chain kernels (floats)
-struct ChainLds { int sS0, sS1, sDiff, sH0, sH1, sX, sZ, sRed, total; };
+struct ChainLds { int sPlan, sS0, sS1, sDiff, sH0, sH1, sX, sZ, sRed, total; };
 __host__ __device__ inline ChainLds chain_lds(int TB, int ldS, int ldH) {
     ChainLds L;
     int o = 0;
+    L.sPlan = o; o += PLAN_FLOATS;
     L.sS0 = o; o += TB * ldS;
     L.sS1 = o; o += TB * ldS;
     L.sDiff = o; o += TB * ldS;
@@ -508,14 +559,95 @@ __host__ __device__ inline ChainLds chain_lds(int TB, int ldS, int ldH) {
 // ------------------------------------------------------------------------------------------------
 // k_chain_fwd
 // ------------------------------------------------------------------------------------------------
+// Registers that hold one encoder's inputs ahead of time: its x tile, the weight fragments of up
+// to two hidden layers (<= 4 k-steps each) and of the state update (<= TQ k-steps), and biases.
+template <int NS> struct LayerRegs { f32x4 b[NS][2]; float bias[2]; };
+template <int RT> struct EncRegs {
+    f32x4 x[2 * RT];
+    LayerRegs<4> h0, h1;
+    LayerRegs<TQ> last;
+};
+struct EncInfo { int t, e, slot, Lh, F, HL, akind; bool fast; };
+
+// next executed sequence position >= t (NaN-skipped slots are passed over), or n_seq
+__device__ __forceinline__ int next_exec(const mmn_batch& b, int t) {
+    while (t < b.n_seq && !slot_present(b, b.seq_data[t])) ++t;
+    return t;
+}
+
+__device__ __forceinline__ EncInfo enc_info(LPlan& p, const mmn_batch& b, int t) {
+    EncInfo I;
+    I.t = t; I.slot = b.seq_data[t]; I.e = b.seq_enc[t];
+    const auto& enc = p.m.enc[I.e];
+    const int S = p.S;
+    I.Lh = enc.n_layers - 1; I.F = enc.n_features; I.akind = enc.activation;
+    I.HL = enc.layer[I.Lh].in_dim - S;
+    // eligibility of the register-prefetch path (everything else takes the just-in-time path)
+    const float* x = b.x[I.slot];
+    bool ok = I.Lh <= 2 && I.F <= XCH && (I.F & 3) == 0 && (b.ldx[I.slot] & 3) == 0 &&
+              (reinterpret_cast<uintptr_t>(x) & 15) == 0 && S <= 128 && (S & 3) == 0 && (I.HL & 3) == 0 &&
+              (p.S16 + round_up(I.HL, 16)) <= 16 * TQ && (reinterpret_cast<uintptr_t>(enc.layer[I.Lh].w) & 15) == 0;
+    for (int l = 0; l < I.Lh && l < 2; ++l) {
+        const auto& lin = enc.layer[l];
+        ok = ok && lin.in_dim <= 64 && (lin.in_dim & 3) == 0 && lin.out_dim <= 128 &&
+             (reinterpret_cast<uintptr_t>(lin.w) & 15) == 0;
+    }
+    I.fast = ok;
+    return I;
+}
+
+template <int RT>
+__device__ __forceinline__ void issue_encoder(EncRegs<RT>& R, LPlan& p, const mmn_batch& b, const EncInfo& I, int row0,
+                                              int nrows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15;
+    const auto& enc = p.m.enc[I.e];
+    const int S = p.S;
+    const int n0[2] = {16 * wave, 16 * (wave + 4)};
+    // x tile [TB x 128]: thread -> (row, 4 columns), clamped + masked
+    const float* xg = b.x[I.slot] + (int64_t)row0 * b.ldx[I.slot];
+    const int64_t ldx = b.ldx[I.slot];
+#pragma unroll
+    for (int k = 0; k < 2 * RT; ++k) {
+        const int idx = threadIdx.x + NT * k;
+        const int row = idx >> 5, c = (idx & 31) << 2;
+        const bool ok = row < nrows && c < I.F;
+        const f32x4 v = g_ld4(xg + (ok ? (int64_t)row * ldx + c : 0));
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        R.x[k] = ok ? v : z;
+    }
+    if (I.Lh >= 1) {
+        const auto& lin = enc.layer[0];
+        const BSrc B = make_bsrc(lin.w, lin.in_dim, lin.out_dim, lin.in_dim, 0, 0, 0);
+        issue_b<4, true>(R.h0.b, B, n0, 0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) R.h0.bias[c] = g_ld(lin.b + min(n0[c] + i, lin.out_dim - 1));
+    }
+    if (I.Lh >= 2) {
+        const auto& lin = enc.layer[1];
+        const BSrc B = make_bsrc(lin.w, lin.in_dim, lin.out_dim, lin.in_dim, 0, 0, 0);
+        issue_b<4, true>(R.h1.b, B, n0, 0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) R.h1.bias[c] = g_ld(lin.b + min(n0[c] + i, lin.out_dim - 1));
+    }
+    {
+        const auto& lin = enc.layer[I.Lh];
+        const BSrc B = make_bsrc(lin.w, lin.in_dim, S, S, I.HL, I.HL, 0);
+        issue_b<TQ, true>(R.last.b, B, n0, 0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) R.last.bias[c] = g_ld(lin.b + min(n0[c] + i, S - 1));
+    }
+}
+
 template <int RT>
 __global__ __launch_bounds__(NT) void k_chain_fwd(const DevPlan* __restrict__ P, mmn_batch b, float cL,
                                                   int want_grads) {
     constexpr int TB = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const DevPlan& p = *P;
-    const int S = p.S, E = p.E, ldS = p.ldS, ldH = p.ldH;
+    // the carve needs ldS / ldH before the LDS copy of the plan exists: two scalar loads
+    const int ldS = P->ldS, ldH = P->ldH;
     const ChainLds L = chain_lds(TB, ldS, ldH);
+    copy_plan_to_lds(P, smem + L.sPlan);
     float* sS[2] = {smem + L.sS0, smem + L.sS1};
     float* sH[2] = {smem + L.sH0, smem + L.sH1};
     float* sX = smem + L.sX;
@@ -524,137 +656,243 @@ __global__ __launch_bounds__(NT) void k_chain_fwd(const DevPlan* __restrict__ P,
     const int row0 = tile * TB;
     const int nrows = min(TB, b.batch - row0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15;
+    int stamp_k = 0;
+    const int stamp_block = 7;
+    __syncthreads();
+    LPlan& p = *(LPlan*)(smem + L.sPlan);
+    const int S = p.S, E = p.E;
+    STAMP();
 
     for (int idx = threadIdx.x; idx < TB * ldS; idx += NT) {
         const int k = idx % ldS;
-        sS[0][idx] = k < S ? p.m.init_state[k] : 0.f;       // state.py:29-32 (tile, never materialised)
-        sS[1][idx] = 0.f;
+        lds_st(sS[0] + idx, k < S ? g_ld(p.m.init_state + k) : 0.f);   // state.py:29-32 (tile, never materialised)
+        lds_st(sS[1] + idx, 0.f);
     }
-    for (int idx = threadIdx.x; idx < TB * ldH; idx += NT) { sH[0][idx] = 0.f; sH[1][idx] = 0.f; }
-    for (int idx = threadIdx.x; idx < TB * LDX; idx += NT) sX[idx] = 0.f;
+    for (int idx = threadIdx.x; idx < TB * ldH; idx += NT) { lds_st(sH[0] + idx, 0.f); lds_st(sH[1] + idx, 0.f); }
+    for (int idx = threadIdx.x; idx < TB * LDX; idx += NT) lds_st(sX + idx, 0.f);
     if (tile == 0 && threadIdx.x == 0) {                   // which state rows exist this step
-        p.exec_flags[0] = 1;
-        for (int e = 0; e < E; ++e) p.exec_flags[e + 1] = 0;
+        g_sti(p.exec_flags, 1);
+        for (int e = 0; e < E; ++e) g_sti(p.exec_flags + e + 1, 0);
         int prev = 0;
         for (int t = 0; t < b.n_seq; ++t) {
             if (!slot_present(b, b.seq_data[t])) continue;
             const int e = b.seq_enc[t];
-            p.exec_flags[e + 1] = 1;
-            p.prev_row[e] = prev;
+            g_sti(p.exec_flags + e + 1, 1);
+            g_sti(p.prev_row + e, prev);
             prev = e + 1;
         }
     }
     DecodeCtx dc;
-    dc.p = P; dc.b = &b; dc.sZ = smem + L.sZ; dc.row0 = row0; dc.nrows = nrows; dc.tile = tile; dc.cL = cL;
+    dc.p = &p; dc.sZ = smem + L.sZ; dc.row0 = row0; dc.nrows = nrows; dc.tile = tile; dc.cL = cL;
     dc.want_grads = want_grads;
     load_decoder_frags(p, dc.wd);
+    {
+        const int row = threadIdx.x & (TB - 1), d = threadIdx.x / TB;
+        const bool ok = d < p.D && row < nrows;
+        dc.y = ok ? (int)*(const MMN_AS1 int64_t*)(b.y + ((int64_t)row0 + row) * p.D + d) : 0;
+        const float* bd = p.m.dec[ok ? d : 0].b;
+        dc.bd0 = g_ld(bd); dc.bd1 = g_ld(bd + 1);
+    }
+    // prefetch the first encoder's inputs behind the decode of the init state
+    EncRegs<RT> R;
+    int tn = next_exec(b, 0);
+    bool have = false;
+    if (tn < b.n_seq) {
+        const EncInfo I = enc_info(p, b, tn);
+        if (I.fast) { issue_encoder<RT>(R, p, b, I, row0, nrows); have = true; }
+    }
     __syncthreads();
 
     int cur = 0;
+    STAMP();
     decode_state<RT>(dc, sS[cur], 0);
+    STAMP();
 
-    for (int t = 0; t < b.n_seq; ++t) {
-        const int slot = b.seq_data[t];
-        if (!slot_present(b, slot)) continue;              // multimodn.py:168-169
-        const int e = b.seq_enc[t];
-        const mmn_encoder& enc = p.m.enc[e];
-        const int nl = enc.n_layers, Lh = nl - 1;
-        const int F = enc.n_features;
-        const float* xg = b.x[slot] + (int64_t)row0 * b.ldx[slot];
-        const int64_t ldx = b.ldx[slot];
-        const int akind = enc.activation;
+    while (tn < b.n_seq) {
+        const EncInfo I = enc_info(p, b, tn);
+        const int e = I.e, Lh = I.Lh, F = I.F, HL = I.HL, akind = I.akind;
+        const auto& enc = p.m.enc[e];
+        const float* xg = b.x[I.slot] + (int64_t)row0 * b.ldx[I.slot];
+        const int64_t ldx = b.ldx[I.slot];
+        const int n0[2] = {16 * wave, 16 * (wave + 4)};
+        const int t_next = next_exec(b, tn + 1);
+        STAMP();
+        float scacc = 0.f;
+        const float* sC = sS[cur];
+        float* sN = sS[cur ^ 1];
 
-        // hidden layers: h = act(W h + b) on x only (mlp_encoder.py:75-76)
-        for (int l = 0; l < Lh; ++l) {
-            const mmn_linear& lin = enc.layer[l];
-            const int N = lin.out_dim;
-            float* out = sH[(Lh - 1 - l) & 1];
-            const float* bias = lin.b;
-            auto epi = [&](int row, int col, float v) {
-                if (col < N) out[row * ldH + col] = act_fwd(v + bias[col], akind);
-            };
-            if (l == 0) {
-                const int ntiles = (N + 15) >> 4;
-                for (int base = 0; base < ntiles; base += 8) {
-                    const int n0[2] = {16 * (base + wave), 16 * (base + wave + 4)};
-                    f32x4 acc[2][RT];
-                    zero_acc<RT>(acc);
-                    for (int xc = 0; xc < F; xc += XCH) {
-                        const int kw = min(XCH, F - xc);
-                        stage_rows(sX, LDX, xg + xc, ldx, nrows, TB, kw);
-                        __syncthreads();
-                        if (n0[0] < N) {
-                            const ASrc A{sX, LDX, sX, LDX};
-                            const BSrc B = make_bsrc(lin.w, lin.in_dim, N, kw, xc, 0, 0);
-                            wave_gemm_any<RT>(acc, A, B, n0);
-                        }
-                        __syncthreads();
-                    }
-                    if (n0[0] < N) run_epilogue<RT>(acc, n0, N, epi);
-                }
-            } else {
-                const float* in = sH[(Lh - l) & 1];
-                const ASrc A{in, ldH, in, ldH};
-                const BSrc B = make_bsrc(lin.w, lin.in_dim, N, lin.in_dim, 0, 0, 0);
-                layer_nt<RT>(A, B, epi);
+        if (I.fast) {
+            if (!have) issue_encoder<RT>(R, p, b, I, row0, nrows);   // previous encoder was not prefetchable
+            // ---- x registers -> LDS image (whole [TB x 128] image, zero padded)
+#pragma unroll
+            for (int k = 0; k < 2 * RT; ++k) {
+                const int idx = threadIdx.x + NT * k;
+                lds_st4(sX + (idx >> 5) * LDX + ((idx & 31) << 2), R.x[k]);
             }
             __syncthreads();
-            if (want_grads) store_rows(p.hid + p.hid_off[e][l] + (int64_t)row0 * N, out, ldH, nrows, N);
-        }
-        // state update: s' = W [h ; s] + b, no activation (mlp_encoder.py:78); the contraction
-        // runs over the state columns first, then the h columns
-        {
-            const mmn_linear& lin = enc.layer[nl - 1];
-            const int HL = lin.in_dim - S;
-            const float* bias = lin.b;
-            const float* sC = sS[cur];
-            float* sN = sS[cur ^ 1];
-            float scacc = 0.f;
-            auto epi = [&](int row, int col, float v) {
-                if (col < S) {
-                    const float ns = v + bias[col];
-                    const float dlt = ns - sC[row * ldS + col];
-                    if (row < nrows) scacc += dlt * dlt;              // multimodn.py:174
-                    sN[row * ldS + col] = ns;
-                }
-            };
-            if (Lh > 0) {
-                const ASrc A{sC, ldS, sH[0], ldH};
-                const BSrc B = make_bsrc(lin.w, lin.in_dim, S, S, HL, HL, 0);
-                layer_nt<RT>(A, B, epi);
-            } else {
-                const int ntiles = (S + 15) >> 4;
-                for (int base = 0; base < ntiles; base += 8) {
-                    const int n0[2] = {16 * (base + wave), 16 * (base + wave + 4)};
+            // ---- hidden layers from prefetched fragments (mlp_encoder.py:75-76)
+            if (Lh >= 1) {
+                const auto& lin = enc.layer[0];
+                const int N = lin.out_dim;
+                float* out = sH[(Lh - 1) & 1];
+                if (n0[0] < N) {
                     f32x4 acc[2][RT];
                     zero_acc<RT>(acc);
-                    if (n0[0] < S) {
-                        const ASrc A{sC, ldS, sC, ldS};
-                        const BSrc B = make_bsrc(lin.w, lin.in_dim, S, S, HL, 0, 0);
-                        wave_gemm_any<RT>(acc, A, B, n0);
-                    }
-                    for (int xc = 0; xc < F; xc += XCH) {
-                        const int kw = min(XCH, F - xc);
-                        stage_rows(sX, LDX, xg + xc, ldx, nrows, TB, kw);
-                        __syncthreads();
-                        if (n0[0] < S) {
-                            const ASrc A{sX, LDX, sX, LDX};
-                            const BSrc B = make_bsrc(lin.w, lin.in_dim, S, kw, xc, 0, 0);
-                            wave_gemm_any<RT>(acc, A, B, n0);
+                    const ASrc A{sX, LDX, sX, LDX};
+                    const BSrc B = make_bsrc(lin.w, lin.in_dim, N, lin.in_dim, 0, 0, 0);
+                    consume_b<RT, 4>(acc, A, B, R.h0.b, 0, n0[1] < N);
+                    run_epilogue<RT>(acc, n0, N, [&](int row, int col, int c, float v) {
+                        if (col < N) lds_st(out + row * ldH + col, act_fwd(v + R.h0.bias[c], akind));
+                    });
+                }
+                __syncthreads();
+                if (want_grads) store_rows(p.hid + p.hid_off[e][0] + (int64_t)row0 * N, out, ldH, nrows, N);
+            }
+            if (Lh >= 2) {
+                const auto& lin = enc.layer[1];
+                const int N = lin.out_dim;
+                const float* in = sH[1];
+                float* out = sH[0];
+                if (n0[0] < N) {
+                    f32x4 acc[2][RT];
+                    zero_acc<RT>(acc);
+                    const ASrc A{in, ldH, in, ldH};
+                    const BSrc B = make_bsrc(lin.w, lin.in_dim, N, lin.in_dim, 0, 0, 0);
+                    consume_b<RT, 4>(acc, A, B, R.h1.b, 0, n0[1] < N);
+                    run_epilogue<RT>(acc, n0, N, [&](int row, int col, int c, float v) {
+                        if (col < N) lds_st(out + row * ldH + col, act_fwd(v + R.h1.bias[c], akind));
+                    });
+                }
+                __syncthreads();
+                if (want_grads) store_rows(p.hid + p.hid_off[e][1] + (int64_t)row0 * N, out, ldH, nrows, N);
+            }
+            STAMP();
+            // ---- state update s' = W [h ; s] + b (mlp_encoder.py:78), state columns first
+            {
+                const auto& lin = enc.layer[Lh];
+                f32x4 acc[2][RT];
+                zero_acc<RT>(acc);
+                const float bias0 = R.last.bias[0], bias1 = R.last.bias[1];
+                if (n0[0] < S) {
+                    const ASrc A{sC, ldS, Lh > 0 ? sH[0] : sX, Lh > 0 ? ldH : LDX};
+                    const BSrc B = make_bsrc(lin.w, lin.in_dim, S, S, HL, HL, 0);
+                    consume_b<RT, TQ>(acc, A, B, R.last.b, 0, n0[1] < S);
+                }
+                STAMP();
+                // R is dead now: request the NEXT encoder's inputs; they land while this encoder's
+                // epilogue, stores and decoder grid run
+                have = false;
+                if (t_next < b.n_seq) {
+                    const EncInfo J = enc_info(p, b, t_next);
+                    if (J.fast) { issue_encoder<RT>(R, p, b, J, row0, nrows); have = true; }
+                }
+                if (n0[0] < S) {
+                    run_epilogue<RT>(acc, n0, S, [&](int row, int col, int c, float v) {
+                        if (col < S) {
+                            const float ns = v + (c ? bias1 : bias0);
+                            const float dlt = ns - lds_ld(sC + row * ldS + col);
+                            if (row < nrows) scacc += dlt * dlt;              // multimodn.py:174
+                            lds_st(sN + row * ldS + col, ns);
                         }
-                        __syncthreads();
-                    }
-                    if (n0[0] < S) run_epilogue<RT>(acc, n0, S, epi);
+                    });
                 }
             }
-            scacc = wave_sum(scacc);
-            if (lane == 0) sRed[wave] = scacc;
-            __syncthreads();
-            if (threadIdx.x == 0) p.scp[(int64_t)tile * E + e] = sRed[0] + sRed[1] + sRed[2] + sRed[3];
-            if (want_grads) store_rows(p.states + ((int64_t)e * p.maxB + row0) * S, sN, ldS, nrows, S);
-            cur ^= 1;
+        } else {
+            have = false;
+            // ---- just-in-time path: any shape
+            for (int l = 0; l < Lh; ++l) {
+                const auto& lin = enc.layer[l];
+                const int N = lin.out_dim;
+                float* out = sH[(Lh - 1 - l) & 1];
+                const float* bias = lin.b;
+                auto epi = [&](int row, int col, int, float v) {
+                    if (col < N) lds_st(out + row * ldH + col, act_fwd(v + g_ld(bias + col), akind));
+                };
+                if (l == 0) {
+                    const int ntiles = (N + 15) >> 4;
+                    for (int base = 0; base < ntiles; base += 8) {
+                        const int m0[2] = {16 * (base + wave), 16 * (base + wave + 4)};
+                        f32x4 acc[2][RT];
+                        zero_acc<RT>(acc);
+                        for (int xc = 0; xc < F; xc += XCH) {
+                            const int kw = min(XCH, F - xc);
+                            stage_rows(sX, LDX, xg + xc, ldx, nrows, TB, kw);
+                            __syncthreads();
+                            if (m0[0] < N) {
+                                const ASrc A{sX, LDX, sX, LDX};
+                                const BSrc B = make_bsrc(lin.w, lin.in_dim, N, kw, xc, 0, 0);
+                                wave_gemm_any<RT>(acc, A, B, m0);
+                            }
+                            __syncthreads();
+                        }
+                        if (m0[0] < N) run_epilogue<RT>(acc, m0, N, epi);
+                    }
+                } else {
+                    const float* in = sH[(Lh - l) & 1];
+                    const ASrc A{in, ldH, in, ldH};
+                    const BSrc B = make_bsrc(lin.w, lin.in_dim, N, lin.in_dim, 0, 0, 0);
+                    layer_nt<RT>(A, B, [&](int row, int col, float v) { epi(row, col, 0, v); });
+                }
+                __syncthreads();
+                if (want_grads) store_rows(p.hid + p.hid_off[e][l] + (int64_t)row0 * N, out, ldH, nrows, N);
+            }
+            STAMP();
+            {
+                const auto& lin = enc.layer[Lh];
+                const float* bias = lin.b;
+                auto epi = [&](int row, int col, int, float v) {
+                    if (col < S) {
+                        const float ns = v + g_ld(bias + col);
+                        const float dlt = ns - lds_ld(sC + row * ldS + col);
+                        if (row < nrows) scacc += dlt * dlt;              // multimodn.py:174
+                        lds_st(sN + row * ldS + col, ns);
+                    }
+                };
+                if (Lh > 0) {
+                    const ASrc A{sC, ldS, sH[0], ldH};
+                    const BSrc B = make_bsrc(lin.w, lin.in_dim, S, S, HL, HL, 0);
+                    layer_nt<RT>(A, B, [&](int row, int col, float v) { epi(row, col, 0, v); });
+                } else {
+                    const int ntiles = (S + 15) >> 4;
+                    for (int base = 0; base < ntiles; base += 8) {
+                        const int m0[2] = {16 * (base + wave), 16 * (base + wave + 4)};
+                        f32x4 acc[2][RT];
+                        zero_acc<RT>(acc);
+                        if (m0[0] < S) {
+                            const ASrc A{sC, ldS, sC, ldS};
+                            const BSrc B = make_bsrc(lin.w, lin.in_dim, S, S, HL, 0, 0);
+                            wave_gemm_any<RT>(acc, A, B, m0);
+                        }
+                        for (int xc = 0; xc < F; xc += XCH) {
+                            const int kw = min(XCH, F - xc);
+                            stage_rows(sX, LDX, xg + xc, ldx, nrows, TB, kw);
+                            __syncthreads();
+                            if (m0[0] < S) {
+                                const ASrc A{sX, LDX, sX, LDX};
+                                const BSrc B = make_bsrc(lin.w, lin.in_dim, S, kw, xc, 0, 0);
+                                wave_gemm_any<RT>(acc, A, B, m0);
+                            }
+                            __syncthreads();
+                        }
+                        if (m0[0] < S) run_epilogue<RT>(acc, m0, S, epi);
+                    }
+                }
+            }
+            STAMP();
         }
+        STAMP();
+        scacc = wave_sum(scacc);
+        if (lane == 0) lds_st(sRed + wave, scacc);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            g_st(p.scp + (int64_t)tile * E + e, ((lds_ld(sRed) + lds_ld(sRed + 1)) + lds_ld(sRed + 2)) + lds_ld(sRed + 3));
+        if (want_grads) store_rows(p.states + ((int64_t)e * p.maxB + row0) * S, sN, ldS, nrows, S);
+        cur ^= 1;
+        STAMP();
         decode_state<RT>(dc, sS[cur], e + 1);
+        STAMP();
+        tn = t_next;
     }
 }
 
@@ -667,8 +905,8 @@ __device__ __forceinline__ void load_dz_tile(const DevPlan& p, float* sDz, int g
     for (int idx = threadIdx.x; idx < TB * 16; idx += NT) {
         const int row = idx >> 4, n = idx & 15;
         float v = 0.f;
-        if (row < nrows && n < D2) v = p.dz[((int64_t)grid_row * p.maxB + row0 + row) * D2 + n];
-        sDz[row * LDZ + n] = v;
+        if (row < nrows && n < D2) v = g_ld(p.dz + ((int64_t)grid_row * p.maxB + row0 + row) * D2 + n);
+        lds_st(sDz + row * LDZ + n, v);
     }
 }
 
@@ -680,10 +918,10 @@ __device__ __forceinline__ void apply_act_grad(float* sBuf, int ld, const float*
         for (int c = lane; c < H; c += 64) {
             float dp = 0.f;
             if (r < nrows) {
-                dp = sBuf[r * ld + c] * act_grad_from_out(hid_g[(int64_t)r * H + c], akind);
-                dpre_g[(int64_t)r * H + c] = dp;
+                dp = lds_ld(sBuf + r * ld + c) * act_grad_from_out(g_ld(hid_g + (int64_t)r * H + c), akind);
+                g_st(dpre_g + (int64_t)r * H + c, dp);
             }
-            sBuf[r * ld + c] = dp;
+            lds_st(sBuf + r * ld + c, dp);
         }
     }
 }
@@ -704,9 +942,9 @@ __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P,
     const int nrows = min(TB, b.batch - row0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    for (int idx = threadIdx.x; idx < TB * ldS; idx += NT) { sG[0][idx] = 0.f; sG[1][idx] = 0.f; sDiff[idx] = 0.f; }
-    for (int idx = threadIdx.x; idx < TB * ldH; idx += NT) { sH[0][idx] = 0.f; sH[1][idx] = 0.f; }
-    for (int idx = threadIdx.x; idx < TB * LDZ; idx += NT) sDz[idx] = 0.f;
+    for (int idx = threadIdx.x; idx < TB * ldS; idx += NT) { lds_st(sG[0] + idx, 0.f); lds_st(sG[1] + idx, 0.f); lds_st(sDiff + idx, 0.f); }
+    for (int idx = threadIdx.x; idx < TB * ldH; idx += NT) { lds_st(sH[0] + idx, 0.f); lds_st(sH[1] + idx, 0.f); }
+    for (int idx = threadIdx.x; idx < TB * LDZ; idx += NT) lds_st(sDz + idx, 0.f);
     __syncthreads();
 
     const ASrc Adz{sDz, LDZ, sDz, LDZ};
@@ -734,16 +972,16 @@ __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P,
             const float* si = prev_row ? p.states + ((int64_t)(prev_row - 1) * p.maxB + row0) * S : nullptr;
             for (int r = wave; r < nrows; r += 4)
                 for (int c = lane; c < S; c += 64) {
-                    const float a = so[(int64_t)r * S + c];
-                    const float d = si ? si[(int64_t)r * S + c] : p.m.init_state[c];
-                    sDiff[r * ldS + c] = a - d;
+                    const float a = g_ld(so + (int64_t)r * S + c);
+                    const float d = si ? g_ld(si + (int64_t)r * S + c) : g_ld(p.m.init_state + c);
+                    lds_st(sDiff + r * ldS + c, a - d);
                 }
             load_dz_tile<TB>(p, sDz, e + 1, row0, nrows);
         }
         __syncthreads();
         // G_out = carry + decoder grad of row e+1 + cS * diff
         layer_nt<RT>(Adz, Bdz, [&](int row, int col, float v) {
-            if (col < S) G[row * ldS + col] += v + cS * sDiff[row * ldS + col];
+            if (col < S) lds_st(G + row * ldS + col, lds_ld(G + row * ldS + col) + v + cS * lds_ld(sDiff + row * ldS + col));
         });
         __syncthreads();
         store_rows(p.dS + ((int64_t)e * p.maxB + row0) * S, G, ldS, nrows, S);
@@ -755,13 +993,13 @@ __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P,
             if (Lh > 0) {
                 const BSrc B = make_bsrc(wT, S, HL + S, S, 0, 0, 0);
                 layer_nt<RT>(A, B, [&](int row, int col, float v) {
-                    if (col < HL) dh[row * ldH + col] = v;
-                    else if (col < HL + S) Gn[row * ldS + (col - HL)] = v - cS * sDiff[row * ldS + (col - HL)];
+                    if (col < HL) lds_st(dh + row * ldH + col, v);
+                    else if (col < HL + S) lds_st(Gn + row * ldS + (col - HL), v - cS * lds_ld(sDiff + row * ldS + (col - HL)));
                 });
             } else {
                 const BSrc B = make_bsrc(wT + (int64_t)HL * S, S, S, S, 0, 0, 0);
                 layer_nt<RT>(A, B, [&](int row, int col, float v) {
-                    if (col < S) Gn[row * ldS + col] = v - cS * sDiff[row * ldS + col];
+                    if (col < S) lds_st(Gn + row * ldS + col, v - cS * lds_ld(sDiff + row * ldS + col));
                 });
             }
         }
@@ -779,7 +1017,7 @@ __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P,
             const ASrc A{cbuf, ldH, cbuf, ldH};
             const BSrc B = make_bsrc(p.wT + p.wt_off[e][l], Hl, Hp, Hl, 0, 0, 0);   // W_l^T [Hp x Hl]
             layer_nt<RT>(A, B, [&](int row, int col, float v) {
-                if (col < Hp) nbuf[row * ldH + col] = v;
+                if (col < Hp) lds_st(nbuf + row * ldH + col, v);
             });
             __syncthreads();
         }
@@ -790,7 +1028,7 @@ __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P,
     load_dz_tile<TB>(p, sDz, 0, row0, nrows);
     __syncthreads();
     layer_nt<RT>(Adz, Bdz, [&](int row, int col, float v) {
-        if (col < S) G[row * ldS + col] += v;
+        if (col < S) lds_st(G + row * ldS + col, lds_ld(G + row * ldS + col) + v);
     });
     __syncthreads();
     store_rows(p.dS + ((int64_t)E * p.maxB + row0) * S, G, ldS, nrows, S);
@@ -841,15 +1079,15 @@ __device__ __forceinline__ void load_frag(float (&dst)[V], const float* __restri
     if (!row_ok || first >= limit) return;
     const float* ptr = base + off + first;
     if (V == 4 && vec_ok && first + 3 < limit) {
-        const float4 v = *reinterpret_cast<const float4*>(ptr);
+        const f32x4 v = g_ld4(ptr);
         dst[0] = v.x; dst[V > 1 ? 1 : 0] = v.y; dst[V > 2 ? 2 : 0] = v.z; dst[V > 3 ? 3 : 0] = v.w;
     } else if (V == 2 && vec_ok && first + 1 < limit) {
-        const float2 v = *reinterpret_cast<const float2*>(ptr);
+        const f32x2 v = g_ld2(ptr);
         dst[0] = v.x; dst[V > 1 ? 1 : 0] = v.y;
     } else {
 #pragma unroll
         for (int k = 0; k < V; ++k)
-            if (first + k < limit) dst[k] = ptr[k];
+            if (first + k < limit) dst[k] = g_ld(ptr + k);
     }
 }
 
@@ -919,12 +1157,12 @@ __device__ __forceinline__ void wgrad_tile(const DevPlan& p, const WTask& tk, co
 #pragma unroll
         for (int d = 0; d < NTL; ++d)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) mine[(MT * (4 * q + k) + c) * TILE_LD + NTL * i + d] = acc[c][d][k];
+            for (int k = 0; k < 4; ++k) lds_st(mine + (MT * (4 * q + k) + c) * TILE_LD + NTL * i + d, acc[c][d][k]);
     if (bias && i == 0) {
 #pragma unroll
         for (int c = 0; c < MT; ++c)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sBias[wave * 64 + MT * (4 * q + k) + c] = accb[c][k];
+            for (int k = 0; k < 4; ++k) lds_st(sBias + wave * 64 + MT * (4 * q + k) + c, accb[c][k]);
     }
     __syncthreads();
     float* slab = p.slabs + tk.slab_base + (int64_t)it.ks * tk.pstride;
@@ -937,15 +1175,17 @@ __device__ __forceinline__ void wgrad_tile(const DevPlan& p, const WTask& tk, co
             const int m = it.m0 + ml, n = it.n0 + nl;
             if (m < M && n < ncols) {
                 const float* s = sTile + ml * TILE_LD + nl;
-                slab[(int64_t)m * ntot + col_off + nl] =
-                    ((s[0] + s[64 * TILE_LD]) + s[2 * 64 * TILE_LD]) + s[3 * 64 * TILE_LD];
+                g_st(slab + (int64_t)m * ntot + col_off + nl,
+                     ((lds_ld(s) + lds_ld(s + 64 * TILE_LD)) + lds_ld(s + 2 * 64 * TILE_LD)) + lds_ld(s + 3 * 64 * TILE_LD));
             }
         }
     }
     if (bias) {
         for (int ml = threadIdx.x; ml < 16 * MT; ml += NT) {
             const int m = it.m0 + ml;
-            if (m < M) slab[(int64_t)m * ntot + (ntot - 1)] = ((sBias[ml] + sBias[64 + ml]) + sBias[128 + ml]) + sBias[192 + ml];
+            if (m < M)
+                g_st(slab + (int64_t)m * ntot + (ntot - 1),
+                     ((lds_ld(sBias + ml) + lds_ld(sBias + 64 + ml)) + lds_ld(sBias + 128 + ml)) + lds_ld(sBias + 192 + ml));
         }
     }
 }
@@ -1036,8 +1276,8 @@ __global__ __launch_bounds__(NT) void k_reduce(const DevPlan* __restrict__ P, in
         const int m = local / sg.kdiv, n = local - m * sg.kdiv;
         const float* src = p.slabs + sg.slab_base + (int64_t)(sg.row_off + m) * sg.ntot + n + sg.coff;
         float sum = 0.f;
-        for (int k = 0; k < sg.n_partials; ++k) sum += src[(int64_t)k * sg.pstride];
-        sg.dst[local] = sum;
+        for (int k = 0; k < sg.n_partials; ++k) sum += g_ld(src + (int64_t)k * sg.pstride);
+        g_st(sg.dst + local, sum);
         return;
     }
     // stats block: one wave per quantity, lanes over tiles, butterfly sum (fixed order)
@@ -1051,13 +1291,13 @@ __global__ __launch_bounds__(NT) void k_reduce(const DevPlan* __restrict__ P, in
         float fs = 0.f;
         int is = 0;
         if (qd < RD) {
-            if (p.exec_flags[qd / D]) for (int t = lane; t < n_tiles; t += 64) fs += p.lossp[(int64_t)t * RD + qd];
+            if (p.exec_flags[qd / D]) for (int t = lane; t < n_tiles; t += 64) fs += g_ld(p.lossp + (int64_t)t * RD + qd);
         } else if (qd < RD + E) {
             const int e = qd - RD;
-            if (p.exec_flags[e + 1]) for (int t = lane; t < n_tiles; t += 64) fs += p.scp[(int64_t)t * E + e];
+            if (p.exec_flags[e + 1]) for (int t = lane; t < n_tiles; t += 64) fs += g_ld(p.scp + (int64_t)t * E + e);
         } else {
             const int k = (qd - RD - E) / RD, cell = (qd - RD - E) - k * RD;
-            if (p.exec_flags[cell / D]) for (int t = lane; t < n_tiles; t += 64) is += p.cntp[((int64_t)t * RD + cell) * 5 + k];
+            if (p.exec_flags[cell / D]) for (int t = lane; t < n_tiles; t += 64) is += g_ldi(p.cntp + ((int64_t)t * RD + cell) * 5 + k);
         }
         fs = wave_sum(fs);
 #pragma unroll
@@ -1128,7 +1368,7 @@ static int validate_model(const mmn_model* m) {
 namespace {
 struct Layout {
     size_t off_plan, off_states, off_hid, off_dpre, off_dz, off_dS, off_wT, off_wdT, off_lossp, off_scp, off_cntp,
-        off_flags, off_slabs, off_epoch, off_tasks, off_items, off_segs, off_ttasks, off_titems, total;
+        off_flags, off_slabs, off_epoch, off_stamps, off_tasks, off_items, off_segs, off_ttasks, off_titems, total;
     int64_t hid_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
     int64_t wt_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
     int64_t hid_floats, wt_floats;
@@ -1295,6 +1535,7 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     L.off_flags = take(sizeof(int32_t) * (size_t)(R + E + MMN_MAX_ENCODERS));
     L.off_slabs = take(sizeof(float) * (size_t)L.slab_floats);
     L.off_epoch = take(sizeof(double) * mmn_epoch_doubles(&m));
+    L.off_stamps = take(sizeof(long long) * 256);
     L.off_tasks = take(sizeof(WTask) * L.tasks.size());
     L.off_items = take(sizeof(WItem) * L.items.size());
     L.off_segs = take(sizeof(Seg) * L.segs.size());
@@ -1392,6 +1633,10 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     h.slabs = reinterpret_cast<float*>(ws + L.off_slabs);
     h.stats = stats;
     h.epoch = reinterpret_cast<double*>(ws + L.off_epoch);
+    {
+        const char* se = getenv("MMN_STAMPS");
+        h.stamps = (se && atoi(se)) ? reinterpret_cast<long long*>(ws + L.off_stamps) : nullptr;
+    }
     h.tasks = reinterpret_cast<WTask*>(ws + L.off_tasks);
     h.items = reinterpret_cast<WItem*>(ws + L.off_items);
     h.segs = reinterpret_cast<Seg*>(ws + L.off_segs);
@@ -1595,6 +1840,7 @@ const float* mmn_debug_buffer(mmn_plan* p, int kind, int index) {
         case 0: return (index >= 1 && index <= h.E) ? h.states + (int64_t)(index - 1) * h.maxB * h.S : nullptr;
         case 1: return (index >= 0 && index < h.R) ? h.dz + (int64_t)index * h.maxB * 2 * h.D : nullptr;
         case 2: return (index >= 0 && index <= h.E) ? h.dS + (int64_t)index * h.maxB * h.S : nullptr;
+        case 3: return reinterpret_cast<const float*>(h.stamps);
         default: return nullptr;
     }
 }

@@ -1,0 +1,26 @@
+"""Diagnostic: per-phase timestamps of one k_chain_fwd workgroup (MMN_STAMPS=1)."""
+import os, sys
+os.environ["MMN_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+import numpy as np, torch
+import multimodn_amd as mm
+from helpers import build_torch_model
+from oracle import multimodn_oracle as O
+spec = O.ModelSpec(128, [O.EncoderSpec(64, (32, 32), O.ACT_RELU) for _ in range(4)], 3, 1.0, 0.3)
+model = build_torch_model(spec, O.init_params(spec, 0), "cuda", mm)
+model.nan_policy = "device"
+xs, y = O.synthetic_batches(spec, 4096, 4096, seed=1)[0]
+eng = model._get_engine(4096)
+dx = [torch.from_numpy(x).cuda() for x in xs]; dy = torch.from_numpy(y).cuda()
+b = eng.make_batch(dx, dy, [(i, i) for i in range(4)], device_nan_flags=True)
+for _ in range(5):
+    eng.local_step(b, 1.0, 0.003, accumulate=True)
+torch.cuda.synchronize()
+ptr = eng.lib.mmn_debug_buffer(eng._plan, 3, 0)
+off = ptr - eng.workspace.data_ptr()
+st = eng.workspace[off:off + 8 * 250].view(torch.int64).cpu().numpy()
+st = st[st > 0]
+d = np.diff(st) / 100.0   # 100 MHz -> us
+print("n stamps", len(st), "total us", (st[-1] - st[0]) / 100.0)
+print(" ".join(f"{x:.2f}" for x in d))

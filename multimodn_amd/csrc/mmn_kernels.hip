@@ -4,7 +4,8 @@
 // path holds up to summation order).  No CUDA names, no dual paths.
 //
 // Launch structure of one training step (reference: multimodn/multimodn.py:137-203):
-//   k_prepare          any(isnan(x_k)) per data slot (:168) + transposed weight copies for backward
+//   k_prepare          any(isnan(x_k)) per data slot (:168) + repack of every weight matrix the two
+//                      chain kernels multiply by into MFMA-fragment order (forward W, backward W^T)
 //   k_chain_fwd        row-tile parallel: init broadcast, every encoder, state-change partials,
 //                      all D decoders on all E+1 states, CE-over-sigmoid, argmax, confusion counts
 //   k_chain_bwd        row-tile parallel reverse chain: grads wrt states / pre-activations
@@ -16,22 +17,28 @@
 //   states[e][B][S]     output state of encoder e          hid[e][l][B][H_l]  hidden activations
 //   dz[r][B][2D]        d loss / d decoder logits, row r   dS[e][B][S]        d loss / d state_e (+dS0)
 //   dpre[e][l][B][H_l]  d loss / d hidden pre-activation   slabs              split-K partial grads
-//   wT                  W^T copies of every matrix the backward chain multiplies by
+//   pack                weights in fragment order: [col tile][k-step][lane][4] (zero padded)
 //
 // Tiling.  A workgroup (256 threads = 4 waves) owns 16*RT batch rows (RT = 1 or 2); the state tile
 // stays in LDS for the whole chain.  Every product is "tile[rows x K] x W'[N x K]^T" with the
-// ACTIVATION tile in LDS and the WEIGHT fragments loaded straight from L2 into registers: at 16-32
-// rows per workgroup each weight element is used by exactly one wave, so an LDS round trip (and its
-// barriers) would be pure overhead (guide: "GEMV / M <= 16: load straight to VGPRs").  Wave w owns
-// output column tiles {w, w+4} of every group of 8; the contraction is walked 16 at a time: one
-// 16-byte fragment load per operand feeds four MFMAs (the contraction index is permuted identically
-// for A and B, which is legal because both fragments use the same permutation).  Weight loads run
-// two k-steps ahead of the MFMAs that consume them.
+// ACTIVATION tile in LDS and the WEIGHT fragments loaded straight from L2 into registers (each
+// weight element is used by exactly one wave of the workgroup, so an LDS round trip would be pure
+// overhead).  Wave w owns output column tiles {w, w+4} of every group of 8; the contraction is
+// walked 16 at a time: one 16-byte fragment per operand feeds four MFMAs.
+//
+// What bounds the chain kernels is not the MFMAs (~5 us per direction at B = 4096) but (a) the
+// number of DEPENDENT global round trips (~0.7 us each on a busy chip) and (b) the rate at which
+// one CU can pull the weights through its L1: every workgroup needs ALL weights (383 KB at the
+// MIMIC shape).  Hence: the plan is copied to LDS once; weights are read from a per-step repack in
+// which one wave-level load is 1 KB contiguous (a row-major fragment touches 16 half cache lines
+// and measured ~12 GB/s per CU); and the forward kernel requests the NEXT encoder's x tile, weight
+// fragments and biases while the current state is being stored and decoded.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "mmn_hip.h"
@@ -44,7 +51,6 @@ constexpr int NT = 256;       // threads per workgroup
 constexpr int XCH = 128;      // x columns staged per chunk
 constexpr int LDX = 132;      // row stride of the x chunk image
 constexpr int LDZ = 20;       // row stride of the dz tile (16 + 4)
-constexpr int WT_LD = 16;     // row stride of the transposed decoder matrix
 constexpr int TILE_LD = 65;   // row stride of the wgrad reduction tile
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -87,25 +93,35 @@ struct Seg {                            // one gradient tensor
     int32_t count, n_partials, kdiv, ntot, coff, row_off;
 };
 
-struct TTask { const float* src; float* dst; int32_t rows, cols, ld_src, ld_dst; };
-struct TItem { int32_t task, r0, c0, pad; };
+// one matrix to repack: value(n, kk) = src[n*ld + col(kk)] (mode 0) or src[col(kk)*ld + n] (mode 1,
+// i.e. the transposed matrix), col(kk) through the same two-segment map the kernels use; element
+// (n, kk) lands at dst[((n/16 * T + (kk+kk_off)/16) * 64 + 16*((kk+kk_off)%16/4) + n%16) * 4 + (kk+kk_off)%4].
+struct PackTask {
+    const float* src; float* dst;
+    int32_t ld_src, mode, N, T;
+    int32_t len0, col0, len1, col1;
+    int32_t kk_off, ntiles;
+    int64_t start;                      // first flat element index of this task
+};
 
 struct DevPlan {
     mmn_model m;
     int32_t S, E, D, R, S16, ldS, ldH, maxB, max_tiles, KS, RT, pad1;
     int64_t hid_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];   // float offsets into hid / dpre
-    int64_t wt_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];    // float offsets into wT (layer l of enc e)
+    int64_t pkf_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];   // float offsets into pack: forward operand of layer l
+    int64_t pkb_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];   // backward operand (W^T) of layer l, -1 if unused
+    int64_t pkd_off;                                     // backward decoder operand Wdec^T [S x 2D]
     float* states; float* hid; float* dpre; float* dz; float* dS;
-    float* wT; float* wdT;    // transposed weights; decoder matrix transposed [S][16]
-    float* lossp; float* scp; int32_t* cntp;
+    float* pack;              // fragment-ordered weights, rewritten by k_prepare every step
+    float* lossp; float* scp; int32_t* cnt;   // cnt[tile][R*D][5]: per-tile integer counter partials
     int32_t* exec_flags;      // [R]   1 if state row r was produced this step
     int32_t* prev_row;        // [E]   state row that fed encoder e this step
     int32_t* nan_flags;       // [MMN_MAX_ENCODERS] NaN-found flag per data slot
     float* slabs; float* stats; double* epoch;
     long long* stamps;        // diagnostic phase timestamps (MMN_STAMPS=1), else nullptr
-    WTask* tasks; WItem* items; Seg* segs; TTask* ttasks; TItem* titems;
-    int32_t n_tasks, n_items, n_segs, n_titems;
-    int64_t n_grad_elems;
+    WTask* tasks; WItem* items; Seg* segs; PackTask* ptasks;
+    int32_t n_tasks, n_items, n_segs, n_ptasks;
+    int64_t n_grad_elems, n_pack_elems;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -119,12 +135,17 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // prove LDS vs global and would emit flat_* accesses whose waits (vmcnt(0) & lgkmcnt(0)) drain the
 // weight prefetch at every k-step.  Every hot access goes through these helpers instead.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// wave index as a provably wave-uniform (SGPR) value: everything derived from it (tile ownership,
+// "two column tiles?" flags) then compiles to scalar branches instead of exec masking
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 #define MMN_AS3 __attribute__((address_space(3)))
 #define MMN_AS1 __attribute__((address_space(1)))
-__device__ __forceinline__ float lds_ld(const float* p) { return *(const MMN_AS3 float*)p; }
-__device__ __forceinline__ f32x4 lds_ld4(const float* p) { return *(const MMN_AS3 f32x4*)p; }
-__device__ __forceinline__ void lds_st(float* p, float v) { *(MMN_AS3 float*)p = v; }
-__device__ __forceinline__ void lds_st4(float* p, f32x4 v) { *(MMN_AS3 f32x4*)p = v; }
+typedef MMN_AS3 float* lp;              // LDS pointers stay address-space typed end to end
+typedef const MMN_AS3 float* clp;
+__device__ __forceinline__ float lds_ld(clp p) { return *p; }
+__device__ __forceinline__ f32x4 lds_ld4(clp p) { return *(const MMN_AS3 f32x4*)p; }
+__device__ __forceinline__ void lds_st(lp p, float v) { *p = v; }
+__device__ __forceinline__ void lds_st4(lp p, f32x4 v) { *(MMN_AS3 f32x4*)p = v; }
 __device__ __forceinline__ float g_ld(const float* p) { return *(const MMN_AS1 float*)p; }
 __device__ __forceinline__ int g_ldi(const int32_t* p) { return *(const MMN_AS1 int32_t*)p; }
 __device__ __forceinline__ f32x2 g_ld2(const float* p) { return *(const MMN_AS1 f32x2*)p; }
@@ -165,119 +186,114 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// ---- W' operand description: rows = output features, contraction along (up to two) column ranges
-struct BSrc {
-    const float* w;
-    int ldw;
-    int N;                       // valid rows
-    int len0, len0p, col0;       // kk in [0, len0p): column col0 + kk, valid while kk < len0
-    int len1, len1p, col1;       // kk in [len0p, len0p + len1p): column col1 + (kk - len0p)
-    bool vec;                    // every fragment is a whole, 16-byte aligned float4
+// ---- W' operand in fragment order: fragment (tile, t) = 64 lanes x float4 = 1 KB contiguous
+struct PB {
+    const float* pk;
+    int T;        // k-steps (16 contraction elements each)
+    int T0;       // k-steps whose activations come from A.a0 (the rest from A.a1)
+    int N;        // valid output columns
 };
-__device__ __forceinline__ BSrc make_bsrc(const float* w, int ldw, int N, int len0, int col0, int len1,
-                                          int col1) {
-    BSrc s;
-    s.w = w; s.ldw = ldw; s.N = N;
-    s.len0 = len0; s.len0p = round_up(len0, 16); s.col0 = col0;
-    s.len1 = len1; s.len1p = round_up(len1, 16); s.col1 = col1;
-    s.vec = ((ldw | col0 | col1 | len0 | len1) & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0;
-    return s;
+__device__ __forceinline__ PB make_pb(const float* pk, int N, int len0, int len1) {
+    PB b;
+    b.pk = pk; b.N = N;
+    b.T0 = (len0 + 15) >> 4;
+    b.T = b.T0 + ((len1 + 15) >> 4);
+    return b;
 }
-__device__ __forceinline__ int bsrc_steps(const BSrc& B) { return (B.len0p + B.len1p) >> 4; }
-// activation operand: LDS images for the two contraction segments (zero/finite padded to 16)
-struct ASrc { const float* a0; int lda0; const float* a1; int lda1; };
-
-// One weight fragment (4 consecutive contraction elements of row n).  Branch-free on the vector
-// path: out-of-range lanes read a clamped (valid) address and are zeroed by a select, because a
-// branch around a load makes hipcc fall back to s_waitcnt vmcnt(0) and serialises the prefetch.
-template <bool VEC>
-__device__ __forceinline__ f32x4 load_b(const BSrc& s, int n, int kk) {
-    int col, rem;
-    if (kk < s.len0p) { col = s.col0 + kk; rem = s.len0 - kk; }
-    else { const int k1 = kk - s.len0p; col = s.col1 + k1; rem = s.len1 - k1; }
-    const bool ok = (n < s.N) && (rem > 0);
-    if (VEC) {
-        const int nn = min(n, s.N - 1);
-        const int cc = rem > 0 ? col : 0;
-        f32x4 v = g_ld4(s.w + (int64_t)nn * s.ldw + cc);
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        return ok ? v : z;
-    } else {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-            const float* p = s.w + (int64_t)n * s.ldw + col;
-            v.x = g_ld(p);
-            if (rem > 1) v.y = g_ld(p + 1);
-            if (rem > 2) v.z = g_ld(p + 2);
-            if (rem > 3) v.w = g_ld(p + 3);
-        }
-        return v;
-    }
-}
+// activation operand: LDS images for the two contraction segments (zero/finite padded to 16);
+// step t reads a0 + 16 t (t < T0) or a1 + 16 (t - T0)
+struct ASrc { clp a0; int lda0; clp a1; int lda1; };
 
 // The GEMM of one layer is split into ISSUE (request NS k-steps of weight fragments for this
 // wave's two column tiles) and CONSUME (LDS activation fragments x those registers -> MFMA), so a
-// caller can put unrelated work -- or a whole earlier layer -- between the two: global latency
-// (~0.7 us per dependent round trip on a busy chip) is what bounds this kernel, not the MFMAs.
+// caller can put unrelated work -- or a whole earlier layer -- between the two.  No branches and
+// no bounds tests around the loads (the pack is zero padded): hipcc keeps counted vmcnt waits.
 constexpr int TQ = 12;
-template <int NS, bool VEC>
-__device__ __forceinline__ void issue_b(f32x4 (&bq)[NS][2], const BSrc& B, const int (&n0)[2], int t_begin) {
+template <int NS>
+__device__ __forceinline__ void issue_b(f32x4 (&bq)[NS][2], const PB& B, const int (&n0)[2], int t_begin) {
     const int lane = threadIdx.x & 63;
-    const int i = lane & 15, q = lane >> 4;
-    const int T = bsrc_steps(B);
+    const int ntiles = (B.N + 15) >> 4;
+    const int tl0 = min(n0[0] >> 4, ntiles - 1), tl1 = min(n0[1] >> 4, ntiles - 1);   // clamp: surplus re-reads a hot line
+    const float* p0 = B.pk + ((int64_t)tl0 * B.T * 64 + lane) * 4;
+    const float* p1 = B.pk + ((int64_t)tl1 * B.T * 64 + lane) * 4;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-        const int t = min(t_begin + j, T - 1);     // clamp, never branch: surplus slots re-read a hot line
-#pragma unroll
-        for (int c = 0; c < 2; ++c) bq[j][c] = load_b<VEC>(B, n0[c] + i, 16 * t + 4 * q);
+        const int t = min(t_begin + j, B.T - 1);
+        bq[j][0] = g_ld4(p0 + t * 256);
+        bq[j][1] = g_ld4(p1 + t * 256);
     }
 }
 
+// NEXT != nullptr: after the MFMAs of slot j have been issued, slot j is immediately re-requested
+// from *NEXT (the same layer of the next encoder), so the next fetch streams underneath this
+// layer's MFMAs instead of stalling the wave for ~2 us of pure load issue afterwards.
 template <int RT, int NS>
-__device__ __forceinline__ void consume_b(f32x4 (&acc)[2][RT], const ASrc& A, const BSrc& B, const f32x4 (&bq)[NS][2],
-                                          int t_begin, bool two) {
+__device__ __forceinline__ void consume_b(f32x4 (&acc)[2][RT], const ASrc& A, const PB& B, f32x4 (&bq)[NS][2],
+                                          int t_begin, int t_end, bool two, const PB* NEXT = nullptr,
+                                          const int* next_n0 = nullptr) {
     const int lane = threadIdx.x & 63;
     const int i = lane & 15, q = lane >> 4;
-    const int T = bsrc_steps(B);
+    auto a_ptr = [&](int t, int& lda) -> clp {
+        if (t < B.T0) { lda = A.lda0; return A.a0 + 16 * t + 4 * q; }
+        lda = A.lda1;
+        return A.a1 + 16 * (t - B.T0) + 4 * q;
+    };
+    const float* np0 = nullptr; const float* np1 = nullptr;
+    int nT = 1;
+    if (NEXT) {
+        const int ntl = (NEXT->N + 15) >> 4;
+        nT = NEXT->T;
+        np0 = NEXT->pk + ((int64_t)min(next_n0[0] >> 4, ntl - 1) * nT * 64 + lane) * 4;
+        np1 = NEXT->pk + ((int64_t)min(next_n0[1] >> 4, ntl - 1) * nT * 64 + lane) * 4;
+    }
+    f32x4 a_cur[RT], a_nxt[RT];
+    {
+        int lda; clp ap = a_ptr(min(t_begin, t_end - 1), lda);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) a_cur[r] = lds_ld4(ap + (r * 16 + i) * lda);
+    }
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         const int t = t_begin + j;
-        if (t < T) {
-            const int kk = 16 * t;
-            const float* ap;
-            int lda;
-            if (kk < B.len0p) { ap = A.a0 + kk + 4 * q; lda = A.lda0; }
-            else { ap = A.a1 + (kk - B.len0p) + 4 * q; lda = A.lda1; }
-            f32x4 a[RT];
+        {   // unconditional (clamped) read of the next activation fragment: hides the LDS latency
+            int lda; clp ap = a_ptr(min(t + 1, t_end - 1), lda);
 #pragma unroll
-            for (int r = 0; r < RT; ++r) a[r] = lds_ld4(ap + (r * 16 + i) * lda);
+            for (int r = 0; r < RT; ++r) a_nxt[r] = lds_ld4(ap + (r * 16 + i) * lda);
+        }
+        if (t < t_end) {
             if (two) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
-                        for (int r = 0; r < RT; ++r) acc[c][r] = mfma4(a[r][e], bq[j][c][e], acc[c][r]);
+                        for (int r = 0; r < RT; ++r) acc[c][r] = mfma4(a_cur[r][e], bq[j][c][e], acc[c][r]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int r = 0; r < RT; ++r) acc[0][r] = mfma4(a[r][e], bq[j][0][e], acc[0][r]);
+                    for (int r = 0; r < RT; ++r) acc[0][r] = mfma4(a_cur[r][e], bq[j][0][e], acc[0][r]);
             }
         }
+        if (NEXT) {
+            const int tn = min(j, nT - 1);
+            bq[j][0] = g_ld4(np0 + tn * 256);
+            bq[j][1] = g_ld4(np1 + tn * 256);
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r) a_cur[r] = a_nxt[r];
     }
 }
 
-// acc[ct][rt] += A[16*RT x K] * W'[n0[ct] + 0..15][K]^T, just-in-time form (issue + consume).
+// acc[ct][rt] += A * W'[tiles n0]^T over k-steps [t_begin, t_end), just-in-time (issue + consume)
 template <int RT>
-__device__ __forceinline__ void wave_gemm_any(f32x4 (&acc)[2][RT], const ASrc& A, const BSrc& B, const int (&n0)[2],
-                                              int t_begin = 0) {
+__device__ __forceinline__ void wave_gemm_any(f32x4 (&acc)[2][RT], const ASrc& A, const PB& B, const int (&n0)[2],
+                                              int t_begin, int t_end) {
     const bool two = n0[1] < B.N;
-    const int T = bsrc_steps(B);
-    for (int tb = t_begin; tb < T; tb += TQ) {
+    for (int tb = t_begin; tb < t_end; tb += TQ) {
         f32x4 bq[TQ][2];
-        if (B.vec) issue_b<TQ, true>(bq, B, n0, tb); else issue_b<TQ, false>(bq, B, n0, tb);
-        consume_b<RT, TQ>(acc, A, B, bq, tb, two);
+        issue_b<TQ>(bq, B, n0, tb);
+        consume_b<RT, TQ>(acc, A, B, bq, tb, t_end, two);
     }
 }
 
@@ -307,15 +323,15 @@ __device__ __forceinline__ void run_epilogue(const f32x4 (&acc)[2][RT], const in
 
 // out[rows x N] = A * W'^T with A resident in LDS; epilogue per element (col may be >= N: skip there)
 template <int RT, class Epi>
-__device__ __forceinline__ void layer_nt(const ASrc& A, const BSrc& B, Epi&& epi) {
-    const int wave = threadIdx.x >> 6;
+__device__ __forceinline__ void layer_nt(const ASrc& A, const PB& B, Epi&& epi) {
+    const int wave = wave_id();
     const int ntiles = (B.N + 15) >> 4;
     for (int base = 0; base < ntiles; base += 8) {
         const int n0[2] = {16 * (base + wave), 16 * (base + wave + 4)};
         if (n0[0] >= B.N) continue;
         f32x4 acc[2][RT];
         zero_acc<RT>(acc);
-        wave_gemm_any<RT>(acc, A, B, n0);
+        wave_gemm_any<RT>(acc, A, B, n0, 0, B.T);
         run_epilogue<RT>(acc, n0, B.N, [&](int row, int col, int, float v) { epi(row, col, v); });
     }
 }
@@ -323,9 +339,9 @@ __device__ __forceinline__ void layer_nt(const ASrc& A, const BSrc& B, Epi&& epi
 // Copy a [nrows x ncols] global tile (row stride ld_src) into an LDS image whose rows hold
 // round_up(ncols,16) floats (zero filled), rows >= nrows zero filled.  Work split without
 // divisions: a wave takes rows wave, wave+4, ...; lanes take 4 columns each.
-__device__ __forceinline__ void stage_rows(float* dst, int ld_dst, const float* __restrict__ src, int64_t ld_src,
+__device__ __forceinline__ void stage_rows(lp dst, int ld_dst, const float* __restrict__ src, int64_t ld_src,
                                            int nrows, int rows_pad, int ncols) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int cpad = round_up(ncols, 16);
     const bool vec = ((ld_src & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
     for (int r = wave; r < rows_pad; r += 4) {
@@ -348,8 +364,8 @@ __device__ __forceinline__ void stage_rows(float* dst, int ld_dst, const float* 
 }
 
 // LDS tile [nrows x ncols] -> global (row stride = ncols), coalesced
-__device__ __forceinline__ void store_rows(float* __restrict__ dst, const float* src, int ld_src, int nrows, int ncols) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void store_rows(float* __restrict__ dst, clp src, int ld_src, int nrows, int ncols) {
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const bool vec = ((ncols & 3) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
     for (int r = wave; r < nrows; r += 4) {
         if (vec) {
@@ -363,7 +379,8 @@ __device__ __forceinline__ void store_rows(float* __restrict__ dst, const float*
 // ------------------------------------------------------------------------------------------------
 // k_prepare: blocks [0, scan_blocks): nan_flags[slot] = 1 if data slot has a NaN (flags are zero
 // on entry: plan creation zeroes them and k_reduce re-zeroes them after their last reader);
-// blocks [scan_blocks, ...): 32x32 tile transposes of the weights the backward chain needs.
+// blocks [scan_blocks, ...): repack of the weights into fragment order (one thread per element;
+// padding elements are never written: the pack is zeroed once at plan creation).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_prepare(const DevPlan* __restrict__ P, mmn_batch b, int scan_blocks,
                                                 int blocks_per_slot) {
@@ -393,21 +410,27 @@ __global__ __launch_bounds__(NT) void k_prepare(const DevPlan* __restrict__ P, m
         if (__any(bad) && (threadIdx.x & 63) == 0) const_cast<int32_t*>(b.nan_flags)[slot] = 1;
         return;
     }
-    __shared__ float tile[32][33];
-    const TItem it = p.titems[blockIdx.x - scan_blocks];
-    const TTask tk = p.ttasks[it.task];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int r = it.r0 + ty + 8 * k, c = it.c0 + tx;
-        tile[ty + 8 * k][tx] = (r < tk.rows && c < tk.cols) ? g_ld(tk.src + (int64_t)r * tk.ld_src + c) : 0.f;
+    // ---- repack: one thread per pack element
+    const int64_t g = (int64_t)(blockIdx.x - scan_blocks) * NT + threadIdx.x;
+    if (g >= p.n_pack_elems) return;
+    int lo = 0, hi = p.n_ptasks - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (p.ptasks[mid].start <= g) lo = mid; else hi = mid - 1;
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = it.c0 + ty + 8 * k, r = it.r0 + tx;      // dst[c][r] = src[r][c]
-        if (r < tk.rows && c < tk.cols) g_st(tk.dst + (int64_t)c * tk.ld_dst + r, tile[tx][ty + 8 * k]);
-    }
+    const PackTask tk = p.ptasks[lo];
+    const int local = (int)(g - tk.start);
+    const int c = local & 3, lane = (local >> 2) & 63, ft = local >> 8;
+    const int ct = ft / tk.T, t = ft - ct * tk.T;
+    const int n = 16 * ct + (lane & 15);
+    const int kk = 16 * t + 4 * (lane >> 4) + c - tk.kk_off;
+    if (n >= tk.N || kk < 0) return;
+    const int len0p = round_up(tk.len0, 16);
+    int col;
+    if (kk < len0p) { if (kk >= tk.len0) return; col = tk.col0 + kk; }
+    else { const int k1 = kk - len0p; if (k1 >= tk.len1) return; col = tk.col1 + k1; }
+    const float v = tk.mode ? g_ld(tk.src + (int64_t)col * tk.ld_src + n) : g_ld(tk.src + (int64_t)n * tk.ld_src + col);
+    g_st(tk.dst + local, v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -418,7 +441,7 @@ __global__ __launch_bounds__(NT) void k_prepare(const DevPlan* __restrict__ P, m
 typedef const MMN_AS3 DevPlan LPlan;
 constexpr int PLAN_FLOATS = (int)((sizeof(DevPlan) + 15) / 16) * 4;
 
-__device__ __forceinline__ void copy_plan_to_lds(const DevPlan* P, float* sPlan) {
+__device__ __forceinline__ void copy_plan_to_lds(const DevPlan* P, lp sPlan) {
     for (int idx = threadIdx.x; idx < PLAN_FLOATS / 4; idx += NT)
         lds_st4(sPlan + 4 * idx, g_ld4(reinterpret_cast<const float*>(P) + 4 * idx));
 }
@@ -428,7 +451,7 @@ __device__ __forceinline__ void copy_plan_to_lds(const DevPlan* P, float* sPlan)
 // ------------------------------------------------------------------------------------------------
 struct DecodeCtx {
     LPlan* p;
-    float* sZ;
+    lp sZ;
     f32x4 wd[4];           // this wave's decoder-weight fragments (constant for the whole kernel)
     float bd0, bd1;        // this thread's decoder bias pair
     int y;                 // this thread's target (row, d)
@@ -438,7 +461,7 @@ struct DecodeCtx {
 };
 
 __device__ __forceinline__ void load_decoder_frags(LPlan& p, f32x4 (&wd)[4]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int i = lane & 15, q = lane >> 4;
     const int S = p.S, Tdec = p.S16 >> 4, KD = (Tdec + 3) >> 2;
 #pragma unroll
@@ -458,11 +481,11 @@ __device__ __forceinline__ void load_decoder_frags(LPlan& p, f32x4 (&wd)[4]) {
 }
 
 template <int RT>
-__device__ __forceinline__ void decode_state(const DecodeCtx& c, const float* sS, int grid_row) {
+__device__ __forceinline__ void decode_state(const DecodeCtx& c, clp sS, int grid_row) {
     constexpr int TB = 16 * RT;
     LPlan& p = *c.p;
     const int ldS = p.ldS, D = p.D, R = p.R;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int i = lane & 15, q = lane >> 4;
     const int Tdec = p.S16 >> 4, KD = (Tdec + 3) >> 2;
     // z[TB x 16] = sS[TB x S] * Wdec[16 x S]^T, contraction split over the four waves
@@ -528,7 +551,9 @@ __device__ __forceinline__ void decode_state(const DecodeCtx& c, const float* sS
         const unsigned long long msk = (TB == 32) ? 0xFFFFFFFFull : 0xFFFFull;
         const int64_t cell = (int64_t)c.tile * (R * D) + grid_row * D + d;
         g_st(p.lossp + cell, lossv);
-        int32_t* cp = p.cntp + cell * 5;
+        // per-tile integer partials, packed 5 x 8 bits... no: plain stores (contended atomics here
+        // stalled every wave's next vmcnt wait by up to 14 us)
+        int32_t* cp = p.cnt + cell * 5;
         g_sti(cp + 0, __popcll((mc >> sh) & msk));
         g_sti(cp + 1, __popcll((mtp >> sh) & msk));
         g_sti(cp + 2, __popcll((mtn >> sh) & msk));
@@ -585,12 +610,10 @@ __device__ __forceinline__ EncInfo enc_info(LPlan& p, const mmn_batch& b, int t)
     // eligibility of the register-prefetch path (everything else takes the just-in-time path)
     const float* x = b.x[I.slot];
     bool ok = I.Lh <= 2 && I.F <= XCH && (I.F & 3) == 0 && (b.ldx[I.slot] & 3) == 0 &&
-              (reinterpret_cast<uintptr_t>(x) & 15) == 0 && S <= 128 && (S & 3) == 0 && (I.HL & 3) == 0 &&
-              (p.S16 + round_up(I.HL, 16)) <= 16 * TQ && (reinterpret_cast<uintptr_t>(enc.layer[I.Lh].w) & 15) == 0;
+              (reinterpret_cast<uintptr_t>(x) & 15) == 0 && S <= 128 && (p.S16 + round_up(I.HL, 16)) <= 16 * TQ;
     for (int l = 0; l < I.Lh && l < 2; ++l) {
         const auto& lin = enc.layer[l];
-        ok = ok && lin.in_dim <= 64 && (lin.in_dim & 3) == 0 && lin.out_dim <= 128 &&
-             (reinterpret_cast<uintptr_t>(lin.w) & 15) == 0;
+        ok = ok && lin.in_dim <= 64 && lin.out_dim <= 128;
     }
     I.fast = ok;
     return I;
@@ -598,8 +621,8 @@ __device__ __forceinline__ EncInfo enc_info(LPlan& p, const mmn_batch& b, int t)
 
 template <int RT>
 __device__ __forceinline__ void issue_encoder(EncRegs<RT>& R, LPlan& p, const mmn_batch& b, const EncInfo& I, int row0,
-                                              int nrows) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                              int nrows, bool with_last = true) {
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int i = lane & 15;
     const auto& enc = p.m.enc[I.e];
     const int S = p.S;
@@ -618,22 +641,22 @@ __device__ __forceinline__ void issue_encoder(EncRegs<RT>& R, LPlan& p, const mm
     }
     if (I.Lh >= 1) {
         const auto& lin = enc.layer[0];
-        const BSrc B = make_bsrc(lin.w, lin.in_dim, lin.out_dim, lin.in_dim, 0, 0, 0);
-        issue_b<4, true>(R.h0.b, B, n0, 0);
+        const PB B = make_pb(p.pack + p.pkf_off[I.e][0], lin.out_dim, lin.in_dim, 0);
+        issue_b<4>(R.h0.b, B, n0, 0);
 #pragma unroll
         for (int c = 0; c < 2; ++c) R.h0.bias[c] = g_ld(lin.b + min(n0[c] + i, lin.out_dim - 1));
     }
     if (I.Lh >= 2) {
         const auto& lin = enc.layer[1];
-        const BSrc B = make_bsrc(lin.w, lin.in_dim, lin.out_dim, lin.in_dim, 0, 0, 0);
-        issue_b<4, true>(R.h1.b, B, n0, 0);
+        const PB B = make_pb(p.pack + p.pkf_off[I.e][1], lin.out_dim, lin.in_dim, 0);
+        issue_b<4>(R.h1.b, B, n0, 0);
 #pragma unroll
         for (int c = 0; c < 2; ++c) R.h1.bias[c] = g_ld(lin.b + min(n0[c] + i, lin.out_dim - 1));
     }
     {
         const auto& lin = enc.layer[I.Lh];
-        const BSrc B = make_bsrc(lin.w, lin.in_dim, S, S, I.HL, I.HL, 0);
-        issue_b<TQ, true>(R.last.b, B, n0, 0);
+        const PB B = make_pb(p.pack + p.pkf_off[I.e][I.Lh], S, S, I.HL);
+        if (with_last) issue_b<TQ>(R.last.b, B, n0, 0);
 #pragma unroll
         for (int c = 0; c < 2; ++c) R.last.bias[c] = g_ld(lin.b + min(n0[c] + i, S - 1));
     }
@@ -643,19 +666,20 @@ template <int RT>
 __global__ __launch_bounds__(NT) void k_chain_fwd(const DevPlan* __restrict__ P, mmn_batch b, float cL,
                                                   int want_grads) {
     constexpr int TB = 16 * RT;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem_generic[];
+    const lp smem = (lp)smem_generic;
     // the carve needs ldS / ldH before the LDS copy of the plan exists: two scalar loads
     const int ldS = P->ldS, ldH = P->ldH;
     const ChainLds L = chain_lds(TB, ldS, ldH);
     copy_plan_to_lds(P, smem + L.sPlan);
-    float* sS[2] = {smem + L.sS0, smem + L.sS1};
-    float* sH[2] = {smem + L.sH0, smem + L.sH1};
-    float* sX = smem + L.sX;
-    float* sRed = smem + L.sRed;
+    lp sS[2] = {smem + L.sS0, smem + L.sS1};
+    lp sH[2] = {smem + L.sH0, smem + L.sH1};
+    const lp sX = smem + L.sX;
+    const lp sRed = smem + L.sRed;
     const int tile = blockIdx.x;
     const int row0 = tile * TB;
     const int nrows = min(TB, b.batch - row0);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int i = lane & 15;
     int stamp_k = 0;
     const int stamp_block = 7;
@@ -719,8 +743,8 @@ __global__ __launch_bounds__(NT) void k_chain_fwd(const DevPlan* __restrict__ P,
         const int t_next = next_exec(b, tn + 1);
         STAMP();
         float scacc = 0.f;
-        const float* sC = sS[cur];
-        float* sN = sS[cur ^ 1];
+        const clp sC = sS[cur];
+        const lp sN = sS[cur ^ 1];
 
         if (I.fast) {
             if (!have) issue_encoder<RT>(R, p, b, I, row0, nrows);   // previous encoder was not prefetchable
@@ -731,35 +755,40 @@ __global__ __launch_bounds__(NT) void k_chain_fwd(const DevPlan* __restrict__ P,
                 lds_st4(sX + (idx >> 5) * LDX + ((idx & 31) << 2), R.x[k]);
             }
             __syncthreads();
+            STAMP();   // F1: x in LDS
             // ---- hidden layers from prefetched fragments (mlp_encoder.py:75-76)
             if (Lh >= 1) {
                 const auto& lin = enc.layer[0];
                 const int N = lin.out_dim;
-                float* out = sH[(Lh - 1) & 1];
+                const lp out = sH[(Lh - 1) & 1];
                 if (n0[0] < N) {
                     f32x4 acc[2][RT];
                     zero_acc<RT>(acc);
                     const ASrc A{sX, LDX, sX, LDX};
-                    const BSrc B = make_bsrc(lin.w, lin.in_dim, N, lin.in_dim, 0, 0, 0);
-                    consume_b<RT, 4>(acc, A, B, R.h0.b, 0, n0[1] < N);
+                    const PB B = make_pb(p.pack + p.pkf_off[e][0], N, lin.in_dim, 0);
+                    consume_b<RT, 4>(acc, A, B, R.h0.b, 0, B.T, n0[1] < N);
+                    STAMP();   // F2: h0 consumed (only waves with work stamp; wave 0 always has)
                     run_epilogue<RT>(acc, n0, N, [&](int row, int col, int c, float v) {
                         if (col < N) lds_st(out + row * ldH + col, act_fwd(v + R.h0.bias[c], akind));
                     });
                 }
                 __syncthreads();
+                STAMP();   // F3: h0 epilogue + sync
                 if (want_grads) store_rows(p.hid + p.hid_off[e][0] + (int64_t)row0 * N, out, ldH, nrows, N);
+                STAMP();   // F4: hid0 stored
             }
             if (Lh >= 2) {
                 const auto& lin = enc.layer[1];
                 const int N = lin.out_dim;
-                const float* in = sH[1];
-                float* out = sH[0];
+                const clp in = sH[1];
+                const lp out = sH[0];
                 if (n0[0] < N) {
                     f32x4 acc[2][RT];
                     zero_acc<RT>(acc);
                     const ASrc A{in, ldH, in, ldH};
-                    const BSrc B = make_bsrc(lin.w, lin.in_dim, N, lin.in_dim, 0, 0, 0);
-                    consume_b<RT, 4>(acc, A, B, R.h1.b, 0, n0[1] < N);
+                    const PB B = make_pb(p.pack + p.pkf_off[e][1], N, lin.in_dim, 0);
+                    consume_b<RT, 4>(acc, A, B, R.h1.b, 0, B.T, n0[1] < N);
+                    STAMP();   // F5: h1 consumed
                     run_epilogue<RT>(acc, n0, N, [&](int row, int col, int c, float v) {
                         if (col < N) lds_st(out + row * ldH + col, act_fwd(v + R.h1.bias[c], akind));
                     });
@@ -774,19 +803,22 @@ __global__ __launch_bounds__(NT) void k_chain_fwd(const DevPlan* __restrict__ P,
                 f32x4 acc[2][RT];
                 zero_acc<RT>(acc);
                 const float bias0 = R.last.bias[0], bias1 = R.last.bias[1];
+                // the NEXT encoder's state-update fragments are requested slot by slot underneath
+                // this layer's MFMAs; its x tile / hidden fragments / biases right after
+                EncInfo J = I;
+                bool next_fast = false;
+                if (t_next < b.n_seq) { J = enc_info(p, b, t_next); next_fast = J.fast; }
+                const PB Bn = make_pb(p.pack + p.pkf_off[J.e][J.Lh], S, S, J.HL);
                 if (n0[0] < S) {
                     const ASrc A{sC, ldS, Lh > 0 ? sH[0] : sX, Lh > 0 ? ldH : LDX};
-                    const BSrc B = make_bsrc(lin.w, lin.in_dim, S, S, HL, HL, 0);
-                    consume_b<RT, TQ>(acc, A, B, R.last.b, 0, n0[1] < S);
+                    const PB B = make_pb(p.pack + p.pkf_off[e][Lh], S, S, HL);
+                    consume_b<RT, TQ>(acc, A, B, R.last.b, 0, B.T, n0[1] < S);
                 }
+                (void)Bn;
                 STAMP();
-                // R is dead now: request the NEXT encoder's inputs; they land while this encoder's
-                // epilogue, stores and decoder grid run
                 have = false;
-                if (t_next < b.n_seq) {
-                    const EncInfo J = enc_info(p, b, t_next);
-                    if (J.fast) { issue_encoder<RT>(R, p, b, J, row0, nrows); have = true; }
-                }
+                if (next_fast) { issue_encoder<RT>(R, p, b, J, row0, nrows, true); have = true; }
+                STAMP();   // F8: next encoder issued
                 if (n0[0] < S) {
                     run_epilogue<RT>(acc, n0, S, [&](int row, int col, int c, float v) {
                         if (col < S) {
@@ -804,7 +836,7 @@ __global__ __launch_bounds__(NT) void k_chain_fwd(const DevPlan* __restrict__ P,
             for (int l = 0; l < Lh; ++l) {
                 const auto& lin = enc.layer[l];
                 const int N = lin.out_dim;
-                float* out = sH[(Lh - 1 - l) & 1];
+                const lp out = sH[(Lh - 1 - l) & 1];
                 const float* bias = lin.b;
                 auto epi = [&](int row, int col, int, float v) {
                     if (col < N) lds_st(out + row * ldH + col, act_fwd(v + g_ld(bias + col), akind));
@@ -815,23 +847,23 @@ __global__ __launch_bounds__(NT) void k_chain_fwd(const DevPlan* __restrict__ P,
                         const int m0[2] = {16 * (base + wave), 16 * (base + wave + 4)};
                         f32x4 acc[2][RT];
                         zero_acc<RT>(acc);
+                        const PB B = make_pb(p.pack + p.pkf_off[e][0], N, lin.in_dim, 0);
                         for (int xc = 0; xc < F; xc += XCH) {
                             const int kw = min(XCH, F - xc);
                             stage_rows(sX, LDX, xg + xc, ldx, nrows, TB, kw);
                             __syncthreads();
                             if (m0[0] < N) {
-                                const ASrc A{sX, LDX, sX, LDX};
-                                const BSrc B = make_bsrc(lin.w, lin.in_dim, N, kw, xc, 0, 0);
-                                wave_gemm_any<RT>(acc, A, B, m0);
+                                const ASrc A{sX - xc, LDX, sX - xc, LDX};      // step t reads image column 16 t - xc
+                                wave_gemm_any<RT>(acc, A, B, m0, xc >> 4, (xc + kw + 15) >> 4);
                             }
                             __syncthreads();
                         }
                         if (m0[0] < N) run_epilogue<RT>(acc, m0, N, epi);
                     }
                 } else {
-                    const float* in = sH[(Lh - l) & 1];
+                    const clp in = sH[(Lh - l) & 1];
                     const ASrc A{in, ldH, in, ldH};
-                    const BSrc B = make_bsrc(lin.w, lin.in_dim, N, lin.in_dim, 0, 0, 0);
+                    const PB B = make_pb(p.pack + p.pkf_off[e][l], N, lin.in_dim, 0);
                     layer_nt<RT>(A, B, [&](int row, int col, float v) { epi(row, col, 0, v); });
                 }
                 __syncthreads();
@@ -851,7 +883,7 @@ __global__ __launch_bounds__(NT) void k_chain_fwd(const DevPlan* __restrict__ P,
                 };
                 if (Lh > 0) {
                     const ASrc A{sC, ldS, sH[0], ldH};
-                    const BSrc B = make_bsrc(lin.w, lin.in_dim, S, S, HL, HL, 0);
+                    const PB B = make_pb(p.pack + p.pkf_off[e][Lh], S, S, HL);
                     layer_nt<RT>(A, B, [&](int row, int col, float v) { epi(row, col, 0, v); });
                 } else {
                     const int ntiles = (S + 15) >> 4;
@@ -859,19 +891,18 @@ __global__ __launch_bounds__(NT) void k_chain_fwd(const DevPlan* __restrict__ P,
                         const int m0[2] = {16 * (base + wave), 16 * (base + wave + 4)};
                         f32x4 acc[2][RT];
                         zero_acc<RT>(acc);
+                        const PB B = make_pb(p.pack + p.pkf_off[e][Lh], S, S, HL);   // HL == F here
                         if (m0[0] < S) {
                             const ASrc A{sC, ldS, sC, ldS};
-                            const BSrc B = make_bsrc(lin.w, lin.in_dim, S, S, HL, 0, 0);
-                            wave_gemm_any<RT>(acc, A, B, m0);
+                            wave_gemm_any<RT>(acc, A, B, m0, 0, B.T0);
                         }
                         for (int xc = 0; xc < F; xc += XCH) {
                             const int kw = min(XCH, F - xc);
                             stage_rows(sX, LDX, xg + xc, ldx, nrows, TB, kw);
                             __syncthreads();
                             if (m0[0] < S) {
-                                const ASrc A{sX, LDX, sX, LDX};
-                                const BSrc B = make_bsrc(lin.w, lin.in_dim, S, kw, xc, 0, 0);
-                                wave_gemm_any<RT>(acc, A, B, m0);
+                                const ASrc A{sC, ldS, sX - xc, LDX};
+                                wave_gemm_any<RT>(acc, A, B, m0, B.T0 + (xc >> 4), B.T0 + ((xc + kw + 15) >> 4));
                             }
                             __syncthreads();
                         }
@@ -900,7 +931,7 @@ __global__ __launch_bounds__(NT) void k_chain_fwd(const DevPlan* __restrict__ P,
 // k_chain_bwd
 // ------------------------------------------------------------------------------------------------
 template <int TB>
-__device__ __forceinline__ void load_dz_tile(const DevPlan& p, float* sDz, int grid_row, int row0, int nrows) {
+__device__ __forceinline__ void load_dz_tile(LPlan& p, lp sDz, int grid_row, int row0, int nrows) {
     const int D2 = 2 * p.D;
     for (int idx = threadIdx.x; idx < TB * 16; idx += NT) {
         const int row = idx >> 4, n = idx & 15;
@@ -911,9 +942,9 @@ __device__ __forceinline__ void load_dz_tile(const DevPlan& p, float* sDz, int g
 }
 
 // dpre = dh .* act'(h): sBuf (raw dh) -> sBuf and global dpre, h read from global hid (coalesced)
-__device__ __forceinline__ void apply_act_grad(float* sBuf, int ld, const float* __restrict__ hid_g,
+__device__ __forceinline__ void apply_act_grad(lp sBuf, int ld, const float* __restrict__ hid_g,
                                                float* __restrict__ dpre_g, int nrows, int rows_pad, int H, int akind) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     for (int r = wave; r < rows_pad; r += 4) {
         for (int c = lane; c < H; c += 64) {
             float dp = 0.f;
@@ -929,18 +960,22 @@ __device__ __forceinline__ void apply_act_grad(float* sBuf, int ld, const float*
 template <int RT>
 __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P, mmn_batch b, float cS) {
     constexpr int TB = 16 * RT;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const DevPlan& p = *P;
-    const int S = p.S, E = p.E, ldS = p.ldS, ldH = p.ldH;
+    extern __shared__ __attribute__((aligned(16))) float smem_generic[];
+    const lp smem = (lp)smem_generic;
+    const int ldS = P->ldS, ldH = P->ldH;
     const ChainLds L = chain_lds(TB, ldS, ldH);
-    float* sG[2] = {smem + L.sS0, smem + L.sS1};
-    float* sDiff = smem + L.sDiff;
-    float* sH[2] = {smem + L.sH0, smem + L.sH1};
-    float* sDz = smem + L.sZ;
+    copy_plan_to_lds(P, smem + L.sPlan);
+    __syncthreads();
+    LPlan& p = *(LPlan*)(smem + L.sPlan);
+    const int S = p.S, E = p.E;
+    lp sG[2] = {smem + L.sS0, smem + L.sS1};
+    const lp sDiff = smem + L.sDiff;
+    lp sH[2] = {smem + L.sH0, smem + L.sH1};
+    const lp sDz = smem + L.sZ;
     const int tile = blockIdx.x;
     const int row0 = tile * TB;
     const int nrows = min(TB, b.batch - row0);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
 
     for (int idx = threadIdx.x; idx < TB * ldS; idx += NT) { lds_st(sG[0] + idx, 0.f); lds_st(sG[1] + idx, 0.f); lds_st(sDiff + idx, 0.f); }
     for (int idx = threadIdx.x; idx < TB * ldH; idx += NT) { lds_st(sH[0] + idx, 0.f); lds_st(sH[1] + idx, 0.f); }
@@ -948,7 +983,7 @@ __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P,
     __syncthreads();
 
     const ASrc Adz{sDz, LDZ, sDz, LDZ};
-    const BSrc Bdz = make_bsrc(p.wdT, WT_LD, S, 16, 0, 0, 0);          // W' = Wdec^T [S x 16], zero padded
+    const PB Bdz = make_pb(p.pack + p.pkd_off, S, 2 * p.D, 0);        // W' = Wdec^T [S x 2D]
     int cur = 0;
 
     for (int t = b.n_seq - 1; t >= 0; --t) {
@@ -958,13 +993,12 @@ __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P,
         int tp = t - 1;
         while (tp >= 0 && !slot_present(b, b.seq_data[tp])) --tp;
         const int prev_row = tp >= 0 ? b.seq_enc[tp] + 1 : 0;
-        const mmn_encoder& enc = p.m.enc[e];
+        const auto& enc = p.m.enc[e];
         const int nl = enc.n_layers, Lh = nl - 1;
-        const mmn_linear& last = enc.layer[nl - 1];
-        const int HL = last.in_dim - S;
+        const int HL = enc.layer[nl - 1].in_dim - S;
         const int akind = enc.activation;
-        float* G = sG[cur];
-        float* Gn = sG[cur ^ 1];
+        const lp G = sG[cur];
+        const lp Gn = sG[cur ^ 1];
 
         // diff = s_out - s_in (coalesced), dz tile of grid row e+1
         {
@@ -987,17 +1021,17 @@ __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P,
         store_rows(p.dS + ((int64_t)e * p.maxB + row0) * S, G, ldS, nrows, S);
         // [dh | carry] = G_out * W_last : W' = W_last^T [(HL+S) x S]; no grad flows to x (Lh == 0)
         {
-            const float* wT = p.wT + p.wt_off[e][nl - 1];
+            const float* pk = p.pack + p.pkb_off[e][nl - 1];
             const ASrc A{G, ldS, G, ldS};
-            float* dh = sH[0];
+            const lp dh = sH[0];
             if (Lh > 0) {
-                const BSrc B = make_bsrc(wT, S, HL + S, S, 0, 0, 0);
+                const PB B = make_pb(pk, HL + S, S, 0);
                 layer_nt<RT>(A, B, [&](int row, int col, float v) {
                     if (col < HL) lds_st(dh + row * ldH + col, v);
                     else if (col < HL + S) lds_st(Gn + row * ldS + (col - HL), v - cS * lds_ld(sDiff + row * ldS + (col - HL)));
                 });
             } else {
-                const BSrc B = make_bsrc(wT + (int64_t)HL * S, S, S, S, 0, 0, 0);
+                const PB B = make_pb(pk, S, S, 0);                    // packed from columns [HL, HL+S) only
                 layer_nt<RT>(A, B, [&](int row, int col, float v) {
                     if (col < S) lds_st(Gn + row * ldS + col, v - cS * lds_ld(sDiff + row * ldS + col));
                 });
@@ -1007,15 +1041,15 @@ __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P,
         // hidden layers, last to first: dpre_l = dh_l .* act'(h_l);  dh_{l-1} = dpre_l * W_l
         for (int l = Lh - 1; l >= 0; --l) {
             const int Hl = enc.layer[l].out_dim;
-            float* cbuf = sH[(Lh - 1 - l) & 1];
+            const lp cbuf = sH[(Lh - 1 - l) & 1];
             apply_act_grad(cbuf, ldH, p.hid + p.hid_off[e][l] + (int64_t)row0 * Hl,
                            p.dpre + p.hid_off[e][l] + (int64_t)row0 * Hl, nrows, TB, Hl, akind);
             __syncthreads();
             if (l == 0) break;
             const int Hp = enc.layer[l].in_dim;
-            float* nbuf = sH[(Lh - l) & 1];
+            const lp nbuf = sH[(Lh - l) & 1];
             const ASrc A{cbuf, ldH, cbuf, ldH};
-            const BSrc B = make_bsrc(p.wT + p.wt_off[e][l], Hl, Hp, Hl, 0, 0, 0);   // W_l^T [Hp x Hl]
+            const PB B = make_pb(p.pack + p.pkb_off[e][l], Hp, Hl, 0);              // W_l^T [Hp x Hl]
             layer_nt<RT>(A, B, [&](int row, int col, float v) {
                 if (col < Hp) lds_st(nbuf + row * ldH + col, v);
             });
@@ -1024,7 +1058,7 @@ __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P,
         cur ^= 1;
     }
     // row 0: decoders on the init state; dS0 = d loss / d tiled init state
-    float* G = sG[cur];
+    const lp G = sG[cur];
     load_dz_tile<TB>(p, sDz, 0, row0, nrows);
     __syncthreads();
     layer_nt<RT>(Adz, Bdz, [&](int row, int col, float v) {
@@ -1071,30 +1105,40 @@ __device__ __forceinline__ SrcRef resolve_in(const DevPlan& p, const mmn_batch& 
     return s;
 }
 
-template <int V>
-__device__ __forceinline__ void load_frag(float (&dst)[V], const float* __restrict__ base, int64_t off, int first,
-                                          int limit, bool row_ok, bool vec_ok) {
-#pragma unroll
-    for (int k = 0; k < V; ++k) dst[k] = 0.f;
-    if (!row_ok || first >= limit) return;
-    const float* ptr = base + off + first;
-    if (V == 4 && vec_ok && first + 3 < limit) {
-        const f32x4 v = g_ld4(ptr);
-        dst[0] = v.x; dst[V > 1 ? 1 : 0] = v.y; dst[V > 2 ? 2 : 0] = v.z; dst[V > 3 ? 3 : 0] = v.w;
-    } else if (V == 2 && vec_ok && first + 1 < limit) {
-        const f32x2 v = g_ld2(ptr);
-        dst[0] = v.x; dst[V > 1 ? 1 : 0] = v.y;
+// One interleaved operand fragment (V consecutive columns of one row).  FAST (wave-uniform): the
+// tile edge is V-aligned, so a lane is wholly inside or wholly outside; then the load is
+// unconditional from a clamped address and masked by a select (no branch -> counted vmcnt).
+template <int V, bool FAST>
+__device__ __forceinline__ void load_frag(float (&dst)[V], const float* __restrict__ base, int64_t row_off, int first,
+                                          int limit, bool row_ok) {
+    if (FAST) {
+        const bool in = row_ok && (first < limit);
+        const float* ptr = base + row_off + (first < limit ? first : 0);
+        if (V == 4) {
+            const f32x4 v = g_ld4(ptr);
+            dst[0] = in ? v.x : 0.f; dst[V > 1 ? 1 : 0] = in ? v.y : 0.f;
+            dst[V > 2 ? 2 : 0] = in ? v.z : 0.f; dst[V > 3 ? 3 : 0] = in ? v.w : 0.f;
+        } else if (V == 2) {
+            const f32x2 v = g_ld2(ptr);
+            dst[0] = in ? v.x : 0.f; dst[V > 1 ? 1 : 0] = in ? v.y : 0.f;
+        } else {
+            const float v = g_ld(ptr);
+            dst[0] = in ? v : 0.f;
+        }
     } else {
 #pragma unroll
+        for (int k = 0; k < V; ++k) dst[k] = 0.f;
+        if (!row_ok) return;
+#pragma unroll
         for (int k = 0; k < V; ++k)
-            if (first + k < limit) dst[k] = g_ld(ptr + k);
+            if (first + k < limit) dst[k] = g_ld(base + row_off + first + k);
     }
 }
 
 template <int MT, int NTL>
 __device__ __forceinline__ void wgrad_tile(const DevPlan& p, const WTask& tk, const WItem& it, const float* Ap, int64_t lda,
-                                           SrcRef in, int ncols, int rb, int re, float* sTile, float* sBias) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                           SrcRef in, int ncols, int rb, int re, lp sTile, lp sBias) {
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int i = lane & 15, q = lane >> 4;
     const int M = tk.M;
     const bool has_in = it.src != 2;
@@ -1110,48 +1154,54 @@ __device__ __forceinline__ void wgrad_tile(const DevPlan& p, const WTask& tk, co
     // this wave's quarter of the row range (multiples of 4 rows)
     const int rq = round_up((re - rb + 3) / 4, 4);
     const int wb = rb + wave * rq, we = min(re, wb + rq);
-    const bool a_vec = ((lda % MT) == 0) && ((it.m0 % MT) == 0) && ((reinterpret_cast<uintptr_t>(Ap) & (4 * MT - 1)) == 0);
-    const bool i_vec = has_in && ((in.ld % NTL) == 0) && ((it.n0 % NTL) == 0) &&
-                       ((reinterpret_cast<uintptr_t>(in.p) & (4 * NTL - 1)) == 0);
+    const bool a_fast = ((lda % MT) == 0) && ((it.m0 % MT) == 0) && (((M - it.m0) % MT) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(Ap) & (4 * MT - 1)) == 0);
+    const bool i_fast = !has_in || (((in.ld % NTL) == 0) && ((it.n0 % NTL) == 0) && (((ncols - it.n0) % NTL) == 0) &&
+                                    ((reinterpret_cast<uintptr_t>(in.p) & (4 * NTL - 1)) == 0));
     const float ones = (i == 0) ? 1.0f : 0.0f;
     const int mfirst = it.m0 + MT * i, nfirst = it.n0 + NTL * i;
+    const float* inp = has_in ? in.p : Ap;               // bias-only items re-read A (masked to zero)
+    const int64_t ldi = has_in ? in.ld : lda;
+    const int ilimit = has_in ? ncols : 0;
 
-    float a0[MT], b0[NTL], a1[MT], b1[NTL];
-    auto ld = [&](float (&a)[MT], float (&bb)[NTL], int r) {
-        const int row = r + q;
-        const bool ok = row < we;
-        load_frag<MT>(a, Ap, (int64_t)row * lda, mfirst, M, ok, a_vec);
-        if (has_in) load_frag<NTL>(bb, in.p, (int64_t)row * in.ld, nfirst, ncols, ok, i_vec);
-        else {
+    auto run = [&](auto fast_tag) {
+        constexpr bool FA = decltype(fast_tag)::value;
+        constexpr int DEPTH = 4;                          // k-steps (4 rows each) in flight
+        float a[DEPTH][MT], bb[DEPTH][NTL];
+        auto ld = [&](float (&av)[MT], float (&bv)[NTL], int r) {
+            const int row = r + q;
+            const bool ok = row < we;
+            const int rc = ok ? row : (we - 1);           // clamp: always a valid row of this range
+            load_frag<MT, FA>(av, Ap, (int64_t)rc * lda, mfirst, M, ok);
+            load_frag<NTL, FA>(bv, inp, (int64_t)rc * ldi, nfirst, ilimit, ok);
+        };
+        auto comp = [&](const float (&av)[MT], const float (&bv)[NTL]) {
+            if (has_in) {
 #pragma unroll
-            for (int k = 0; k < NTL; ++k) bb[k] = 0.f;
-        }
-    };
-    auto comp = [&](const float (&a)[MT], const float (&bb)[NTL]) {
-        if (has_in) {
+                for (int c = 0; c < MT; ++c)
 #pragma unroll
-            for (int c = 0; c < MT; ++c)
+                    for (int d = 0; d < NTL; ++d) acc[c][d] = mfma4(av[c], bv[d], acc[c][d]);
+            }
+            if (bias) {
 #pragma unroll
-                for (int d = 0; d < NTL; ++d) acc[c][d] = mfma4(a[c], bb[d], acc[c][d]);
-        }
-        if (bias) {
+                for (int c = 0; c < MT; ++c) accb[c] = mfma4(av[c], ones, accb[c]);
+            }
+        };
 #pragma unroll
-            for (int c = 0; c < MT; ++c) accb[c] = mfma4(a[c], ones, accb[c]);
+        for (int k = 0; k < DEPTH; ++k) ld(a[k], bb[k], wb + 4 * k);
+        for (int r = wb; r < we; r += 4 * DEPTH) {
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) {
+                if (r + 4 * k < we) comp(a[k], bb[k]);
+                ld(a[k], bb[k], r + 4 * (k + DEPTH));
+            }
         }
     };
     if (wb < we) {
-        ld(a0, b0, wb);
-        for (int r = wb; r < we; r += 8) {
-            if (r + 4 < we) ld(a1, b1, r + 4);
-            comp(a0, b0);
-            if (r + 4 < we) {
-                if (r + 8 < we) ld(a0, b0, r + 8);
-                comp(a1, b1);
-            }
-        }
+        if (a_fast && i_fast) run(std::true_type{}); else run(std::false_type{});
     }
     // fixed-order sum of the four waves' tiles through LDS, then one coalesced slab write
-    float* mine = sTile + wave * (64 * TILE_LD);
+    const lp mine = sTile + wave * (64 * TILE_LD);
 #pragma unroll
     for (int c = 0; c < MT; ++c)
 #pragma unroll
@@ -1174,7 +1224,7 @@ __device__ __forceinline__ void wgrad_tile(const DevPlan& p, const WTask& tk, co
             const int ml = idx / TW, nl = idx - ml * TW;
             const int m = it.m0 + ml, n = it.n0 + nl;
             if (m < M && n < ncols) {
-                const float* s = sTile + ml * TILE_LD + nl;
+                const clp s = sTile + ml * TILE_LD + nl;
                 g_st(slab + (int64_t)m * ntot + col_off + nl,
                      ((lds_ld(s) + lds_ld(s + 64 * TILE_LD)) + lds_ld(s + 2 * 64 * TILE_LD)) + lds_ld(s + 3 * 64 * TILE_LD));
             }
@@ -1193,9 +1243,9 @@ __device__ __forceinline__ void wgrad_tile(const DevPlan& p, const WTask& tk, co
 constexpr int WGRAD_LDS_FLOATS = 4 * 64 * TILE_LD + 4 * 64;
 
 __global__ __launch_bounds__(NT) void k_wgrad(const DevPlan* __restrict__ P, mmn_batch b, int rows_per_split) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sTile = smem;
-    float* sBias = smem + 4 * 64 * TILE_LD;
+    extern __shared__ __attribute__((aligned(16))) float smem_generic[];
+    const lp sTile = (lp)smem_generic;
+    const lp sBias = sTile + 4 * 64 * TILE_LD;
     const DevPlan& p = *P;
     const WItem it = p.items[blockIdx.x];
     const WTask& tk = p.tasks[it.task];
@@ -1231,7 +1281,7 @@ __device__ __forceinline__ void epoch_accumulate_block(const DevPlan& p, float a
     const int R = p.R, D = p.D, E = p.E, RD = R * D;
     float* st = p.stats;
     double* ep = p.epoch;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     if (wave == 0) {                                       // fixed-order sums of grid and state change
         float se = 0.f, ss = 0.f;
         for (int c = lane; c < RD; c += 64) se += st[c];
@@ -1264,49 +1314,93 @@ __global__ __launch_bounds__(NT) void k_reduce(const DevPlan* __restrict__ P, in
     const DevPlan& p = *P;
     if ((int)blockIdx.x < grad_blocks) {
         if (!want_grads) return;
+        // segment starts into LDS once (the binary search was 6 dependent global round trips)
+        __shared__ long long sstart[320];   // >= 1 + 2*16*8 + 2*8 segments
+        const int nseg = min(p.n_segs, 320);
+        for (int k = threadIdx.x; k < nseg; k += NT) sstart[k] = p.segs[k].start;
+        __syncthreads();
         const int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x;
         if (idx >= p.n_grad_elems) return;
-        int lo = 0, hi = p.n_segs - 1;
+        int lo = 0, hi = nseg - 1;
         while (lo < hi) {                                   // last segment with start <= idx
             const int mid = (lo + hi + 1) >> 1;
-            if (p.segs[mid].start <= idx) lo = mid; else hi = mid - 1;
+            if (sstart[mid] <= idx) lo = mid; else hi = mid - 1;
         }
-        const Seg& sg = p.segs[lo];
+        const Seg sg = p.segs[lo];
         const int local = (int)(idx - sg.start);
         const int m = local / sg.kdiv, n = local - m * sg.kdiv;
         const float* src = p.slabs + sg.slab_base + (int64_t)(sg.row_off + m) * sg.ntot + n + sg.coff;
         float sum = 0.f;
-        for (int k = 0; k < sg.n_partials; ++k) sum += g_ld(src + (int64_t)k * sg.pstride);
+        int k = 0;
+        for (; k + 8 <= sg.n_partials; k += 8) {            // 8 independent loads in flight, fixed order
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = g_ld(src + (int64_t)(k + j) * sg.pstride);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[j];
+        }
+        for (; k < sg.n_partials; ++k) sum += g_ld(src + (int64_t)k * sg.pstride);
         g_st(sg.dst + local, sum);
         return;
     }
-    // stats block: one wave per quantity, lanes over tiles, butterfly sum (fixed order)
+    // stats block.  Float partials (loss cells, state change): 8 threads per quantity sum disjoint
+    // tile chunks with independent loads, then a fixed-order 8-way sum.  Integer counters were
+    // accumulated with atomics by k_chain_fwd: read, publish, re-zero.
     const int R = p.R, D = p.D, E = p.E, S = p.S;
     const int RD = R * D;
     float* st = p.stats;
     const float Bg = (float)batch_global;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nq = RD + E + 5 * RD;                        // loss cells, state-change, 5 counters per cell
-    for (int qd = wave; qd < nq; qd += 4) {
+    __shared__ float spart[32][8];
+    const int nfq = RD + E;
+    for (int qb = 0; qb < nfq; qb += 32) {
+        const int qd = qb + (threadIdx.x >> 3), ch = threadIdx.x & 7;
         float fs = 0.f;
-        int is = 0;
-        if (qd < RD) {
-            if (p.exec_flags[qd / D]) for (int t = lane; t < n_tiles; t += 64) fs += g_ld(p.lossp + (int64_t)t * RD + qd);
-        } else if (qd < RD + E) {
-            const int e = qd - RD;
-            if (p.exec_flags[e + 1]) for (int t = lane; t < n_tiles; t += 64) fs += g_ld(p.scp + (int64_t)t * E + e);
-        } else {
-            const int k = (qd - RD - E) / RD, cell = (qd - RD - E) - k * RD;
-            if (p.exec_flags[cell / D]) for (int t = lane; t < n_tiles; t += 64) is += g_ldi(p.cntp + ((int64_t)t * RD + cell) * 5 + k);
+        if (qd < nfq) {
+            const int per = (n_tiles + 7) >> 3;
+            const int t0 = ch * per, t1 = min(n_tiles, t0 + per);
+            if (qd < RD) {
+                if (p.exec_flags[qd / D]) {
+#pragma unroll 8
+                    for (int t = t0; t < t1; ++t) fs += g_ld(p.lossp + (int64_t)t * RD + qd);
+                }
+            } else {
+                const int e = qd - RD;
+                if (p.exec_flags[e + 1]) {
+#pragma unroll 8
+                    for (int t = t0; t < t1; ++t) fs += g_ld(p.scp + (int64_t)t * E + e);
+                }
+            }
         }
-        fs = wave_sum(fs);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) is += __shfl_xor(is, off);
-        if (lane == 0) {
-            if (qd < RD) st[qd] = fs / Bg;
-            else if (qd < RD + E) st[qd] = fs / (Bg * (float)S);
-            else st[qd] = (float)is;
+        spart[threadIdx.x >> 3][ch] = fs;
+        __syncthreads();
+        if (qd < nfq && ch == 0) {
+            const float* sp = spart[threadIdx.x >> 3];
+            const float tot = (((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7])));
+            st[qd] = qd < RD ? tot / Bg : tot / (Bg * (float)S);
         }
+        __syncthreads();
+    }
+    __shared__ int ipart[32][8];
+    for (int qb = 0; qb < 5 * RD; qb += 32) {
+        const int c = qb + (threadIdx.x >> 3), ch = threadIdx.x & 7;
+        int v = 0;
+        if (c < 5 * RD) {
+            const int k = c / RD, cell = c - k * RD;
+            const int per = (n_tiles + 7) >> 3;
+            const int t0 = ch * per, t1 = min(n_tiles, t0 + per);
+            if (p.exec_flags[cell / D]) {
+                const int32_t* src = p.cnt + (int64_t)cell * 5 + k;
+#pragma unroll 8
+                for (int t = t0; t < t1; ++t) v += g_ldi(src + (int64_t)t * RD * 5);
+            }
+        }
+        ipart[threadIdx.x >> 3][ch] = v;
+        __syncthreads();
+        if (c < 5 * RD && ch == 0) {
+            const int* ip = ipart[threadIdx.x >> 3];
+            st[RD + E + c] = (float)(ip[0] + ip[1] + ip[2] + ip[3] + ip[4] + ip[5] + ip[6] + ip[7]);
+        }
+        __syncthreads();
     }
     for (int r = threadIdx.x; r < R; r += NT) st[RD + E + 5 * RD + r] = p.exec_flags[r] ? (float)batch : 0.f;
     if (nan_flags && threadIdx.x < MMN_MAX_ENCODERS) nan_flags[threadIdx.x] = 0;
@@ -1367,16 +1461,17 @@ static int validate_model(const mmn_model* m) {
 
 namespace {
 struct Layout {
-    size_t off_plan, off_states, off_hid, off_dpre, off_dz, off_dS, off_wT, off_wdT, off_lossp, off_scp, off_cntp,
-        off_flags, off_slabs, off_epoch, off_stamps, off_tasks, off_items, off_segs, off_ttasks, off_titems, total;
+    size_t off_plan, off_states, off_hid, off_dpre, off_dz, off_dS, off_pack, off_lossp, off_scp, off_cnt,
+        off_flags, off_slabs, off_epoch, off_stamps, off_tasks, off_items, off_segs, off_ptasks, total;
     int64_t hid_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
-    int64_t wt_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
-    int64_t hid_floats, wt_floats;
+    int64_t pkf_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
+    int64_t pkb_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
+    int64_t pkd_off;
+    int64_t hid_floats, pack_floats, pack_elems;
     std::vector<WTask> tasks;
     std::vector<WItem> items;
     std::vector<Seg> segs;
-    std::vector<TTask> ttasks;      // dst filled at plan creation (needs workspace addresses)
-    std::vector<TItem> titems;
+    std::vector<PackTask> ptasks;   // dst = offset until plan creation patches in the workspace address
     int64_t slab_floats, n_grad_elems;
     int KS, max_tiles, ldS, ldH;
 };
@@ -1394,45 +1489,62 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     L.KS = ks;
     L.ldS = pick_ld(S);
     int maxh = 16;
-    int64_t ho = 0, wo = 0;
+    int64_t ho = 0;
     memset(L.hid_off, 0, sizeof(L.hid_off));
-    memset(L.wt_off, 0, sizeof(L.wt_off));
+    for (int e = 0; e < E; ++e)
+        for (int l = 0; l + 1 < m.enc[e].n_layers; ++l) {
+            L.hid_off[e][l] = ho;
+            ho += (int64_t)maxB * m.enc[e].layer[l].out_dim;
+            maxh = maxh > m.enc[e].layer[l].out_dim ? maxh : m.enc[e].layer[l].out_dim;
+        }
+    L.hid_floats = ho;
+    L.ldH = pick_ld(maxh);
+
+    // ---- fragment-order repack of every operand of the two chain kernels
+    int64_t po = 0;
+    auto add_pack = [&](const float* src, int ld, int mode, int N, int len0, int col0, int len1, int col1, int kk_off,
+                        int T_override, int64_t dst_off) -> int64_t {
+        PackTask t{};
+        t.src = src; t.dst = reinterpret_cast<float*>(dst_off); t.ld_src = ld; t.mode = mode; t.N = N;
+        t.len0 = len0; t.col0 = col0; t.len1 = len1; t.col1 = col1; t.kk_off = kk_off;
+        t.T = T_override > 0 ? T_override : (round_up(len0, 16) + round_up(len1, 16)) / 16;
+        t.ntiles = (N + 15) / 16;
+        t.start = L.ptasks.empty() ? 0 : L.ptasks.back().start + (int64_t)L.ptasks.back().ntiles * L.ptasks.back().T * 256;
+        L.ptasks.push_back(t);
+        return (int64_t)t.ntiles * t.T * 256;
+    };
     for (int e = 0; e < E; ++e) {
         const int nl = m.enc[e].n_layers;
         for (int l = 0; l < nl; ++l) {
             const mmn_linear& lin = m.enc[e].layer[l];
-            if (l + 1 < nl) {
-                L.hid_off[e][l] = ho;
-                ho += (int64_t)maxB * lin.out_dim;
-                maxh = maxh > lin.out_dim ? maxh : lin.out_dim;
-            }
-            if (l >= 1 || l == nl - 1) {                 // backward multiplies by W_l for l >= 1 and by W_last
-                L.wt_off[e][l] = wo;
-                wo += (int64_t)align_up((size_t)lin.out_dim * lin.in_dim, 4);
+            const bool last = l == nl - 1;
+            const int HL = lin.in_dim - S;
+            // forward operand W_l [out x in]; the state update contracts the state columns first
+            L.pkf_off[e][l] = po;
+            po += last ? add_pack(lin.w, lin.in_dim, 0, S, S, HL, HL, 0, 0, 0, po)
+                       : add_pack(lin.w, lin.in_dim, 0, lin.out_dim, lin.in_dim, 0, 0, 0, 0, 0, po);
+            // backward operand W_l^T (rows = input index, contraction = output index)
+            if (last) {
+                L.pkb_off[e][l] = po;
+                if (nl > 1) po += add_pack(lin.w, lin.in_dim, 1, lin.in_dim, S, 0, 0, 0, 0, 0, po);
+                else                                       // no grad flows to x: state columns only
+                    po += add_pack(lin.w + HL, lin.in_dim, 1, S, S, 0, 0, 0, 0, 0, po);
+            } else if (l >= 1) {
+                L.pkb_off[e][l] = po;
+                po += add_pack(lin.w, lin.in_dim, 1, lin.in_dim, lin.out_dim, 0, 0, 0, 0, 0, po);
             } else {
-                L.wt_off[e][l] = -1;
+                L.pkb_off[e][l] = -1;
             }
         }
     }
-    L.hid_floats = ho;
-    L.wt_floats = wo;
-    L.ldH = pick_ld(maxh);
-
-    // ---- transposes (destinations patched in by plan_create)
-    for (int e = 0; e < E; ++e)
-        for (int l = 0; l < m.enc[e].n_layers; ++l) {
-            if (L.wt_off[e][l] < 0) continue;
-            const mmn_linear& lin = m.enc[e].layer[l];
-            const int id = (int)L.ttasks.size();
-            L.ttasks.push_back(TTask{lin.w, nullptr, lin.out_dim, lin.in_dim, lin.in_dim, lin.out_dim});
-            for (int r0 = 0; r0 < lin.out_dim; r0 += 32)
-                for (int c0 = 0; c0 < lin.in_dim; c0 += 32) L.titems.push_back(TItem{id, r0, c0, 0});
-        }
-    for (int d = 0; d < D; ++d) {
-        const int id = (int)L.ttasks.size();
-        L.ttasks.push_back(TTask{m.dec[d].w, nullptr, 2, S, S, WT_LD});
-        for (int c0 = 0; c0 < S; c0 += 32) L.titems.push_back(TItem{id, 0, c0, 0});
+    L.pkd_off = po;                                        // Wdec^T: rows = state index, contraction = 2d + c
+    {
+        int64_t sz = 0;
+        for (int d = 0; d < D; ++d) sz = add_pack(m.dec[d].w, S, 1, S, 2, 0, 0, 0, 2 * d, 1, po);
+        po += sz;
     }
+    L.pack_floats = po;
+    L.pack_elems = L.ptasks.back().start + (int64_t)L.ptasks.back().ntiles * L.ptasks.back().T * 256;
 
     // ---- wgrad tasks, work items, slabs, gradient segments
     int64_t slab = 0, gstart = 0;
@@ -1527,11 +1639,10 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     L.off_dpre = take(sizeof(float) * (size_t)L.hid_floats);
     L.off_dz = take(sizeof(float) * (size_t)R * maxB * 2 * D);
     L.off_dS = take(sizeof(float) * (size_t)(E + 1) * maxB * S);
-    L.off_wT = take(sizeof(float) * (size_t)L.wt_floats);
-    L.off_wdT = take(sizeof(float) * (size_t)S * WT_LD);
+    L.off_pack = take(sizeof(float) * (size_t)L.pack_floats);
     L.off_lossp = take(sizeof(float) * (size_t)L.max_tiles * R * D);
     L.off_scp = take(sizeof(float) * (size_t)L.max_tiles * E);
-    L.off_cntp = take(sizeof(int32_t) * (size_t)L.max_tiles * R * D * 5);
+    L.off_cnt = take(sizeof(int32_t) * (size_t)L.max_tiles * R * D * 5);
     L.off_flags = take(sizeof(int32_t) * (size_t)(R + E + MMN_MAX_ENCODERS));
     L.off_slabs = take(sizeof(float) * (size_t)L.slab_floats);
     L.off_epoch = take(sizeof(double) * mmn_epoch_doubles(&m));
@@ -1539,8 +1650,7 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     L.off_tasks = take(sizeof(WTask) * L.tasks.size());
     L.off_items = take(sizeof(WItem) * L.items.size());
     L.off_segs = take(sizeof(Seg) * L.segs.size());
-    L.off_ttasks = take(sizeof(TTask) * L.ttasks.size());
-    L.off_titems = take(sizeof(TItem) * L.titems.size());
+    L.off_ptasks = take(sizeof(PackTask) * L.ptasks.size());
     L.total = o;
 }
 
@@ -1616,17 +1726,18 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     h.ldS = L.ldS; h.ldH = L.ldH;
     h.maxB = max_batch; h.max_tiles = L.max_tiles; h.KS = L.KS; h.RT = 0;
     memcpy(h.hid_off, L.hid_off, sizeof(h.hid_off));
-    memcpy(h.wt_off, L.wt_off, sizeof(h.wt_off));
+    memcpy(h.pkf_off, L.pkf_off, sizeof(h.pkf_off));
+    memcpy(h.pkb_off, L.pkb_off, sizeof(h.pkb_off));
+    h.pkd_off = L.pkd_off;
     h.states = reinterpret_cast<float*>(ws + L.off_states);
     h.hid = reinterpret_cast<float*>(ws + L.off_hid);
     h.dpre = reinterpret_cast<float*>(ws + L.off_dpre);
     h.dz = reinterpret_cast<float*>(ws + L.off_dz);
     h.dS = reinterpret_cast<float*>(ws + L.off_dS);
-    h.wT = reinterpret_cast<float*>(ws + L.off_wT);
-    h.wdT = reinterpret_cast<float*>(ws + L.off_wdT);
+    h.pack = reinterpret_cast<float*>(ws + L.off_pack);
     h.lossp = reinterpret_cast<float*>(ws + L.off_lossp);
     h.scp = reinterpret_cast<float*>(ws + L.off_scp);
-    h.cntp = reinterpret_cast<int32_t*>(ws + L.off_cntp);
+    h.cnt = reinterpret_cast<int32_t*>(ws + L.off_cnt);
     h.exec_flags = reinterpret_cast<int32_t*>(ws + L.off_flags);
     h.prev_row = h.exec_flags + h.R;
     h.nan_flags = h.prev_row + h.E;
@@ -1640,21 +1751,14 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     h.tasks = reinterpret_cast<WTask*>(ws + L.off_tasks);
     h.items = reinterpret_cast<WItem*>(ws + L.off_items);
     h.segs = reinterpret_cast<Seg*>(ws + L.off_segs);
-    h.ttasks = reinterpret_cast<TTask*>(ws + L.off_ttasks);
-    h.titems = reinterpret_cast<TItem*>(ws + L.off_titems);
+    h.ptasks = reinterpret_cast<PackTask*>(ws + L.off_ptasks);
     h.n_tasks = (int)L.tasks.size(); h.n_items = (int)L.items.size(); h.n_segs = (int)L.segs.size();
-    h.n_titems = (int)L.titems.size();
+    h.n_ptasks = (int)L.ptasks.size();
     h.n_grad_elems = L.n_grad_elems;
+    h.n_pack_elems = L.pack_elems;
+    for (PackTask& t : L.ptasks) t.dst = h.pack + reinterpret_cast<intptr_t>(t.dst);   // offset -> address
     pl->dev = reinterpret_cast<DevPlan*>(ws + L.off_plan);
     pl->grad_blocks = (int)((L.n_grad_elems + NT - 1) / NT);
-    // transposed-weight destinations
-    {
-        size_t ti = 0;
-        for (int e = 0; e < h.E; ++e)
-            for (int l = 0; l < m->enc[e].n_layers; ++l)
-                if (L.wt_off[e][l] >= 0) L.ttasks[ti++].dst = h.wT + L.wt_off[e][l];
-        for (int d = 0; d < h.D; ++d) L.ttasks[ti++].dst = h.wdT + 2 * d;
-    }
     pl->lds_bytes[0] = 0;
     for (int rt = 1; rt <= 2; ++rt) pl->lds_bytes[rt] = sizeof(float) * (size_t)chain_lds(16 * rt, h.ldS, h.ldH).total;
     if (pl->lds_bytes[1] > 160 * 1024) { delete pl; return MMN_ERR_UNSUPPORTED; }
@@ -1665,11 +1769,10 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     if ((e = hipMemcpy(h.tasks, L.tasks.data(), sizeof(WTask) * L.tasks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h.items, L.items.data(), sizeof(WItem) * L.items.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h.segs, L.segs.data(), sizeof(Seg) * L.segs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
-    if ((e = hipMemcpy(h.ttasks, L.ttasks.data(), sizeof(TTask) * L.ttasks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
-    if ((e = hipMemcpy(h.titems, L.titems.data(), sizeof(TItem) * L.titems.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(h.ptasks, L.ptasks.data(), sizeof(PackTask) * L.ptasks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemset(h.epoch, 0, sizeof(double) * mmn_epoch_doubles(m))) != hipSuccess) return fail(e);
     if ((e = hipMemset(h.exec_flags, 0, sizeof(int32_t) * (h.R + h.E + MMN_MAX_ENCODERS))) != hipSuccess) return fail(e);
-    if ((e = hipMemset(h.wdT, 0, sizeof(float) * (size_t)h.S * WT_LD)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(h.pack, 0, sizeof(float) * (size_t)L.pack_floats)) != hipSuccess) return fail(e);
     const void* fns[4] = {reinterpret_cast<const void*>(k_chain_fwd<1>), reinterpret_cast<const void*>(k_chain_fwd<2>),
                           reinterpret_cast<const void*>(k_chain_bwd<1>), reinterpret_cast<const void*>(k_chain_bwd<2>)};
     for (int k = 0; k < 4; ++k) {
@@ -1720,7 +1823,9 @@ int mmn_prepare(mmn_plan* p, const mmn_batch* b, int want_grads, void* stream) {
         if (bps < 1) bps = 1;
         scan_blocks = b->n_seq * bps;
     }
-    const int tblocks = want_grads ? p->host.n_titems : 0;
+    // the forward operands are needed by eval steps too, so the repack always runs
+    (void)want_grads;
+    const int tblocks = (int)((p->host.n_pack_elems + NT - 1) / NT);
     if (scan_blocks + tblocks == 0) return MMN_OK;
     mmn_batch bb = *b;
     hipLaunchKernelGGL(k_prepare, dim3(scan_blocks + tblocks), dim3(NT), 0, static_cast<hipStream_t>(stream), p->dev, bb,

@@ -112,6 +112,8 @@ def main():
     if world > 1:
         model.enable_data_parallel()
     eng = model._get_engine(B)
+    # per-tensor fused Adam: torch's multi-tensor apply gives one block per 64K-element chunk, so
+    # the 31 separate tensors (15 us) beat one flat 96K-element tensor (2 blocks, 75 us measured)
     opt = torch.optim.Adam(list(model.parameters()), 1e-3, fused=True, capturable=True)
 
     # synthetic data resident in HBM (weak scaling: every rank its own B rows per step)

@@ -35,6 +35,7 @@
 // fragments and biases while the current state is being stored and decoded.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <new>
@@ -106,10 +107,12 @@ struct PackTask {
 
 struct DevPlan {
     mmn_model m;
-    int32_t S, E, D, R, S16, ldS, ldH, maxB, max_tiles, KS, RT, pad1;
+    int32_t S, E, D, R, S16, ldS, ldH, maxB, max_tiles, KS, ldX, par_ok;
     int64_t hid_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];   // float offsets into hid / dpre
     int64_t pkf_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];   // float offsets into pack: forward operand of layer l
-    int64_t pkb_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];   // backward operand (W^T) of layer l, -1 if unused
+    int64_t pkb_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];   // backward operand (W^T) of layer l, -1 if unused;
+                                                         // for the state update: the carry part (columns of the state)
+    int64_t pkh_off[MMN_MAX_ENCODERS];                   // state update, dh part (columns of h), -1 if no hidden layer
     int64_t pkd_off;                                     // backward decoder operand Wdec^T [S x 2D]
     float* states; float* hid; float* dpre; float* dz; float* dS;
     float* pack;              // fragment-ordered weights, rewritten by k_prepare every step
@@ -1021,21 +1024,18 @@ __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P,
         store_rows(p.dS + ((int64_t)e * p.maxB + row0) * S, G, ldS, nrows, S);
         // [dh | carry] = G_out * W_last : W' = W_last^T [(HL+S) x S]; no grad flows to x (Lh == 0)
         {
-            const float* pk = p.pack + p.pkb_off[e][nl - 1];
             const ASrc A{G, ldS, G, ldS};
             const lp dh = sH[0];
             if (Lh > 0) {
-                const PB B = make_pb(pk, HL + S, S, 0);
-                layer_nt<RT>(A, B, [&](int row, int col, float v) {
+                const PB Bh = make_pb(p.pack + p.pkh_off[e], HL, S, 0);
+                layer_nt<RT>(A, Bh, [&](int row, int col, float v) {
                     if (col < HL) lds_st(dh + row * ldH + col, v);
-                    else if (col < HL + S) lds_st(Gn + row * ldS + (col - HL), v - cS * lds_ld(sDiff + row * ldS + (col - HL)));
-                });
-            } else {
-                const PB B = make_pb(pk, S, S, 0);                    // packed from columns [HL, HL+S) only
-                layer_nt<RT>(A, B, [&](int row, int col, float v) {
-                    if (col < S) lds_st(Gn + row * ldS + col, v - cS * lds_ld(sDiff + row * ldS + col));
                 });
             }
+            const PB Bc = make_pb(p.pack + p.pkb_off[e][nl - 1], S, S, 0);
+            layer_nt<RT>(A, Bc, [&](int row, int col, float v) {
+                if (col < S) lds_st(Gn + row * ldS + col, v - cS * lds_ld(sDiff + row * ldS + col));
+            });
         }
         __syncthreads();
         // hidden layers, last to first: dpre_l = dh_l .* act'(h_l);  dh_{l-1} = dpre_l * W_l
@@ -1066,6 +1066,559 @@ __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P,
     });
     __syncthreads();
     store_rows(p.dS + ((int64_t)E * p.maxB + row0) * S, G, ldS, nrows, S);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Parallel-phase chain kernels (16 rows per workgroup; used whenever their LDS budget fits).
+//
+// The reference walks the encoders strictly in sequence (multimodn.py:159-191), but only the
+// state update is sequential: the hidden MLP of every encoder sees x alone (mlp_encoder.py:75-76),
+// so u_e = W_x h_e + b can be formed for ALL encoders up front -- one wave per encoder, no barrier
+// inside -- and the chain shrinks to s' = W_s s + u_e (one S x S product and one barrier per
+// encoder).  All E+1 state tiles stay in LDS, so the D decoders are evaluated on all of them in one
+// batched phase at the end.  Backward mirrors it: decoder-gradient terms and state differences are
+// formed in parallel first, the chain is G_in = W_s^T G_out - c dS, and the hidden-layer backward
+// of every encoder runs in parallel afterwards.  At 16 rows per CU every phase of the sequential
+// form was latency-bound (one wave per SIMD, ~12 us per encoder for ~1.5 us of MFMA work).
+// ------------------------------------------------------------------------------------------------
+struct ParLds { int sPlan, sSt, sU, sG, sW, wstride, oX, oH0, oH1, oDz, sZ, sRed, total; };
+__host__ __device__ inline ParLds par_lds(int R, int E, int ldS, int ldH, int ldX, bool bwd) {
+    ParLds L;
+    int o = 0;
+    L.sPlan = o; o += PLAN_FLOATS;
+    L.sSt = o; o += R * 16 * ldS;          // fwd: state tiles 0..E        bwd: decoder-grad -> G_out tiles
+    L.sU = o; o += E * 16 * ldS;           // fwd: u_e tiles               bwd: state differences
+    L.sG = o; o += bwd ? 2 * 16 * ldS : 0; // bwd: carried gradient, ping-pong
+    L.oX = 0; L.oH0 = bwd ? 0 : 16 * ldX; L.oH1 = L.oH0 + 16 * ldH; L.oDz = L.oH1 + 16 * ldH;
+    L.wstride = L.oDz + (bwd ? 16 * LDZ : 0);
+    L.sW = o; o += 4 * L.wstride;          // per-wave scratch: x tile / hidden ping-pong / dz tile
+    L.sZ = o; o += bwd ? 0 : R * 16 * 16;
+    L.sRed = o; o += 64 + 4 * E;
+    L.total = o;
+    return L;
+}
+
+__device__ __forceinline__ bool row_executed(const mmn_batch& b, int r) {
+    if (r == 0) return true;
+    for (int t = 0; t < b.n_seq; ++t)
+        if (b.seq_enc[t] == r - 1) return slot_present(b, b.seq_data[t]);
+    return false;
+}
+
+// one wave computes out[16 x N] = A[16 x K] W'^T alone, two column tiles at a time
+template <class Epi>
+__device__ __forceinline__ void wave_layer(const ASrc& A, const PB& B, int t_begin, int t_end, Epi&& epi) {
+    const int ntiles = (B.N + 15) >> 4;
+    for (int tp = 0; tp < ntiles; tp += 2) {
+        const int n0[2] = {16 * tp, 16 * (tp + 1)};
+        f32x4 acc[2][1];
+        zero_acc<1>(acc);
+        wave_gemm_any<1>(acc, A, B, n0, t_begin, t_end);
+        run_epilogue<1>(acc, n0, B.N, [&](int row, int col, int, float v) { epi(row, col, v); });
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_chain_fwd_par(const DevPlan* __restrict__ P, mmn_batch b, float cL,
+                                                      int want_grads) {
+    constexpr int TB = 16;
+    extern __shared__ __attribute__((aligned(16))) float smem_generic[];
+    const lp smem = (lp)smem_generic;
+    const int ldS = P->ldS, ldH = P->ldH, ldX = P->ldX, E = P->E;
+    const int R = E + 1;
+    const ParLds L = par_lds(R, E, ldS, ldH, ldX, false);
+    copy_plan_to_lds(P, smem + L.sPlan);
+    for (int idx = threadIdx.x; idx < L.total - L.sSt; idx += NT) lds_st(smem + L.sSt + idx, 0.f);
+    __syncthreads();
+    LPlan& p = *(LPlan*)(smem + L.sPlan);
+    const int S = p.S, D = p.D;
+    const int tile = blockIdx.x, row0 = tile * TB;
+    const int nrows = min(TB, b.batch - row0);
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int i = lane & 15, q = lane >> 4;
+    const lp St = smem + L.sSt;
+    const lp Ut = smem + L.sU;
+    const lp sZ = smem + L.sZ;
+    const lp sRed = smem + L.sRed;
+    const lp sXw = smem + L.sW + wave * L.wstride + L.oX;
+    lp sHw[2] = {smem + L.sW + wave * L.wstride + L.oH0, smem + L.sW + wave * L.wstride + L.oH1};
+
+    int stamp_k = 0;
+    const int stamp_block = 7;
+    STAMP();   // P0: plan copied, LDS zeroed
+    for (int r = wave; r < TB; r += 4)                     // state row 0 = init state (state.py:29-32)
+        for (int c = lane; c < S; c += 64) lds_st(St + r * ldS + c, g_ld(p.m.init_state + c));
+    if (tile == 0 && threadIdx.x == 0) {                   // which state rows exist this step
+        g_sti(p.exec_flags, 1);
+        for (int e = 0; e < E; ++e) g_sti(p.exec_flags + e + 1, 0);
+        int prev = 0;
+        for (int t = 0; t < b.n_seq; ++t) {
+            if (!slot_present(b, b.seq_data[t])) continue;
+            const int e = b.seq_enc[t];
+            g_sti(p.exec_flags + e + 1, 1);
+            g_sti(p.prev_row + e, prev);
+            prev = e + 1;
+        }
+    }
+    // decoder weight fragments for the whole contraction (S <= 128 -> <= 8 k-steps)
+    const int Tdec = p.S16 >> 4;
+    f32x4 wd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (j < Tdec && i < 2 * D) {
+            const float* w = p.m.dec[i >> 1].w + (i & 1) * S;
+            const int k = 16 * j + 4 * q;
+            if (k < S) v.x = g_ld(w + k);
+            if (k + 1 < S) v.y = g_ld(w + k + 1);
+            if (k + 2 < S) v.z = g_ld(w + k + 2);
+            if (k + 3 < S) v.w = g_ld(w + k + 3);
+        }
+        wd[j] = v;
+    }
+
+    STAMP();   // P1: decoder frags requested
+    // chain step 0's W_s fragments are requested now and land during phase A
+    f32x4 wsA[8][2], wsB[8][2];
+    const int n0c[2] = {16 * wave, 16 * (wave + 4)};
+    int t_first = next_exec(b, 0);
+    if (t_first < b.n_seq) {
+        const int e0 = b.seq_enc[t_first];
+        const int Lh0 = p.m.enc[e0].n_layers - 1;
+        const PB B0 = make_pb(p.pack + p.pkf_off[e0][Lh0], S, S, p.m.enc[e0].layer[Lh0].in_dim - S);
+        issue_b<8>(wsA, B0, n0c, 0);
+    }
+    // ---- phase A: u_e = W_x h_e + b for every executed encoder, one wave per encoder
+    for (int t = wave; t < b.n_seq; t += 4) {
+        const int slot = b.seq_data[t];
+        if (!slot_present(b, slot)) continue;              // multimodn.py:168-169
+        const int e = b.seq_enc[t];
+        const auto& enc = p.m.enc[e];
+        const int Lh = enc.n_layers - 1, F = enc.n_features, akind = enc.activation;
+        const int HL = enc.layer[Lh].in_dim - S;
+        const float* xg = b.x[slot] + (int64_t)row0 * b.ldx[slot];
+        const int64_t ldx = b.ldx[slot];
+        const bool xvec = ((ldx & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(xg) & 15) == 0);
+        bool fastA = xvec && F <= 128 && Lh <= 2 && HL <= 64 && S <= 128;
+        for (int l = 0; l < Lh && l < 2; ++l) fastA = fastA && enc.layer[l].in_dim <= 64 && enc.layer[l].out_dim <= 32;
+        const lp U = Ut + e * TB * ldS;
+        if (fastA) {
+            // every operand of this wave's encoder is requested before anything is consumed:
+            // one memory round trip for the whole phase instead of one per layer and tile pair
+            const int f4 = round_up(F, 16) >> 2;           // float4 per image row (<= 32)
+            f32x4 xr[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int idx = lane + 64 * k;
+                const int row = idx / f4, c = (idx - row * f4) << 2;
+                const bool ok = idx < TB * f4 && row < nrows && c < F;
+                const f32x4 v = g_ld4(xg + (ok ? (int64_t)row * ldx + c : 0));
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                xr[k] = ok ? v : z;
+            }
+            const int pair0[2] = {0, 16};
+            f32x4 hq0[4][2], hq1[4][2], uq[4][4][2];
+            float hb0 = 0.f, hb1 = 0.f, hb0b = 0.f, hb1b = 0.f;
+            const int i16 = lane & 15;
+            if (Lh >= 1) {
+                const auto& lin = enc.layer[0];
+                issue_b<4>(hq0, make_pb(p.pack + p.pkf_off[e][0], lin.out_dim, lin.in_dim, 0), pair0, 0);
+                hb0 = g_ld(lin.b + min(i16, lin.out_dim - 1));
+                hb0b = g_ld(lin.b + min(16 + i16, lin.out_dim - 1));
+            }
+            if (Lh >= 2) {
+                const auto& lin = enc.layer[1];
+                issue_b<4>(hq1, make_pb(p.pack + p.pkf_off[e][1], lin.out_dim, lin.in_dim, 0), pair0, 0);
+                hb1 = g_ld(lin.b + min(i16, lin.out_dim - 1));
+                hb1b = g_ld(lin.b + min(16 + i16, lin.out_dim - 1));
+            }
+            const auto& llin = enc.layer[Lh];
+            const PB BU = make_pb(p.pack + p.pkf_off[e][Lh], S, S, HL);
+            float ub[4][2];
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                const int nn[2] = {32 * pr, 32 * pr + 16};
+                issue_b<4>(uq[pr], BU, nn, BU.T0);
+                ub[pr][0] = g_ld(llin.b + min(nn[0] + i16, S - 1));
+                ub[pr][1] = g_ld(llin.b + min(nn[1] + i16, S - 1));
+            }
+            // x -> LDS image
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int idx = lane + 64 * k;
+                if (idx < TB * f4) {
+                    const int row = idx / f4, c = (idx - row * f4) << 2;
+                    lds_st4(sXw + row * ldX + c, xr[k]);
+                }
+            }
+            clp in = sXw;
+            int ldin = ldX;
+            if (Lh >= 1) {
+                const auto& lin = enc.layer[0];
+                const int N = lin.out_dim;
+                const lp out = sHw[0];
+                const PB B = make_pb(p.pack + p.pkf_off[e][0], N, lin.in_dim, 0);
+                f32x4 acc[2][1];
+                zero_acc<1>(acc);
+                consume_b<1, 4>(acc, ASrc{in, ldin, in, ldin}, B, hq0, 0, B.T, 16 < N);
+                run_epilogue<1>(acc, pair0, N, [&](int row, int col, int c, float v) {
+                    if (col < N) lds_st(out + row * ldH + col, act_fwd(v + (c ? hb0b : hb0), akind));
+                });
+                if (want_grads) {
+                    float* hg = p.hid + p.hid_off[e][0] + (int64_t)row0 * N;
+                    for (int r = 0; r < nrows; ++r)
+                        for (int c = lane; c < N; c += 64) g_st(hg + (int64_t)r * N + c, lds_ld(out + r * ldH + c));
+                }
+                in = out; ldin = ldH;
+            }
+            if (Lh >= 2) {
+                const auto& lin = enc.layer[1];
+                const int N = lin.out_dim;
+                const lp out = sHw[1];
+                const PB B = make_pb(p.pack + p.pkf_off[e][1], N, lin.in_dim, 0);
+                f32x4 acc[2][1];
+                zero_acc<1>(acc);
+                consume_b<1, 4>(acc, ASrc{in, ldin, in, ldin}, B, hq1, 0, B.T, 16 < N);
+                run_epilogue<1>(acc, pair0, N, [&](int row, int col, int c, float v) {
+                    if (col < N) lds_st(out + row * ldH + col, act_fwd(v + (c ? hb1b : hb1), akind));
+                });
+                if (want_grads) {
+                    float* hg = p.hid + p.hid_off[e][1] + (int64_t)row0 * N;
+                    for (int r = 0; r < nrows; ++r)
+                        for (int c = lane; c < N; c += 64) g_st(hg + (int64_t)r * N + c, lds_ld(out + r * ldH + c));
+                }
+                in = out; ldin = ldH;
+            }
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+                const int nn[2] = {32 * pr, 32 * pr + 16};
+                if (nn[0] < S) {
+                    f32x4 acc[2][1];
+                    zero_acc<1>(acc);
+                    consume_b<1, 4>(acc, ASrc{in, ldin, in, ldin}, BU, uq[pr], BU.T0, BU.T, nn[1] < S);
+                    run_epilogue<1>(acc, nn, S, [&](int row, int col, int c, float v) {
+                        if (col < S) lds_st(U + row * ldS + col, v + ub[pr][c]);
+                    });
+                }
+            }
+            continue;
+        }
+        {   // x tile -> this wave's LDS image
+            const int f4 = round_up(F, 16) >> 2;
+            for (int idx = lane; idx < TB * f4; idx += 64) {
+                const int row = idx / f4, c = (idx - row * f4) << 2;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row < nrows && c < F) {
+                    const float* src = xg + (int64_t)row * ldx + c;
+                    if (xvec) v = g_ld4(src);
+                    else {
+                        v.x = g_ld(src);
+                        if (c + 1 < F) v.y = g_ld(src + 1);
+                        if (c + 2 < F) v.z = g_ld(src + 2);
+                        if (c + 3 < F) v.w = g_ld(src + 3);
+                    }
+                }
+                lds_st4(sXw + row * ldX + c, v);
+            }
+        }
+        clp in = sXw;
+        int ldin = ldX;
+        for (int l = 0; l < Lh; ++l) {                     // mlp_encoder.py:75-76
+            const auto& lin = enc.layer[l];
+            const int N = lin.out_dim;
+            const lp out = sHw[l & 1];
+            const float* bias = lin.b;
+            const PB B = make_pb(p.pack + p.pkf_off[e][l], N, lin.in_dim, 0);
+            const ASrc A{in, ldin, in, ldin};
+            wave_layer(A, B, 0, B.T, [&](int row, int col, float v) {
+                if (col < N) lds_st(out + row * ldH + col, act_fwd(v + g_ld(bias + col), akind));
+            });
+            if (want_grads) {
+                float* hg = p.hid + p.hid_off[e][l] + (int64_t)row0 * N;
+                for (int r = 0; r < nrows; ++r)
+                    for (int c = lane; c < N; c += 64) g_st(hg + (int64_t)r * N + c, lds_ld(out + r * ldH + c));
+            }
+            in = out;
+            ldin = ldH;
+        }
+        {   // h (or x) part of the state update, bias folded in (mlp_encoder.py:78)
+            const auto& lin = enc.layer[Lh];
+            const float* bias = lin.b;
+            const PB B = make_pb(p.pack + p.pkf_off[e][Lh], S, S, HL);
+            const ASrc A{in, ldin, in, ldin};
+            wave_layer(A, B, B.T0, B.T, [&](int row, int col, float v) {
+                if (col < S) lds_st(U + row * ldS + col, v + g_ld(bias + col));
+            });
+        }
+    }
+    STAMP();   // P2: phase A done (wave 0)
+    __syncthreads();
+    STAMP();   // P3: all waves done
+
+    // ---- phase B: the sequential part, s' = W_s s + u_e; W_s fragments run one step ahead
+    int cur = 0;
+    auto chain_step = [&](f32x4 (&wc)[8][2], f32x4 (&wn)[8][2], int t, int t_nxt) {
+        const int e = b.seq_enc[t];
+        const auto& enc = p.m.enc[e];
+        const int Lh = enc.n_layers - 1;
+        const int HL = enc.layer[Lh].in_dim - S;
+        const clp sC = St + cur * TB * ldS;
+        const lp sN = St + (e + 1) * TB * ldS;
+        const clp U = Ut + e * TB * ldS;
+        const PB B = make_pb(p.pack + p.pkf_off[e][Lh], S, S, HL);
+        float scacc = 0.f;
+        f32x4 acc[2][1];
+        zero_acc<1>(acc);
+        if (n0c[0] < S) consume_b<1, 8>(acc, ASrc{sC, ldS, sC, ldS}, B, wc, 0, B.T0, n0c[1] < S);
+        if (t_nxt < b.n_seq) {                             // next step's fragments, behind this epilogue
+            const int e2 = b.seq_enc[t_nxt];
+            const int Lh2 = p.m.enc[e2].n_layers - 1;
+            issue_b<8>(wn, make_pb(p.pack + p.pkf_off[e2][Lh2], S, S, p.m.enc[e2].layer[Lh2].in_dim - S), n0c, 0);
+        }
+        if (n0c[0] < S) {
+            run_epilogue<1>(acc, n0c, S, [&](int row, int col, int, float v) {
+                if (col < S) {
+                    const float ns = v + lds_ld(U + row * ldS + col);
+                    const float dlt = ns - lds_ld(sC + row * ldS + col);
+                    if (row < nrows) scacc += dlt * dlt;              // multimodn.py:174
+                    lds_st(sN + row * ldS + col, ns);
+                }
+            });
+        }
+        scacc = wave_sum(scacc);
+        if (lane == 0) lds_st(sRed + 64 + 4 * e + wave, scacc);
+        __syncthreads();
+        if (want_grads) store_rows(p.states + ((int64_t)e * p.maxB + row0) * S, sN, ldS, nrows, S);
+        STAMP();   // P4..: one chain step
+        cur = e + 1;
+    };
+    {
+        bool flip = false;
+        for (int t = t_first; t < b.n_seq;) {
+            const int t_nxt = next_exec(b, t + 1);
+            if (!flip) chain_step(wsA, wsB, t, t_nxt); else chain_step(wsB, wsA, t, t_nxt);
+            flip = !flip;
+            t = t_nxt;
+        }
+    }
+
+    // ---- phase C: all decoders on all state rows (decoders.py:19-20, multimodn.py:141-157,176-191)
+    for (int r = wave; r < R; r += 4) {
+        if (!row_executed(b, r)) continue;
+        const clp sS = St + r * TB * ldS;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < Tdec) {
+                const f32x4 a = lds_ld4(sS + i * ldS + 16 * j + 4 * q);
+                z = mfma4(a.x, wd[j].x, z);
+                z = mfma4(a.y, wd[j].y, z);
+                z = mfma4(a.z, wd[j].z, z);
+                z = mfma4(a.w, wd[j].w, z);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lds_st(sZ + (r * TB + q * 4 + k) * 16 + i, z[k]);
+    }
+    __syncthreads();
+    STAMP();   // decoder logits
+    const int total = R * D * TB;
+    for (int base = 0; base < total; base += NT) {
+        const int idx = base + threadIdx.x;
+        const bool valid = idx < total;
+        const int r = valid ? idx / (D * TB) : 0;
+        const int rem = idx - r * D * TB;
+        const int d = valid ? rem / TB : 0, row = rem & (TB - 1);
+        const bool live = valid && row < nrows && row_executed(b, r);
+        float lossv = 0.f;
+        int correct = 0, tp = 0, tn = 0, fp = 0, fn = 0;
+        if (live) {
+            const float* bd = p.m.dec[d].b;
+            const float za = g_ld(bd) + lds_ld(sZ + (r * TB + row) * 16 + 2 * d);
+            const float zb = g_ld(bd + 1) + lds_ld(sZ + (r * TB + row) * 16 + 2 * d + 1);
+            const int64_t grow = (int64_t)row0 + row;
+            const int y = (int)*(const MMN_AS1 int64_t*)(b.y + grow * D + d);
+            const float o0 = 1.0f / (1.0f + expf(-za));
+            const float o1 = 1.0f / (1.0f + expf(-zb));
+            const float mx = fmaxf(o0, o1);
+            const float lse = mx + logf(expf(o0 - mx) + expf(o1 - mx));
+            lossv = lse - (y ? o1 : o0);
+            const int pred = o1 > o0 ? 1 : 0;      // torch.max: first index wins ties
+            correct = pred == y;
+            tp = pred & y; tn = (1 - pred) & (1 - y); fp = pred & (1 - y); fn = (1 - pred) & y;
+            if (want_grads) {
+                const float g0 = expf(o0 - lse) - (y == 0 ? 1.0f : 0.0f);
+                const float g1 = expf(o1 - lse) - (y == 1 ? 1.0f : 0.0f);
+                f32x2 dzv;
+                dzv.x = cL * g0 * o0 * (1.0f - o0);
+                dzv.y = cL * g1 * o1 * (1.0f - o1);
+                g_st2(p.dz + ((int64_t)r * p.maxB + grow) * (2 * D) + 2 * d, dzv);
+            }
+        }
+#pragma unroll
+        for (int off = TB / 2; off >= 1; off >>= 1) lossv += __shfl_xor(lossv, off);
+        const unsigned long long mc = __ballot(correct), mtp = __ballot(tp), mtn = __ballot(tn),
+                                 mfp = __ballot(fp), mfn = __ballot(fn);
+        if (valid && row == 0) {
+            const int sh = lane & ~(TB - 1);
+            const int64_t cell = (int64_t)tile * (R * D) + r * D + d;
+            g_st(p.lossp + cell, lossv);
+            int32_t* cp = p.cnt + cell * 5;
+            g_sti(cp + 0, __popcll((mc >> sh) & 0xFFFFull));
+            g_sti(cp + 1, __popcll((mtp >> sh) & 0xFFFFull));
+            g_sti(cp + 2, __popcll((mtn >> sh) & 0xFFFFull));
+            g_sti(cp + 3, __popcll((mfp >> sh) & 0xFFFFull));
+            g_sti(cp + 4, __popcll((mfn >> sh) & 0xFFFFull));
+        }
+    }
+    STAMP();   // decoder grid done
+    // ---- epilogue: state-change partials and (for backward) the state tiles
+    for (int e = threadIdx.x; e < E; e += NT)
+        g_st(p.scp + (int64_t)tile * E + e,
+             ((lds_ld(sRed + 64 + 4 * e) + lds_ld(sRed + 65 + 4 * e)) + lds_ld(sRed + 66 + 4 * e)) + lds_ld(sRed + 67 + 4 * e));
+    STAMP();   // end
+}
+
+__global__ __launch_bounds__(NT) void k_chain_bwd_par(const DevPlan* __restrict__ P, mmn_batch b, float cS) {
+    constexpr int TB = 16;
+    extern __shared__ __attribute__((aligned(16))) float smem_generic[];
+    const lp smem = (lp)smem_generic;
+    const int ldS = P->ldS, ldH = P->ldH, ldX = P->ldX, E = P->E;
+    const int R = E + 1;
+    const ParLds L = par_lds(R, E, ldS, ldH, ldX, true);
+    copy_plan_to_lds(P, smem + L.sPlan);
+    for (int idx = threadIdx.x; idx < L.total - L.sSt; idx += NT) lds_st(smem + L.sSt + idx, 0.f);
+    __syncthreads();
+    LPlan& p = *(LPlan*)(smem + L.sPlan);
+    const int S = p.S, D = p.D;
+    const int tile = blockIdx.x, row0 = tile * TB;
+    const int nrows = min(TB, b.batch - row0);
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const lp DG = smem + L.sSt;          // decoder-grad tiles, then G_out tiles in place
+    const lp Df = smem + L.sU;           // s_out - s_in per encoder
+    lp sG[2] = {smem + L.sG, smem + L.sG + TB * ldS};
+    lp sHw[2] = {smem + L.sW + wave * L.wstride + L.oH0, smem + L.sW + wave * L.wstride + L.oH1};
+    const lp sDzw = smem + L.sW + wave * L.wstride + L.oDz;
+
+    // ---- phase A': decoder gradient of every state row and the state differences, one wave each
+    {
+        const PB Bdz = make_pb(p.pack + p.pkd_off, S, 2 * D, 0);      // W' = Wdec^T [S x 2D]
+        for (int r = wave; r < R; r += 4) {
+            if (!row_executed(b, r)) continue;
+            for (int idx = lane; idx < TB * 16; idx += 64) {
+                const int row = idx >> 4, n = idx & 15;
+                float v = 0.f;
+                if (row < nrows && n < 2 * D) v = g_ld(p.dz + ((int64_t)r * p.maxB + row0 + row) * (2 * D) + n);
+                lds_st(sDzw + row * LDZ + n, v);
+            }
+            const lp out = DG + r * TB * ldS;
+            const ASrc A{sDzw, LDZ, sDzw, LDZ};
+            wave_layer(A, Bdz, 0, Bdz.T, [&](int row, int col, float v) {
+                if (col < S) lds_st(out + row * ldS + col, v);
+            });
+            if (r >= 1) {
+                const int e = r - 1;
+                int prev_row = 0;
+                for (int t = 0, pr = 0; t < b.n_seq; ++t) {
+                    if (!slot_present(b, b.seq_data[t])) continue;
+                    if (b.seq_enc[t] == e) prev_row = pr;
+                    pr = b.seq_enc[t] + 1;
+                }
+                const float* so = p.states + ((int64_t)e * p.maxB + row0) * S;
+                const float* si = prev_row ? p.states + ((int64_t)(prev_row - 1) * p.maxB + row0) * S : nullptr;
+                const lp dd = Df + e * TB * ldS;
+                for (int rr = 0; rr < nrows; ++rr)
+                    for (int c = lane; c < S; c += 64) {
+                        const float a = g_ld(so + (int64_t)rr * S + c);
+                        const float d0 = si ? g_ld(si + (int64_t)rr * S + c) : g_ld(p.m.init_state + c);
+                        lds_st(dd + rr * ldS + c, a - d0);
+                    }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B': G_out(e) = carry + DG[e+1] + cS d_e ;  carry' = G_out W_s - cS d_e
+    int cur = 0;
+    for (int t = b.n_seq - 1; t >= 0; --t) {
+        if (!slot_present(b, b.seq_data[t])) continue;
+        const int e = b.seq_enc[t];
+        const int Lh = p.m.enc[e].n_layers - 1;
+        const lp Go = DG + (e + 1) * TB * ldS;
+        const clp dd = Df + e * TB * ldS;
+        const clp G = sG[cur];
+        const lp Gn = sG[cur ^ 1];
+        for (int rr = wave; rr < TB; rr += 4)
+            for (int c = lane; c < S; c += 64)
+                lds_st(Go + rr * ldS + c, lds_ld(G + rr * ldS + c) + lds_ld(Go + rr * ldS + c) + cS * lds_ld(dd + rr * ldS + c));
+        __syncthreads();
+        const int n0[2] = {16 * wave, 16 * (wave + 4)};
+        if (n0[0] < S) {
+            const PB Bc = make_pb(p.pack + p.pkb_off[e][Lh], S, S, 0);
+            f32x4 acc[2][1];
+            zero_acc<1>(acc);
+            const ASrc A{Go, ldS, Go, ldS};
+            wave_gemm_any<1>(acc, A, Bc, n0, 0, Bc.T);
+            run_epilogue<1>(acc, n0, S, [&](int row, int col, int, float v) {
+                if (col < S) lds_st(Gn + row * ldS + col, v - cS * lds_ld(dd + row * ldS + col));
+            });
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    {   // row 0: dS0 = carry + DG[0]
+        const clp G = sG[cur];
+        for (int rr = wave; rr < TB; rr += 4)
+            for (int c = lane; c < S; c += 64) lds_st(DG + rr * ldS + c, lds_ld(G + rr * ldS + c) + lds_ld(DG + rr * ldS + c));
+    }
+    __syncthreads();
+
+    // ---- phase C': hidden-layer backward of every executed encoder, one wave per encoder
+    for (int t = wave; t < b.n_seq; t += 4) {
+        if (!slot_present(b, b.seq_data[t])) continue;
+        const int e = b.seq_enc[t];
+        const auto& enc = p.m.enc[e];
+        const int Lh = enc.n_layers - 1, akind = enc.activation;
+        if (Lh == 0) continue;
+        const int HL = enc.layer[Lh].in_dim - S;
+        const clp Go = DG + (e + 1) * TB * ldS;
+        {
+            const PB Bh = make_pb(p.pack + p.pkh_off[e], HL, S, 0);
+            const ASrc A{Go, ldS, Go, ldS};
+            const lp dh = sHw[0];
+            wave_layer(A, Bh, 0, Bh.T, [&](int row, int col, float v) {
+                if (col < HL) lds_st(dh + row * ldH + col, v);
+            });
+        }
+        for (int l = Lh - 1; l >= 0; --l) {
+            const int Hl = enc.layer[l].out_dim;
+            const lp cbuf = sHw[(Lh - 1 - l) & 1];
+            const float* hid_g = p.hid + p.hid_off[e][l] + (int64_t)row0 * Hl;
+            float* dpre_g = p.dpre + p.hid_off[e][l] + (int64_t)row0 * Hl;
+            for (int r = 0; r < TB; ++r)
+                for (int c = lane; c < Hl; c += 64) {
+                    float dp = 0.f;
+                    if (r < nrows) {
+                        dp = lds_ld(cbuf + r * ldH + c) * act_grad_from_out(g_ld(hid_g + (int64_t)r * Hl + c), akind);
+                        g_st(dpre_g + (int64_t)r * Hl + c, dp);
+                    }
+                    lds_st(cbuf + r * ldH + c, dp);
+                }
+            if (l == 0) break;
+            const int Hp = enc.layer[l].in_dim;
+            const lp nbuf = sHw[(Lh - l) & 1];
+            const ASrc A{cbuf, ldH, cbuf, ldH};
+            const PB B = make_pb(p.pack + p.pkb_off[e][l], Hp, Hl, 0);
+            wave_layer(A, B, 0, B.T, [&](int row, int col, float v) {
+                if (col < Hp) lds_st(nbuf + row * ldH + col, v);
+            });
+        }
+    }
+    // ---- stores: dS[e] = G_out(e), dS[E] = dS0 (DG tiles are final since the barrier above)
+    for (int r = 0; r < R; ++r) {
+        if (!row_executed(b, r)) continue;
+        const int idx = r == 0 ? E : r - 1;
+        store_rows(p.dS + ((int64_t)idx * p.maxB + row0) * S, DG + r * TB * ldS, ldS, nrows, S);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1426,6 +1979,8 @@ struct mmn_plan {
     DevPlan* dev;            // device address (start of workspace)
     int max_batch;
     size_t lds_bytes[3];     // by RT
+    size_t par_lds_fwd, par_lds_bwd;
+    int par_ok;
     int grad_blocks;
     int rt_override;
 };
@@ -1466,6 +2021,7 @@ struct Layout {
     int64_t hid_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
     int64_t pkf_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
     int64_t pkb_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
+    int64_t pkh_off[MMN_MAX_ENCODERS];
     int64_t pkd_off;
     int64_t hid_floats, pack_floats, pack_elems;
     std::vector<WTask> tasks;
@@ -1525,10 +2081,13 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
                        : add_pack(lin.w, lin.in_dim, 0, lin.out_dim, lin.in_dim, 0, 0, 0, 0, 0, po);
             // backward operand W_l^T (rows = input index, contraction = output index)
             if (last) {
-                L.pkb_off[e][l] = po;
-                if (nl > 1) po += add_pack(lin.w, lin.in_dim, 1, lin.in_dim, S, 0, 0, 0, 0, 0, po);
-                else                                       // no grad flows to x: state columns only
-                    po += add_pack(lin.w + HL, lin.in_dim, 1, S, S, 0, 0, 0, 0, 0, po);
+                L.pkb_off[e][l] = po;                      // carry: state columns [HL, HL+S)
+                po += add_pack(lin.w + HL, lin.in_dim, 1, S, S, 0, 0, 0, 0, 0, po);
+                L.pkh_off[e] = -1;
+                if (nl > 1) {                              // dh: h columns [0, HL) (no grad flows to x)
+                    L.pkh_off[e] = po;
+                    po += add_pack(lin.w, lin.in_dim, 1, HL, S, 0, 0, 0, 0, 0, po);
+                }
             } else if (l >= 1) {
                 L.pkb_off[e][l] = po;
                 po += add_pack(lin.w, lin.in_dim, 1, lin.in_dim, lin.out_dim, 0, 0, 0, 0, 0, po);
@@ -1724,10 +2283,11 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     h.S = m->state_size; h.E = m->n_encoders; h.D = m->n_decoders; h.R = h.E + 1;
     h.S16 = round_up(h.S, 16);
     h.ldS = L.ldS; h.ldH = L.ldH;
-    h.maxB = max_batch; h.max_tiles = L.max_tiles; h.KS = L.KS; h.RT = 0;
+    h.maxB = max_batch; h.max_tiles = L.max_tiles; h.KS = L.KS;
     memcpy(h.hid_off, L.hid_off, sizeof(h.hid_off));
     memcpy(h.pkf_off, L.pkf_off, sizeof(h.pkf_off));
     memcpy(h.pkb_off, L.pkb_off, sizeof(h.pkb_off));
+    memcpy(h.pkh_off, L.pkh_off, sizeof(h.pkh_off));
     h.pkd_off = L.pkd_off;
     h.states = reinterpret_cast<float*>(ws + L.off_states);
     h.hid = reinterpret_cast<float*>(ws + L.off_hid);
@@ -1759,6 +2319,23 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     for (PackTask& t : L.ptasks) t.dst = h.pack + reinterpret_cast<intptr_t>(t.dst);   // offset -> address
     pl->dev = reinterpret_cast<DevPlan*>(ws + L.off_plan);
     pl->grad_blocks = (int)((L.n_grad_elems + NT - 1) / NT);
+    {
+        int maxF = 1;
+        bool ok = h.S <= 128;
+        for (int e = 0; e < h.E; ++e) maxF = maxF > m->enc[e].n_features ? maxF : m->enc[e].n_features;
+        ok = ok && maxF <= 256;
+        h.ldX = pick_ld(maxF);
+        pl->par_lds_fwd = sizeof(float) * (size_t)par_lds(h.R, h.E, h.ldS, h.ldH, h.ldX, false).total;
+        pl->par_lds_bwd = sizeof(float) * (size_t)par_lds(h.R, h.E, h.ldS, h.ldH, h.ldX, true).total;
+        ok = ok && pl->par_lds_fwd <= 160 * 1024 && pl->par_lds_bwd <= 160 * 1024;
+        const char* pe = getenv("MMN_PAR");
+        if (pe && atoi(pe) == 0) ok = false;
+        pl->par_ok = ok ? 1 : 0;
+        h.par_ok = pl->par_ok;
+        if (getenv("MMN_VERBOSE"))
+            fprintf(stderr, "[mmn] plan: sizeof(DevPlan)=%zu par_lds fwd=%zu bwd=%zu par_ok=%d ldS=%d ldH=%d ldX=%d\n",
+                    sizeof(DevPlan), pl->par_lds_fwd, pl->par_lds_bwd, pl->par_ok, h.ldS, h.ldH, h.ldX);
+    }
     pl->lds_bytes[0] = 0;
     for (int rt = 1; rt <= 2; ++rt) pl->lds_bytes[rt] = sizeof(float) * (size_t)chain_lds(16 * rt, h.ldS, h.ldH).total;
     if (pl->lds_bytes[1] > 160 * 1024) { delete pl; return MMN_ERR_UNSUPPORTED; }
@@ -1780,6 +2357,12 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
         if (need <= 160 * 1024 &&
             (e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)) != hipSuccess)
             return fail(e);
+    }
+    if (pl->par_ok) {
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_par), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)pl->par_lds_fwd)) != hipSuccess) return fail(e);
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_bwd_par), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)pl->par_lds_bwd)) != hipSuccess) return fail(e);
     }
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(sizeof(float) * WGRAD_LDS_FLOATS))) != hipSuccess) return fail(e);
@@ -1808,6 +2391,7 @@ static int check_batch(const mmn_plan* p, const mmn_batch* b) {
 }
 
 static int rt_for(const mmn_plan* p, const mmn_batch* b) {
+    if (p->par_ok) return 1;                 // the parallel-phase kernels use 16-row tiles
     int rt = choose_rt(p, b->batch);
     if (p->lds_bytes[rt] > 160 * 1024) rt = 1;
     return rt;
@@ -1846,7 +2430,8 @@ int mmn_chain_fwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float sc_p
     const float cL = err_penalty / ((float)p->m.n_decoders * (float)(p->m.n_encoders + 1) * (float)b->batch_global);
     mmn_batch bb = *b;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (rt == 1) hipLaunchKernelGGL(k_chain_fwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cL, want_grads);
+    if (p->par_ok) hipLaunchKernelGGL(k_chain_fwd_par, dim3(tiles), dim3(NT), p->par_lds_fwd, st, p->dev, bb, cL, want_grads);
+    else if (rt == 1) hipLaunchKernelGGL(k_chain_fwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cL, want_grads);
     else hipLaunchKernelGGL(k_chain_fwd<2>, dim3(tiles), dim3(NT), p->lds_bytes[2], st, p->dev, bb, cL, want_grads);
     HIP_TRY(hipGetLastError());
     return MMN_OK;
@@ -1864,7 +2449,8 @@ int mmn_chain_bwd(mmn_plan* p, const mmn_batch* b, float sc_pen_x001, void* stre
     mmn_batch bb = *b;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float cS = sc_coeff(p, b, sc_pen_x001);
-    if (rt == 1) hipLaunchKernelGGL(k_chain_bwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cS);
+    if (p->par_ok) hipLaunchKernelGGL(k_chain_bwd_par, dim3(tiles), dim3(NT), p->par_lds_bwd, st, p->dev, bb, cS);
+    else if (rt == 1) hipLaunchKernelGGL(k_chain_bwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cS);
     else hipLaunchKernelGGL(k_chain_bwd<2>, dim3(tiles), dim3(NT), p->lds_bytes[2], st, p->dev, bb, cS);
     HIP_TRY(hipGetLastError());
     return MMN_OK;

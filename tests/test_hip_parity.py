@@ -68,8 +68,10 @@ def check_against(stats, grads, ref: O.StepResult, tol_loss=1e-5, tol_grad=2e-5,
             assert rel_err(grads[n].reshape(g.shape), g) < tol_grad, (n, rel_err(grads[n].reshape(g.shape), g))
 
 
+@pytest.mark.parametrize("mode", ["par16", "seq16"])
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
-def test_first_step_matches_reference_golden(lib, name):
+def test_first_step_matches_reference_golden(lib, name, mode, monkeypatch):
+    set_mode(monkeypatch, mode)
     g = Golden(name)
     model = build_torch_model(g.spec, g.init_params(), "cuda", lib)
     stats, grads, _ = run_step(model, g.batch(0))
@@ -118,10 +120,21 @@ def test_training_matches_reference_golden(lib, name):
         assert rel_err(sd[n], w) < tol, (n, rel_err(sd[n], w))
 
 
-@pytest.mark.parametrize("rt", ["1", "2"])
+KERNEL_MODES = {"par16": ("1", "1"), "seq16": ("1", "0"), "seq32": ("2", "0")}
+
+
+def set_mode(monkeypatch, mode):
+    """Kernel family, read at plan creation: parallel-phase chain kernels (16-row tiles) or the
+    sequential chain kernels with 16- / 32-row tiles."""
+    rt, par = KERNEL_MODES[mode]
+    monkeypatch.setenv("MMN_RT", rt)
+    monkeypatch.setenv("MMN_PAR", par)
+
+
+@pytest.mark.parametrize("mode", list(KERNEL_MODES))
 @pytest.mark.parametrize("B", [1, 15, 16, 17, 31, 32, 33, 257])
-def test_ragged_batches_match_oracle(lib, B, rt, monkeypatch):
-    monkeypatch.setenv("MMN_RT", rt)          # 16- and 32-row workgroup tiles (read at plan creation)
+def test_ragged_batches_match_oracle(lib, B, mode, monkeypatch):
+    set_mode(monkeypatch, mode)
     spec = O.ModelSpec(20, [O.EncoderSpec(7, (9, 6), O.ACT_RELU), O.EncoderSpec(3, (), O.ACT_RELU),
                             O.EncoderSpec(70, (33,), O.ACT_SIGMOID)], 3, 1.0, 0.7)
     params = O.init_params(spec, 3)
@@ -148,9 +161,9 @@ def c3_spec():
     return O.ModelSpec(128, [O.EncoderSpec(64, (32, 32), O.ACT_RELU) for _ in range(4)], 3, 1.0, 0.3)
 
 
-@pytest.mark.parametrize("rt", ["1", "2"])
-def test_full_size_c3_step_matches_oracle(lib, rt, monkeypatch):
-    monkeypatch.setenv("MMN_RT", rt)
+@pytest.mark.parametrize("mode", list(KERNEL_MODES))
+def test_full_size_c3_step_matches_oracle(lib, mode, monkeypatch):
+    set_mode(monkeypatch, mode)
     spec = c3_spec()
     params = O.init_params(spec, 0)
     batch = O.synthetic_batches(spec, 4096, 4096, seed=1)[0]

@@ -1105,6 +1105,23 @@ __device__ __forceinline__ bool row_executed(const mmn_batch& b, int r) {
     return false;
 }
 
+// one wave stores its LDS tile [nrows x N] to global (row stride N), 16 bytes per lane when possible
+__device__ __forceinline__ void wave_store_tile(float* __restrict__ dst, clp src, int ld_src, int nrows, int N) {
+    const int lane = threadIdx.x & 63;
+    if ((N & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        const int n4 = N >> 2;
+        for (int idx = lane; idx < nrows * n4; idx += 64) {
+            const int r = idx / n4, c = (idx - r * n4) << 2;
+            g_st4(dst + (int64_t)r * N + c, lds_ld4(src + r * ld_src + c));
+        }
+    } else {
+        for (int idx = lane; idx < nrows * N; idx += 64) {
+            const int r = idx / N, c = idx - r * N;
+            g_st(dst + (int64_t)r * N + c, lds_ld(src + r * ld_src + c));
+        }
+    }
+}
+
 // one wave computes out[16 x N] = A[16 x K] W'^T alone, two column tiles at a time
 template <class Epi>
 __device__ __forceinline__ void wave_layer(const ASrc& A, const PB& B, int t_begin, int t_end, Epi&& epi) {
@@ -1206,14 +1223,18 @@ __global__ __launch_bounds__(NT) void k_chain_fwd_par(const DevPlan* __restrict_
             // one memory round trip for the whole phase instead of one per layer and tile pair
             const int f4 = round_up(F, 16) >> 2;           // float4 per image row (<= 32)
             f32x4 xr[8];
+            const int nx = (TB * f4 + 63) >> 6;             // float4 per lane actually needed (wave-uniform)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int idx = lane + 64 * k;
-                const int row = idx / f4, c = (idx - row * f4) << 2;
-                const bool ok = idx < TB * f4 && row < nrows && c < F;
-                const f32x4 v = g_ld4(xg + (ok ? (int64_t)row * ldx + c : 0));
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                xr[k] = ok ? v : z;
+                xr[k] = z;
+                if (k < nx) {
+                    const int idx = lane + 64 * k;
+                    const int row = idx / f4, c = (idx - row * f4) << 2;
+                    const bool ok = idx < TB * f4 && row < nrows && c < F;
+                    const f32x4 v = g_ld4(xg + (ok ? (int64_t)row * ldx + c : 0));
+                    xr[k] = ok ? v : z;
+                }
             }
             const int pair0[2] = {0, 16};
             f32x4 hq0[4][2], hq1[4][2], uq[4][4][2];
@@ -1221,13 +1242,15 @@ __global__ __launch_bounds__(NT) void k_chain_fwd_par(const DevPlan* __restrict_
             const int i16 = lane & 15;
             if (Lh >= 1) {
                 const auto& lin = enc.layer[0];
-                issue_b<4>(hq0, make_pb(p.pack + p.pkf_off[e][0], lin.out_dim, lin.in_dim, 0), pair0, 0);
+                const PB Bq = make_pb(p.pack + p.pkf_off[e][0], lin.out_dim, lin.in_dim, 0);
+                if (Bq.T <= 2) issue_b<2>(reinterpret_cast<f32x4 (&)[2][2]>(hq0), Bq, pair0, 0); else issue_b<4>(hq0, Bq, pair0, 0);
                 hb0 = g_ld(lin.b + min(i16, lin.out_dim - 1));
                 hb0b = g_ld(lin.b + min(16 + i16, lin.out_dim - 1));
             }
             if (Lh >= 2) {
                 const auto& lin = enc.layer[1];
-                issue_b<4>(hq1, make_pb(p.pack + p.pkf_off[e][1], lin.out_dim, lin.in_dim, 0), pair0, 0);
+                const PB Bq = make_pb(p.pack + p.pkf_off[e][1], lin.out_dim, lin.in_dim, 0);
+                if (Bq.T <= 2) issue_b<2>(reinterpret_cast<f32x4 (&)[2][2]>(hq1), Bq, pair0, 0); else issue_b<4>(hq1, Bq, pair0, 0);
                 hb1 = g_ld(lin.b + min(i16, lin.out_dim - 1));
                 hb1b = g_ld(lin.b + min(16 + i16, lin.out_dim - 1));
             }
@@ -1237,10 +1260,14 @@ __global__ __launch_bounds__(NT) void k_chain_fwd_par(const DevPlan* __restrict_
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) {
                 const int nn[2] = {32 * pr, 32 * pr + 16};
-                issue_b<4>(uq[pr], BU, nn, BU.T0);
+                if (nn[0] < S) {
+                    if (BU.T - BU.T0 <= 2) issue_b<2>(reinterpret_cast<f32x4 (&)[2][2]>(uq[pr]), BU, nn, BU.T0);
+                    else issue_b<4>(uq[pr], BU, nn, BU.T0);
+                }
                 ub[pr][0] = g_ld(llin.b + min(nn[0] + i16, S - 1));
                 ub[pr][1] = g_ld(llin.b + min(nn[1] + i16, S - 1));
             }
+            STAMP();   // A0: all operand loads issued
             // x -> LDS image
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -1250,6 +1277,7 @@ __global__ __launch_bounds__(NT) void k_chain_fwd_par(const DevPlan* __restrict_
                     lds_st4(sXw + row * ldX + c, xr[k]);
                 }
             }
+            STAMP();   // A1: x landed and written to LDS
             clp in = sXw;
             int ldin = ldX;
             if (Lh >= 1) {
@@ -1260,15 +1288,14 @@ __global__ __launch_bounds__(NT) void k_chain_fwd_par(const DevPlan* __restrict_
                 f32x4 acc[2][1];
                 zero_acc<1>(acc);
                 consume_b<1, 4>(acc, ASrc{in, ldin, in, ldin}, B, hq0, 0, B.T, 16 < N);
+                STAMP();   // A2: h0 MFMAs
                 run_epilogue<1>(acc, pair0, N, [&](int row, int col, int c, float v) {
                     if (col < N) lds_st(out + row * ldH + col, act_fwd(v + (c ? hb0b : hb0), akind));
                 });
-                if (want_grads) {
-                    float* hg = p.hid + p.hid_off[e][0] + (int64_t)row0 * N;
-                    for (int r = 0; r < nrows; ++r)
-                        for (int c = lane; c < N; c += 64) g_st(hg + (int64_t)r * N + c, lds_ld(out + r * ldH + c));
-                }
+                STAMP();   // A3: h0 epilogue
+                if (want_grads) wave_store_tile(p.hid + p.hid_off[e][0] + (int64_t)row0 * N, out, ldH, nrows, N);
                 in = out; ldin = ldH;
+                STAMP();   // A4: hid0 stored
             }
             if (Lh >= 2) {
                 const auto& lin = enc.layer[1];
@@ -1281,16 +1308,14 @@ __global__ __launch_bounds__(NT) void k_chain_fwd_par(const DevPlan* __restrict_
                 run_epilogue<1>(acc, pair0, N, [&](int row, int col, int c, float v) {
                     if (col < N) lds_st(out + row * ldH + col, act_fwd(v + (c ? hb1b : hb1), akind));
                 });
-                if (want_grads) {
-                    float* hg = p.hid + p.hid_off[e][1] + (int64_t)row0 * N;
-                    for (int r = 0; r < nrows; ++r)
-                        for (int c = lane; c < N; c += 64) g_st(hg + (int64_t)r * N + c, lds_ld(out + r * ldH + c));
-                }
+                if (want_grads) wave_store_tile(p.hid + p.hid_off[e][1] + (int64_t)row0 * N, out, ldH, nrows, N);
                 in = out; ldin = ldH;
             }
+            STAMP();   // A5: h1 done
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) {
                 const int nn[2] = {32 * pr, 32 * pr + 16};
+                STAMP();   // A6..: one u pair
                 if (nn[0] < S) {
                     f32x4 acc[2][1];
                     zero_acc<1>(acc);
@@ -1332,11 +1357,7 @@ __global__ __launch_bounds__(NT) void k_chain_fwd_par(const DevPlan* __restrict_
             wave_layer(A, B, 0, B.T, [&](int row, int col, float v) {
                 if (col < N) lds_st(out + row * ldH + col, act_fwd(v + g_ld(bias + col), akind));
             });
-            if (want_grads) {
-                float* hg = p.hid + p.hid_off[e][l] + (int64_t)row0 * N;
-                for (int r = 0; r < nrows; ++r)
-                    for (int c = lane; c < N; c += 64) g_st(hg + (int64_t)r * N + c, lds_ld(out + r * ldH + c));
-            }
+            if (want_grads) wave_store_tile(p.hid + p.hid_off[e][l] + (int64_t)row0 * N, out, ldH, nrows, N);
             in = out;
             ldin = ldH;
         }
@@ -1369,6 +1390,7 @@ __global__ __launch_bounds__(NT) void k_chain_fwd_par(const DevPlan* __restrict_
         f32x4 acc[2][1];
         zero_acc<1>(acc);
         if (n0c[0] < S) consume_b<1, 8>(acc, ASrc{sC, ldS, sC, ldS}, B, wc, 0, B.T0, n0c[1] < S);
+        STAMP();   // B1: MFMAs
         if (t_nxt < b.n_seq) {                             // next step's fragments, behind this epilogue
             const int e2 = b.seq_enc[t_nxt];
             const int Lh2 = p.m.enc[e2].n_layers - 1;
@@ -1384,11 +1406,13 @@ __global__ __launch_bounds__(NT) void k_chain_fwd_par(const DevPlan* __restrict_
                 }
             });
         }
+        STAMP();   // B2: next issued + epilogue
         scacc = wave_sum(scacc);
         if (lane == 0) lds_st(sRed + 64 + 4 * e + wave, scacc);
         __syncthreads();
+        STAMP();   // B3: barrier
         if (want_grads) store_rows(p.states + ((int64_t)e * p.maxB + row0) * S, sN, ldS, nrows, S);
-        STAMP();   // P4..: one chain step
+        STAMP();   // B4: state tile stored
         cur = e + 1;
     };
     {
@@ -1618,6 +1642,575 @@ __global__ __launch_bounds__(NT) void k_chain_bwd_par(const DevPlan* __restrict_
         if (!row_executed(b, r)) continue;
         const int idx = r == 0 ? E : r - 1;
         store_rows(p.dS + ((int64_t)idx * p.maxB + row0) * S, DG + r * TB * ldS, ldS, nrows, S);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast tier: 8-wave parallel-phase chain kernels for MIMIC-like shapes
+//   E <= 8, D <= 8, S <= 128, <= 2 hidden layers of width <= 32, n_features <= 128 (16-byte
+//   aligned rows), h width into the state update <= 64.
+// Same phase structure as the 4-wave parallel kernels above, but (a) the model descriptor arrives
+// through kernel arguments (scalar loads, no per-lane LDS reads of the plan), (b) 512 threads =
+// 2 waves per SIMD, so one wave's s_waitcnt / barrier time is covered by its partner (the 4-wave
+// form was parked 52 % of its cycles), with the work cut finer: one 16-column tile per wave in
+// the chain, two waves per encoder in the parallel phases, (c) every operand is requested ahead.
+// ------------------------------------------------------------------------------------------------
+constexpr int NT8 = 512;
+
+struct ParEnc {
+    int32_t F, Lh, HL, akind;
+    int32_t in[3], out[3];              // layer dims; layer Lh is the state update (in = HL + S, out = S)
+    int32_t pad0[2];
+    int64_t pkf[3], pkb[3], pkh;        // float offsets into the pack
+    int64_t hid[2];                     // float offsets into hid / dpre
+    const float* bias[3];
+};
+struct ParArgs {
+    int32_t S, E, D, R, S16, ldS, ldH, ldX, maxB, needs_zero, pad0[2];
+    const float* init; const float* pack;
+    int64_t pkd;
+    float* states; float* hid; float* dpre; float* dz; float* dS;
+    float* lossp; float* scp; int32_t* cnt; int32_t* exec_flags; int32_t* prev_row;
+    long long* stamps;
+    const float* dec_w[MMN_MAX_DECODERS]; const float* dec_b[MMN_MAX_DECODERS];
+    ParEnc enc[8];
+};
+
+struct Par8Lds { int sSt, sU, sG, sW, wstride, oX, oH0, oH1, sDz, sZ, sRed, total; };
+__host__ __device__ inline Par8Lds par8_lds(int R, int E, int ldS, int ldH, int ldX, bool bwd) {
+    Par8Lds L;
+    int o = 0;
+    L.sSt = o; o += R * 16 * ldS;          // fwd: state tiles 0..E        bwd: decoder-grad -> G_out tiles
+    L.sU = o; o += E * 16 * ldS;           // fwd: u_e tiles               bwd: state differences
+    L.sG = o; o += bwd ? 2 * 16 * ldS : 0;
+    L.oX = 0; L.oH0 = bwd ? 0 : 16 * ldX; L.oH1 = L.oH0 + 16 * ldH;
+    L.wstride = L.oH1 + 16 * ldH;
+    L.sW = o; o += 4 * L.wstride;          // scratch per wave PAIR: x tile / hidden ping-pong
+    L.sDz = o; o += bwd ? 8 * 16 * LDZ : 0;  // dz tile per wave
+    L.sZ = o; o += bwd ? 0 : R * 16 * 16;
+    L.sRed = o; o += 8 * 8 + 16;
+    L.total = o;
+    return L;
+}
+
+// NS k-steps of ONE column tile
+template <int NS>
+__device__ __forceinline__ void issue_t(f32x4 (&bq)[NS], const float* pk, int T, int ntiles, int tile, int t_begin) {
+    const int lane = threadIdx.x & 63;
+    const float* p0 = pk + ((int64_t)min(tile, ntiles - 1) * T * 64 + lane) * 4;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) bq[j] = g_ld4(p0 + min(t_begin + j, T - 1) * 256);
+}
+// acc += A[16 x 16*(t_end-t_begin)] x fragment registers; A image row stride lda, step t reads a + 16 (t - t_base)
+template <int NS>
+__device__ __forceinline__ void consume_t(f32x4& acc, clp a, int lda, int t_base, const f32x4 (&bq)[NS], int t_begin, int t_end) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, q = lane >> 4;
+    clp ap = a + i * lda + 4 * q;
+    f32x4 av[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) av[j] = lds_ld4(ap + 16 * (min(t_begin + j, t_end - 1) - t_base));
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        if (t_begin + j < t_end) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma4(av[j][e], bq[j][e], acc);
+        }
+    }
+}
+#define STAMP8() stamp(nullptr, a.stamps, stamp_k, stamp_block)
+
+__device__ __forceinline__ int enc_of(const mmn_batch& b, int t) { return b.seq_enc[t]; }
+
+__global__ __launch_bounds__(NT8) void k_fwd8(const ParArgs a, const mmn_batch b, float cL, int want_grads) {
+    constexpr int TB = 16;
+    extern __shared__ __attribute__((aligned(16))) float smem_generic[];
+    const lp smem = (lp)smem_generic;
+    const int S = a.S, E = a.E, D = a.D, R = a.R, ldS = a.ldS, ldH = a.ldH, ldX = a.ldX;
+    const Par8Lds L = par8_lds(R, E, ldS, ldH, ldX, false);
+    const int tile = blockIdx.x, row0 = tile * TB;
+    const int nrows = min(TB, b.batch - row0);
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int i = lane & 15, q = lane >> 4;
+    const int g = wave >> 1, half = wave & 1;
+    const lp St = smem + L.sSt;
+    const lp Ut = smem + L.sU;
+    const lp sZ = smem + L.sZ;
+    const lp sRed = smem + L.sRed;
+    const lp sXg = smem + L.sW + g * L.wstride + L.oX;
+    lp sHg[2] = {smem + L.sW + g * L.wstride + L.oH0, smem + L.sW + g * L.wstride + L.oH1};
+    int stamp_k = 0;
+    const int stamp_block = 7;
+    STAMP8();
+    if (a.needs_zero) {                                    // K-padding columns must be finite
+        for (int idx = threadIdx.x; idx < L.total; idx += NT8) lds_st(smem + idx, 0.f);
+        __syncthreads();
+    }
+    for (int r = wave; r < TB; r += 8)                     // state row 0 = init state (state.py:29-32)
+        for (int c = lane; c < S; c += 64) lds_st(St + r * ldS + c, g_ld(a.init + c));
+    if (tile == 0 && threadIdx.x == 0) {                   // which state rows exist this step
+        g_sti(a.exec_flags, 1);
+        for (int e = 0; e < E; ++e) g_sti(a.exec_flags + e + 1, 0);
+        int prev = 0;
+        for (int t = 0; t < b.n_seq; ++t) {
+            if (!slot_present(b, b.seq_data[t])) continue;
+            const int e = b.seq_enc[t];
+            g_sti(a.exec_flags + e + 1, 1);
+            g_sti(a.prev_row + e, prev);
+            prev = e + 1;
+        }
+    }
+    const int ntS = (S + 15) >> 4, T0 = a.S16 >> 4;
+    // decoder fragments: wave r evaluates state row r (R <= 8)
+    f32x4 wd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (wave < R && j < T0 && i < 2 * D) {
+            const float* w = a.dec_w[i >> 1] + (i & 1) * S;
+            const int k = 16 * j + 4 * q;
+            if (k < S) v.x = g_ld(w + k);
+            if (k + 1 < S) v.y = g_ld(w + k + 1);
+            if (k + 2 < S) v.z = g_ld(w + k + 2);
+            if (k + 3 < S) v.w = g_ld(w + k + 3);
+        }
+        wd[j] = v;
+    }
+    // chain step 0's W_s fragments (tile = wave) land during phase A
+    f32x4 wsA[8], wsB[8];
+    const int t_first = next_exec(b, 0);
+    if (t_first < b.n_seq && wave < ntS) {
+        const ParEnc& pe = a.enc[b.seq_enc[t_first]];
+        issue_t<8>(wsA, a.pack + pe.pkf[pe.Lh], T0 + ((pe.HL + 15) >> 4), ntS, wave, 0);
+    }
+    STAMP8();
+
+    // ---- phase A: u_e = W_x h_e + b for every executed encoder; wave pair g takes encoder t = tb + g
+    for (int tb = 0; tb < b.n_seq; tb += 4) {
+        const int t = tb + g;
+        const bool act = t < b.n_seq && slot_present(b, b.seq_data[min(t, b.n_seq - 1)]);
+        const int e = act ? b.seq_enc[t] : 0;
+        const ParEnc& pe = a.enc[e];
+        const int Lh = pe.Lh, F = pe.F, HL = pe.HL, akind = pe.akind;
+        int Lmax = 0;                                       // barrier count must be uniform over the workgroup
+        for (int k = 0; k < 4; ++k)
+            if (tb + k < b.n_seq && slot_present(b, b.seq_data[tb + k])) Lmax = max(Lmax, a.enc[b.seq_enc[tb + k]].Lh);
+        const int f4 = round_up(F, 16) >> 2;               // float4 per image row (<= 32)
+        const int TU = (HL + 15) >> 4;
+        const float* pkU = a.pack + pe.pkf[Lh];
+        // -- request everything this wave will consume in this round
+        f32x4 xr[4], h0q[8], h1q[2], uq[2][4][2];
+        float hb0 = 0.f, hb1 = 0.f, ub[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        if (act) {
+            const int slot = b.seq_data[t];
+            const float* xg = b.x[slot] + (int64_t)row0 * b.ldx[slot];
+            const int64_t ldx = b.ldx[slot];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                  // this half's 8 rows of the x tile
+                const int idx = lane + 64 * k;
+                const int row = 8 * half + idx / f4, c = (idx % f4) << 2;
+                const bool ok = idx < 8 * f4 && row < nrows && c < F;
+                const f32x4 v = g_ld4(xg + (ok ? (int64_t)row * ldx + c : 0));
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                xr[k] = ok ? v : z;
+            }
+            if (Lh >= 1) {
+                issue_t<8>(h0q, a.pack + pe.pkf[0], (pe.in[0] + 15) >> 4, (pe.out[0] + 15) >> 4, half, 0);
+                hb0 = g_ld(pe.bias[0] + min(16 * half + i, pe.out[0] - 1));
+            }
+            if (Lh >= 2) {
+                issue_t<2>(h1q, a.pack + pe.pkf[1], (pe.in[1] + 15) >> 4, (pe.out[1] + 15) >> 4, half, 0);
+                hb1 = g_ld(pe.bias[1] + min(16 * half + i, pe.out[1] - 1));
+            }
+            const PB BU = make_pb(pkU, S, S, HL);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int nn[2] = {16 * (4 * half + 2 * pr), 16 * (4 * half + 2 * pr + 1)};
+                if (nn[0] < S) {
+                    issue_b<4>(uq[pr], BU, nn, BU.T0);
+                    ub[pr][0] = g_ld(pe.bias[Lh] + min(nn[0] + i, S - 1));
+                    ub[pr][1] = g_ld(pe.bias[Lh] + min(nn[1] + i, S - 1));
+                }
+            }
+            // -- x -> the pair's LDS image
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane + 64 * k;
+                if (idx < 8 * f4) lds_st4(sXg + (8 * half + idx / f4) * ldX + ((idx % f4) << 2), xr[k]);
+            }
+        }
+        __syncthreads();
+        if (Lmax >= 1) {                                   // hidden layer 0 (mlp_encoder.py:75-76), tile = half
+            if (act && Lh >= 1 && 16 * half < pe.out[0]) {
+                const int N = pe.out[0], T = (pe.in[0] + 15) >> 4;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                consume_t<8>(acc, sXg, ldX, 0, h0q, 0, T);
+                const int col = 16 * half + i;
+                if (col < N) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) lds_st(sHg[0] + (4 * q + k) * ldH + col, act_fwd(acc[k] + hb0, akind));
+                }
+            }
+            __syncthreads();
+            if (act && Lh >= 1 && want_grads) {            // each half stores 8 rows of the tile
+                const int N = pe.out[0];
+                const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
+                wave_store_tile(a.hid + pe.hid[0] + (int64_t)(row0 + r0) * N, sHg[0] + r0 * ldH, ldH, nr, N);
+            }
+        }
+        if (Lmax >= 2) {
+            if (act && Lh >= 2 && 16 * half < pe.out[1]) {
+                const int N = pe.out[1], T = (pe.in[1] + 15) >> 4;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                consume_t<2>(acc, sHg[0], ldH, 0, h1q, 0, T);
+                const int col = 16 * half + i;
+                if (col < N) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) lds_st(sHg[1] + (4 * q + k) * ldH + col, act_fwd(acc[k] + hb1, akind));
+                }
+            }
+            __syncthreads();
+            if (act && Lh >= 2 && want_grads) {
+                const int N = pe.out[1];
+                const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
+                wave_store_tile(a.hid + pe.hid[1] + (int64_t)(row0 + r0) * N, sHg[1] + r0 * ldH, ldH, nr, N);
+            }
+        }
+        if (act) {                                         // u_e = W_x h + b (mlp_encoder.py:78), this half's 4 tiles
+            clp in = Lh == 0 ? (clp)sXg : (clp)sHg[Lh - 1];
+            const int ldin = Lh == 0 ? ldX : ldH;
+            const lp U = Ut + e * TB * ldS;
+            const PB BU = make_pb(pkU, S, S, HL);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int nn[2] = {16 * (4 * half + 2 * pr), 16 * (4 * half + 2 * pr + 1)};
+                if (nn[0] < S) {
+                    f32x4 acc[2][1];
+                    zero_acc<1>(acc);
+                    consume_b<1, 4>(acc, ASrc{in, ldin, in, ldin}, BU, uq[pr], BU.T0, BU.T0 + TU, nn[1] < S);
+                    run_epilogue<1>(acc, nn, S, [&](int row, int col, int c, float v) {
+                        if (col < S) lds_st(U + row * ldS + col, v + ub[pr][c]);
+                    });
+                }
+            }
+        }
+        __syncthreads();                                    // scratch is reused by the next round
+    }
+    STAMP8();
+
+    // ---- phase B: s' = W_s s + u_e; one column tile per wave, fragments one step ahead
+    int cur = 0;
+    auto chain_step = [&](f32x4 (&wc)[8], f32x4 (&wn)[8], int t, int t_nxt) {
+        const int e = b.seq_enc[t];
+        const clp sC = St + cur * TB * ldS;
+        const lp sN = St + (e + 1) * TB * ldS;
+        const clp U = Ut + e * TB * ldS;
+        float scacc = 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (wave < ntS) consume_t<8>(acc, sC, ldS, 0, wc, 0, T0);
+        if (t_nxt < b.n_seq && wave < ntS) {
+            const ParEnc& p2 = a.enc[b.seq_enc[t_nxt]];
+            issue_t<8>(wn, a.pack + p2.pkf[p2.Lh], T0 + ((p2.HL + 15) >> 4), ntS, wave, 0);
+        }
+        const int col = 16 * wave + i;
+        if (wave < ntS && col < S) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = 4 * q + k;
+                const float ns = acc[k] + lds_ld(U + row * ldS + col);
+                const float dlt = ns - lds_ld(sC + row * ldS + col);
+                if (row < nrows) scacc += dlt * dlt;              // multimodn.py:174
+                lds_st(sN + row * ldS + col, ns);
+            }
+        }
+        scacc = wave_sum(scacc);
+        if (lane == 0) lds_st(sRed + 8 * e + wave, scacc);
+        __syncthreads();
+        if (want_grads) {                                   // each wave stores two rows of the new state tile
+            for (int r = wave; r < nrows; r += 8)
+                for (int c = lane * 4; c < S; c += 256) {
+                    if (((S & 3) == 0)) g_st4(a.states + ((int64_t)e * a.maxB + row0 + r) * S + c, lds_ld4(sN + r * ldS + c));
+                    else for (int k = 0; k < 4 && c + k < S; ++k) g_st(a.states + ((int64_t)e * a.maxB + row0 + r) * S + c + k, lds_ld(sN + r * ldS + c + k));
+                }
+        }
+        cur = e + 1;
+    };
+    {
+        bool flip = false;
+        for (int t = t_first; t < b.n_seq;) {
+            const int t_nxt = next_exec(b, t + 1);
+            if (!flip) chain_step(wsA, wsB, t, t_nxt); else chain_step(wsB, wsA, t, t_nxt);
+            flip = !flip;
+            t = t_nxt;
+        }
+    }
+    STAMP8();
+
+    // ---- phase C: all decoders on all state rows (decoders.py:19-20, multimodn.py:141-157,176-191)
+    if (wave < R && row_executed(b, wave)) {
+        const clp sS = St + wave * TB * ldS;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        consume_t<8>(z, sS, ldS, 0, wd, 0, T0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lds_st(sZ + (wave * TB + q * 4 + k) * 16 + i, z[k]);
+    }
+    __syncthreads();
+    const int total = R * D * TB;
+    for (int base = 0; base < total; base += NT8) {
+        const int idx = base + threadIdx.x;
+        const bool valid = idx < total;
+        const int r = valid ? idx / (D * TB) : 0;
+        const int rem = idx - r * D * TB;
+        const int d = valid ? rem / TB : 0, row = rem & (TB - 1);
+        const bool live = valid && row < nrows && row_executed(b, r);
+        float lossv = 0.f;
+        int correct = 0, tp = 0, tn = 0, fp = 0, fn = 0;
+        if (live) {
+            const float* bd = a.dec_b[d];
+            const float za = g_ld(bd) + lds_ld(sZ + (r * TB + row) * 16 + 2 * d);
+            const float zb = g_ld(bd + 1) + lds_ld(sZ + (r * TB + row) * 16 + 2 * d + 1);
+            const int64_t grow = (int64_t)row0 + row;
+            const int y = (int)*(const MMN_AS1 int64_t*)(b.y + grow * D + d);
+            const float o0 = 1.0f / (1.0f + expf(-za));
+            const float o1 = 1.0f / (1.0f + expf(-zb));
+            const float mx = fmaxf(o0, o1);
+            const float lse = mx + logf(expf(o0 - mx) + expf(o1 - mx));
+            lossv = lse - (y ? o1 : o0);
+            const int pred = o1 > o0 ? 1 : 0;      // torch.max: first index wins ties
+            correct = pred == y;
+            tp = pred & y; tn = (1 - pred) & (1 - y); fp = pred & (1 - y); fn = (1 - pred) & y;
+            if (want_grads) {
+                const float g0 = expf(o0 - lse) - (y == 0 ? 1.0f : 0.0f);
+                const float g1 = expf(o1 - lse) - (y == 1 ? 1.0f : 0.0f);
+                f32x2 dzv;
+                dzv.x = cL * g0 * o0 * (1.0f - o0);
+                dzv.y = cL * g1 * o1 * (1.0f - o1);
+                g_st2(a.dz + ((int64_t)r * a.maxB + grow) * (2 * D) + 2 * d, dzv);
+            }
+        }
+#pragma unroll
+        for (int off = TB / 2; off >= 1; off >>= 1) lossv += __shfl_xor(lossv, off);
+        const unsigned long long mc = __ballot(correct), mtp = __ballot(tp), mtn = __ballot(tn),
+                                 mfp = __ballot(fp), mfn = __ballot(fn);
+        if (valid && row == 0) {
+            const int sh = lane & ~(TB - 1);
+            const int64_t cell = (int64_t)tile * (R * D) + r * D + d;
+            g_st(a.lossp + cell, lossv);
+            int32_t* cp = a.cnt + cell * 5;
+            g_sti(cp + 0, __popcll((mc >> sh) & 0xFFFFull));
+            g_sti(cp + 1, __popcll((mtp >> sh) & 0xFFFFull));
+            g_sti(cp + 2, __popcll((mtn >> sh) & 0xFFFFull));
+            g_sti(cp + 3, __popcll((mfp >> sh) & 0xFFFFull));
+            g_sti(cp + 4, __popcll((mfn >> sh) & 0xFFFFull));
+        }
+    }
+    for (int e = threadIdx.x; e < E; e += NT8) {            // state-change partials, fixed order
+        float s = 0.f;
+        for (int w = 0; w < 8; ++w) s += lds_ld(sRed + 8 * e + w);
+        g_st(a.scp + (int64_t)tile * E + e, s);
+    }
+    STAMP8();
+}
+
+__global__ __launch_bounds__(NT8) void k_bwd8(const ParArgs a, const mmn_batch b, float cS) {
+    constexpr int TB = 16;
+    extern __shared__ __attribute__((aligned(16))) float smem_generic[];
+    const lp smem = (lp)smem_generic;
+    const int S = a.S, E = a.E, D = a.D, R = a.R, ldS = a.ldS, ldH = a.ldH, ldX = a.ldX;
+    const Par8Lds L = par8_lds(R, E, ldS, ldH, ldX, true);
+    const int tile = blockIdx.x, row0 = tile * TB;
+    const int nrows = min(TB, b.batch - row0);
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int i = lane & 15, q = lane >> 4;
+    const int g = wave >> 1, half = wave & 1;
+    const lp DG = smem + L.sSt;          // decoder-grad tiles, then G_out tiles in place
+    const lp Df = smem + L.sU;           // s_out - s_in per encoder
+    lp sG[2] = {smem + L.sG, smem + L.sG + TB * ldS};
+    lp sHg[2] = {smem + L.sW + g * L.wstride + L.oH0, smem + L.sW + g * L.wstride + L.oH1};
+    const lp sDzw = smem + L.sDz + wave * 16 * LDZ;
+    const int ntS = (S + 15) >> 4, T0 = a.S16 >> 4;
+    // everything else is fully overwritten before it is read; the carried gradient starts at zero
+    for (int idx = threadIdx.x; idx < (a.needs_zero ? L.total : 2 * TB * ldS); idx += NT8)
+        lds_st((a.needs_zero ? smem : smem + L.sG) + idx, 0.f);
+    // first chain step's W_s^T fragments (tile = wave)
+    f32x4 wcA[8], wcB[8];
+    int t_last = b.n_seq - 1;
+    while (t_last >= 0 && !slot_present(b, b.seq_data[t_last])) --t_last;
+    if (t_last >= 0 && wave < ntS) {
+        const ParEnc& pe = a.enc[b.seq_enc[t_last]];
+        issue_t<8>(wcA, a.pack + pe.pkb[pe.Lh], T0, ntS, wave, 0);
+    }
+    if (a.needs_zero) __syncthreads();
+
+    // ---- phase A': decoder gradient of state row r (wave r), state differences (all waves)
+    if (wave < R && row_executed(b, wave)) {
+        const int r = wave;
+        for (int idx = lane; idx < TB * 16; idx += 64) {
+            const int row = idx >> 4, n = idx & 15;
+            float v = 0.f;
+            if (row < nrows && n < 2 * D) v = g_ld(a.dz + ((int64_t)r * a.maxB + row0 + row) * (2 * D) + n);
+            lds_st(sDzw + row * LDZ + n, v);
+        }
+        const PB Bdz = make_pb(a.pack + a.pkd, S, 2 * D, 0);      // W' = Wdec^T [S x 2D]
+        const lp out = DG + r * TB * ldS;
+        wave_layer(ASrc{sDzw, LDZ, sDzw, LDZ}, Bdz, 0, Bdz.T, [&](int row, int col, float v) {
+            if (col < S) lds_st(out + row * ldS + col, v);
+        });
+    }
+    for (int t = wave; t < b.n_seq; t += 8) {
+        if (!slot_present(b, b.seq_data[t])) continue;
+        const int e = b.seq_enc[t];
+        int prev_row = 0;
+        for (int u = 0, pr = 0; u < b.n_seq; ++u) {
+            if (!slot_present(b, b.seq_data[u])) continue;
+            if (b.seq_enc[u] == e) prev_row = pr;
+            pr = b.seq_enc[u] + 1;
+        }
+        const float* so = a.states + ((int64_t)e * a.maxB + row0) * S;
+        const float* si = prev_row ? a.states + ((int64_t)(prev_row - 1) * a.maxB + row0) * S : nullptr;
+        const lp dd = Df + e * TB * ldS;
+        for (int rr = 0; rr < TB; ++rr)
+            for (int c = lane; c < S; c += 64) {
+                float v = 0.f;
+                if (rr < nrows) {
+                    const float x0 = g_ld(so + (int64_t)rr * S + c);
+                    const float x1 = si ? g_ld(si + (int64_t)rr * S + c) : g_ld(a.init + c);
+                    v = x0 - x1;
+                }
+                lds_st(dd + rr * ldS + c, v);
+            }
+    }
+    __syncthreads();
+
+    // ---- phase B': G_out(e) = carry + DG[e+1] + cS d_e ;  carry' = G_out W_s - cS d_e
+    int cur = 0;
+    auto chain_step = [&](f32x4 (&wc)[8], f32x4 (&wn)[8], int t, int t_prv) {
+        const int e = b.seq_enc[t];
+        const lp Go = DG + (e + 1) * TB * ldS;
+        const clp dd = Df + e * TB * ldS;
+        const clp G = sG[cur];
+        const lp Gn = sG[cur ^ 1];
+        for (int rr = wave; rr < TB; rr += 8)
+            for (int c = lane; c < S; c += 64)
+                lds_st(Go + rr * ldS + c, lds_ld(G + rr * ldS + c) + lds_ld(Go + rr * ldS + c) + cS * lds_ld(dd + rr * ldS + c));
+        __syncthreads();
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (wave < ntS) consume_t<8>(acc, Go, ldS, 0, wc, 0, T0);
+        if (t_prv >= 0 && wave < ntS) {
+            const ParEnc& p2 = a.enc[b.seq_enc[t_prv]];
+            issue_t<8>(wn, a.pack + p2.pkb[p2.Lh], T0, ntS, wave, 0);
+        }
+        const int col = 16 * wave + i;
+        if (wave < ntS && col < S) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = 4 * q + k;
+                lds_st(Gn + row * ldS + col, acc[k] - cS * lds_ld(dd + row * ldS + col));
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    };
+    {
+        bool flip = false;
+        for (int t = t_last; t >= 0;) {
+            int t_prv = t - 1;
+            while (t_prv >= 0 && !slot_present(b, b.seq_data[t_prv])) --t_prv;
+            if (!flip) chain_step(wcA, wcB, t, t_prv); else chain_step(wcB, wcA, t, t_prv);
+            flip = !flip;
+            t = t_prv;
+        }
+    }
+    {   // row 0: dS0 = carry + DG[0]
+        const clp G = sG[cur];
+        for (int rr = wave; rr < TB; rr += 8)
+            for (int c = lane; c < S; c += 64) lds_st(DG + rr * ldS + c, lds_ld(G + rr * ldS + c) + lds_ld(DG + rr * ldS + c));
+    }
+    __syncthreads();
+    // ---- stores: dS[e] = G_out(e), dS[E] = dS0 (final since the barrier above); fire and forget
+    for (int r = 0; r < R; ++r) {
+        if (!row_executed(b, r)) continue;
+        const int idx = r == 0 ? E : r - 1;
+        for (int rr = wave; rr < nrows; rr += 8)
+            for (int c = lane * 4; c < S; c += 256) {
+                if ((S & 3) == 0) g_st4(a.dS + ((int64_t)idx * a.maxB + row0 + rr) * S + c, lds_ld4(DG + (r * TB + rr) * ldS + c));
+                else for (int k = 0; k < 4 && c + k < S; ++k) g_st(a.dS + ((int64_t)idx * a.maxB + row0 + rr) * S + c + k, lds_ld(DG + (r * TB + rr) * ldS + c + k));
+            }
+    }
+
+    // ---- phase C': hidden-layer backward; wave pair g takes encoder t = tb + g, halves split the tiles
+    for (int tb = 0; tb < b.n_seq; tb += 4) {
+        const int t = tb + g;
+        const bool act0 = t < b.n_seq && slot_present(b, b.seq_data[min(t, b.n_seq - 1)]);
+        const int e = act0 ? b.seq_enc[t] : 0;
+        const ParEnc& pe = a.enc[e];
+        const int Lh = pe.Lh, HL = pe.HL, akind = pe.akind;
+        const bool act = act0 && Lh >= 1;
+        int Lmax = 0;
+        for (int k = 0; k < 4; ++k)
+            if (tb + k < b.n_seq && slot_present(b, b.seq_data[tb + k])) Lmax = max(Lmax, a.enc[b.seq_enc[tb + k]].Lh);
+        if (Lmax == 0) continue;
+        const clp Go = DG + (e + 1) * TB * ldS;
+        // dh = G_out W_x : tile = half of the <= 2 tiles of HL... HL may be up to 64 -> tiles half, half+2
+        f32x4 hq[2][8];
+        f32x4 h1q[2];
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (16 * (half + 2 * k) < HL) issue_t<8>(hq[k], a.pack + pe.pkh, T0, (HL + 15) >> 4, half + 2 * k, 0);
+            if (Lh >= 2 && 16 * half < pe.in[1])
+                issue_t<2>(h1q, a.pack + pe.pkb[1], (pe.out[1] + 15) >> 4, (pe.in[1] + 15) >> 4, half, 0);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int tl = half + 2 * k;
+                if (16 * tl < HL) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    consume_t<8>(acc, Go, ldS, 0, hq[k], 0, T0);
+                    const int col = 16 * tl + i;
+                    if (col < HL) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) lds_st(sHg[0] + (4 * q + kk) * ldH + col, acc[kk]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int l = Lmax - 1; l >= 0; --l) {
+            // dpre_l = dh_l .* act'(h_l): each half takes 8 rows
+            const int lb = Lh - 1 - (Lmax - 1 - l);        // this encoder's layer at this depth (aligned at the top)
+            if (act && lb >= 0) {
+                const int Hl = pe.out[lb];
+                const lp cbuf = sHg[(Lh - 1 - lb) & 1];
+                const float* hid_g = a.hid + pe.hid[lb] + (int64_t)row0 * Hl;
+                float* dpre_g = a.dpre + pe.hid[lb] + (int64_t)row0 * Hl;
+                for (int r = 8 * half; r < 8 * half + 8; ++r)
+                    for (int c = lane; c < Hl; c += 64) {
+                        float dp = 0.f;
+                        if (r < nrows) {
+                            dp = lds_ld(cbuf + r * ldH + c) * act_grad_from_out(g_ld(hid_g + (int64_t)r * Hl + c), akind);
+                            g_st(dpre_g + (int64_t)r * Hl + c, dp);
+                        }
+                        lds_st(cbuf + r * ldH + c, dp);
+                    }
+            }
+            __syncthreads();
+            if (l == 0) break;
+            if (act && lb >= 1) {                           // dh_{lb-1} = dpre_lb W_lb, tile = half
+                const int Hp = pe.in[lb], Hl = pe.out[lb];
+                if (16 * half < Hp) {
+                    const lp cbuf = sHg[(Lh - 1 - lb) & 1];
+                    const lp nbuf = sHg[(Lh - lb) & 1];
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    consume_t<2>(acc, cbuf, ldH, 0, h1q, 0, (Hl + 15) >> 4);
+                    const int col = 16 * half + i;
+                    if (col < Hp) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) lds_st(nbuf + (4 * q + kk) * ldH + col, acc[kk]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -1981,6 +2574,9 @@ struct mmn_plan {
     size_t lds_bytes[3];     // by RT
     size_t par_lds_fwd, par_lds_bwd;
     int par_ok;
+    ParArgs pa;              // kernel-argument descriptor of the 8-wave fast tier
+    size_t f8_lds_fwd, f8_lds_bwd;
+    int f8_ok;
     int grad_blocks;
     int rt_override;
 };
@@ -2336,6 +2932,50 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
             fprintf(stderr, "[mmn] plan: sizeof(DevPlan)=%zu par_lds fwd=%zu bwd=%zu par_ok=%d ldS=%d ldH=%d ldX=%d\n",
                     sizeof(DevPlan), pl->par_lds_fwd, pl->par_lds_bwd, pl->par_ok, h.ldS, h.ldH, h.ldX);
     }
+    {   // ---- 8-wave fast tier: eligibility + kernel-argument descriptor
+        ParArgs& a = pl->pa;
+        memset(&a, 0, sizeof(a));
+        bool ok = pl->par_ok && h.E <= 8 && h.D <= MMN_MAX_DECODERS && h.S <= 128;
+        bool aligned16 = (h.S % 16) == 0;
+        for (int e = 0; e < h.E && ok; ++e) {
+            const mmn_encoder& enc = m->enc[e];
+            const int Lh = enc.n_layers - 1;
+            ParEnc& pe = a.enc[e];
+            ok = ok && Lh <= 2 && enc.n_features <= 128 && (enc.n_features % 4) == 0;
+            if (!ok) break;
+            pe.F = enc.n_features; pe.Lh = Lh; pe.akind = enc.activation;
+            pe.HL = enc.layer[Lh].in_dim - h.S;
+            ok = ok && pe.HL <= 64;
+            aligned16 = aligned16 && (pe.F % 16) == 0 && (pe.HL % 16) == 0;
+            for (int l = 0; l <= Lh; ++l) {
+                pe.in[l] = enc.layer[l].in_dim; pe.out[l] = enc.layer[l].out_dim;
+                pe.pkf[l] = L.pkf_off[e][l]; pe.pkb[l] = L.pkb_off[e][l];
+                pe.bias[l] = enc.layer[l].b;
+                if (l < Lh) {
+                    pe.hid[l] = L.hid_off[e][l];
+                    ok = ok && enc.layer[l].out_dim <= 32;
+                    aligned16 = aligned16 && (enc.layer[l].out_dim % 16) == 0;
+                }
+            }
+            pe.pkh = L.pkh_off[e];
+        }
+        a.S = h.S; a.E = h.E; a.D = h.D; a.R = h.R; a.S16 = h.S16; a.ldS = h.ldS; a.ldH = h.ldH; a.ldX = h.ldX;
+        a.maxB = h.maxB; a.needs_zero = aligned16 ? 0 : 1;
+        a.init = m->init_state; a.pack = h.pack; a.pkd = L.pkd_off;
+        a.states = h.states; a.hid = h.hid; a.dpre = h.dpre; a.dz = h.dz; a.dS = h.dS;
+        a.lossp = h.lossp; a.scp = h.scp; a.cnt = h.cnt; a.exec_flags = h.exec_flags; a.prev_row = h.prev_row;
+        a.stamps = h.stamps;
+        for (int d = 0; d < h.D && d < MMN_MAX_DECODERS; ++d) { a.dec_w[d] = m->dec[d].w; a.dec_b[d] = m->dec[d].b; }
+        pl->f8_lds_fwd = sizeof(float) * (size_t)par8_lds(h.R, h.E, h.ldS, h.ldH, h.ldX, false).total;
+        pl->f8_lds_bwd = sizeof(float) * (size_t)par8_lds(h.R, h.E, h.ldS, h.ldH, h.ldX, true).total;
+        ok = ok && pl->f8_lds_fwd <= 160 * 1024 && pl->f8_lds_bwd <= 160 * 1024;
+        const char* fe = getenv("MMN_FAST8");
+        if (fe && atoi(fe) == 0) ok = false;
+        pl->f8_ok = ok ? 1 : 0;
+        if (getenv("MMN_VERBOSE"))
+            fprintf(stderr, "[mmn] fast8: ok=%d lds fwd=%zu bwd=%zu needs_zero=%d sizeof(ParArgs)=%zu\n", pl->f8_ok,
+                    pl->f8_lds_fwd, pl->f8_lds_bwd, a.needs_zero, sizeof(ParArgs));
+    }
     pl->lds_bytes[0] = 0;
     for (int rt = 1; rt <= 2; ++rt) pl->lds_bytes[rt] = sizeof(float) * (size_t)chain_lds(16 * rt, h.ldS, h.ldH).total;
     if (pl->lds_bytes[1] > 160 * 1024) { delete pl; return MMN_ERR_UNSUPPORTED; }
@@ -2357,6 +2997,12 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
         if (need <= 160 * 1024 &&
             (e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)) != hipSuccess)
             return fail(e);
+    }
+    if (pl->f8_ok) {
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd8), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)pl->f8_lds_fwd)) != hipSuccess) return fail(e);
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bwd8), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)pl->f8_lds_bwd)) != hipSuccess) return fail(e);
     }
     if (pl->par_ok) {
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_fwd_par), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2388,6 +3034,16 @@ static int check_batch(const mmn_plan* p, const mmn_batch* b) {
         if (!b->x[k] || b->ldx[k] < p->m.enc[e].n_features) return MMN_ERR_ARG;
     }
     return MMN_OK;
+}
+
+// the 8-wave tier additionally needs 16-byte aligned feature rows in this batch
+static bool use_fast8(const mmn_plan* p, const mmn_batch* b) {
+    if (!p->f8_ok) return false;
+    for (int t = 0; t < b->n_seq; ++t) {
+        const int k = b->seq_data[t];
+        if ((b->ldx[k] & 3) != 0 || (reinterpret_cast<uintptr_t>(b->x[k]) & 15) != 0) return false;
+    }
+    return true;
 }
 
 static int rt_for(const mmn_plan* p, const mmn_batch* b) {
@@ -2430,7 +3086,8 @@ int mmn_chain_fwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float sc_p
     const float cL = err_penalty / ((float)p->m.n_decoders * (float)(p->m.n_encoders + 1) * (float)b->batch_global);
     mmn_batch bb = *b;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (p->par_ok) hipLaunchKernelGGL(k_chain_fwd_par, dim3(tiles), dim3(NT), p->par_lds_fwd, st, p->dev, bb, cL, want_grads);
+    if (use_fast8(p, b)) hipLaunchKernelGGL(k_fwd8, dim3(tiles), dim3(NT8), p->f8_lds_fwd, st, p->pa, bb, cL, want_grads);
+    else if (p->par_ok) hipLaunchKernelGGL(k_chain_fwd_par, dim3(tiles), dim3(NT), p->par_lds_fwd, st, p->dev, bb, cL, want_grads);
     else if (rt == 1) hipLaunchKernelGGL(k_chain_fwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cL, want_grads);
     else hipLaunchKernelGGL(k_chain_fwd<2>, dim3(tiles), dim3(NT), p->lds_bytes[2], st, p->dev, bb, cL, want_grads);
     HIP_TRY(hipGetLastError());
@@ -2449,7 +3106,8 @@ int mmn_chain_bwd(mmn_plan* p, const mmn_batch* b, float sc_pen_x001, void* stre
     mmn_batch bb = *b;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float cS = sc_coeff(p, b, sc_pen_x001);
-    if (p->par_ok) hipLaunchKernelGGL(k_chain_bwd_par, dim3(tiles), dim3(NT), p->par_lds_bwd, st, p->dev, bb, cS);
+    if (use_fast8(p, b)) hipLaunchKernelGGL(k_bwd8, dim3(tiles), dim3(NT8), p->f8_lds_bwd, st, p->pa, bb, cS);
+    else if (p->par_ok) hipLaunchKernelGGL(k_chain_bwd_par, dim3(tiles), dim3(NT), p->par_lds_bwd, st, p->dev, bb, cS);
     else if (rt == 1) hipLaunchKernelGGL(k_chain_bwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cS);
     else hipLaunchKernelGGL(k_chain_bwd<2>, dim3(tiles), dim3(NT), p->lds_bytes[2], st, p->dev, bb, cS);
     HIP_TRY(hipGetLastError());

@@ -1763,18 +1763,31 @@ __global__ __launch_bounds__(NT8) void k_fwd8(const ParArgs a, const mmn_batch b
     const int ntS = (S + 15) >> 4, T0 = a.S16 >> 4;
     // decoder fragments: wave r evaluates state row r (R <= 8)
     f32x4 wd[8];
+    {
+        const bool rowok = i < 2 * D;
+        const float* w = a.dec_w[rowok ? (i >> 1) : 0] + (rowok ? (i & 1) * S : 0);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (wave < R && j < T0 && i < 2 * D) {
-            const float* w = a.dec_w[i >> 1] + (i & 1) * S;
+        for (int j = 0; j < 8; ++j) {                      // clamped address + select: no branch around a load
             const int k = 16 * j + 4 * q;
-            if (k < S) v.x = g_ld(w + k);
-            if (k + 1 < S) v.y = g_ld(w + k + 1);
-            if (k + 2 < S) v.z = g_ld(w + k + 2);
-            if (k + 3 < S) v.w = g_ld(w + k + 3);
+            const bool ok = rowok && k < S && j < T0;
+            const f32x4 v = g_ld4(w + (ok ? k : 0));
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            wd[j] = ok ? v : z;
         }
-        wd[j] = v;
+    }
+    // targets / decoder biases of this thread's (row r, decoder d, batch row) triple, first pass
+    int y_pre = 0;
+    float bd0_pre = 0.f, bd1_pre = 0.f;
+    {
+        const int idx = threadIdx.x;
+        const bool valid = idx < R * D * TB;
+        const int r = valid ? idx / (D * TB) : 0;
+        const int rem = idx - r * D * TB;
+        const int d = valid ? rem / TB : 0, row = rem & (TB - 1);
+        const bool ok = valid && row < nrows;
+        y_pre = (int)*(const MMN_AS1 int64_t*)(b.y + (ok ? ((int64_t)row0 + row) * D + d : 0));
+        bd0_pre = g_ld(a.dec_b[d]);
+        bd1_pre = g_ld(a.dec_b[d] + 1);
     }
     // chain step 0's W_s fragments (tile = wave) land during phase A
     f32x4 wsA[8], wsB[8];
@@ -1967,10 +1980,10 @@ __global__ __launch_bounds__(NT8) void k_fwd8(const ParArgs a, const mmn_batch b
         int correct = 0, tp = 0, tn = 0, fp = 0, fn = 0;
         if (live) {
             const float* bd = a.dec_b[d];
-            const float za = g_ld(bd) + lds_ld(sZ + (r * TB + row) * 16 + 2 * d);
-            const float zb = g_ld(bd + 1) + lds_ld(sZ + (r * TB + row) * 16 + 2 * d + 1);
+            const float za = (base == 0 ? bd0_pre : g_ld(bd)) + lds_ld(sZ + (r * TB + row) * 16 + 2 * d);
+            const float zb = (base == 0 ? bd1_pre : g_ld(bd + 1)) + lds_ld(sZ + (r * TB + row) * 16 + 2 * d + 1);
             const int64_t grow = (int64_t)row0 + row;
-            const int y = (int)*(const MMN_AS1 int64_t*)(b.y + grow * D + d);
+            const int y = base == 0 ? y_pre : (int)*(const MMN_AS1 int64_t*)(b.y + grow * D + d);
             const float o0 = 1.0f / (1.0f + expf(-za));
             const float o1 = 1.0f / (1.0f + expf(-zb));
             const float mx = fmaxf(o0, o1);
@@ -2025,13 +2038,13 @@ __global__ __launch_bounds__(NT8) void k_bwd8(const ParArgs a, const mmn_batch b
     const int g = wave >> 1, half = wave & 1;
     const lp DG = smem + L.sSt;          // decoder-grad tiles, then G_out tiles in place
     const lp Df = smem + L.sU;           // s_out - s_in per encoder
-    lp sG[2] = {smem + L.sG, smem + L.sG + TB * ldS};
     lp sHg[2] = {smem + L.sW + g * L.wstride + L.oH0, smem + L.sW + g * L.wstride + L.oH1};
     const lp sDzw = smem + L.sDz + wave * 16 * LDZ;
     const int ntS = (S + 15) >> 4, T0 = a.S16 >> 4;
-    // everything else is fully overwritten before it is read; the carried gradient starts at zero
-    for (int idx = threadIdx.x; idx < (a.needs_zero ? L.total : 2 * TB * ldS); idx += NT8)
-        lds_st((a.needs_zero ? smem : smem + L.sG) + idx, 0.f);
+    if (a.needs_zero) {
+        for (int idx = threadIdx.x; idx < L.total; idx += NT8) lds_st(smem + idx, 0.f);
+        __syncthreads();
+    }
     // first chain step's W_s^T fragments (tile = wave)
     f32x4 wcA[8], wcB[8];
     int t_last = b.n_seq - 1;
@@ -2040,78 +2053,92 @@ __global__ __launch_bounds__(NT8) void k_bwd8(const ParArgs a, const mmn_batch b
         const ParEnc& pe = a.enc[b.seq_enc[t_last]];
         issue_t<8>(wcA, a.pack + pe.pkb[pe.Lh], T0, ntS, wave, 0);
     }
-    if (a.needs_zero) __syncthreads();
 
-    // ---- phase A': decoder gradient of state row r (wave r), state differences (all waves)
+    // ---- phase A': wave r owns state row r: d_e = s_out - s_in (e = r - 1), then
+    //      DG[r] = dz[r] Wdec + cS d_e  (everything the chain adds to the carried gradient at row r)
     if (wave < R && row_executed(b, wave)) {
         const int r = wave;
-        for (int idx = lane; idx < TB * 16; idx += 64) {
+        const lp out = DG + r * TB * ldS;
+        // requests first, all branch-free
+        float dzr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = lane + 64 * k;
             const int row = idx >> 4, n = idx & 15;
-            float v = 0.f;
-            if (row < nrows && n < 2 * D) v = g_ld(a.dz + ((int64_t)r * a.maxB + row0 + row) * (2 * D) + n);
-            lds_st(sDzw + row * LDZ + n, v);
+            const bool ok = row < nrows && n < 2 * D;
+            const float v = g_ld(a.dz + (ok ? ((int64_t)r * a.maxB + row0 + row) * (2 * D) + n : 0));
+            dzr[k] = ok ? v : 0.f;
+        }
+        const int e = r - 1;
+        f32x4 so4[8], si4[8];
+        const int s4 = a.S16 >> 2;                          // float4 per state row (<= 32)
+        if (r >= 1) {
+            int prev_row = 0;
+            for (int u = 0, pr = 0; u < b.n_seq; ++u) {
+                if (!slot_present(b, b.seq_data[u])) continue;
+                if (b.seq_enc[u] == e) prev_row = pr;
+                pr = b.seq_enc[u] + 1;
+            }
+            const float* so = a.states + ((int64_t)e * a.maxB + row0) * S;
+            const float* si = prev_row ? a.states + ((int64_t)(prev_row - 1) * a.maxB + row0) * S : a.init;
+            const int64_t si_ld = prev_row ? S : 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int idx = lane + 64 * k;
+                const int row = idx / s4, c = (idx - row * s4) << 2;
+                const bool ok = idx < TB * s4 && row < nrows && c < S;
+                so4[k] = g_ld4(so + (ok ? (int64_t)row * S + c : 0));
+                si4[k] = g_ld4(si + (ok ? (int64_t)row * si_ld + c : 0));
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                if (!ok) { so4[k] = z; si4[k] = z; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = lane + 64 * k;
+            lds_st(sDzw + (idx >> 4) * LDZ + (idx & 15), dzr[k]);
+        }
+        const lp dd = Df + (r >= 1 ? e : 0) * TB * ldS;
+        if (r >= 1) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int idx = lane + 64 * k;
+                if (idx < TB * s4) lds_st4(dd + (idx / s4) * ldS + ((idx % s4) << 2), so4[k] - si4[k]);
+            }
         }
         const PB Bdz = make_pb(a.pack + a.pkd, S, 2 * D, 0);      // W' = Wdec^T [S x 2D]
-        const lp out = DG + r * TB * ldS;
         wave_layer(ASrc{sDzw, LDZ, sDzw, LDZ}, Bdz, 0, Bdz.T, [&](int row, int col, float v) {
-            if (col < S) lds_st(out + row * ldS + col, v);
+            if (col < S) lds_st(out + row * ldS + col, r >= 1 ? v + cS * lds_ld(dd + row * ldS + col) : v);
         });
-    }
-    for (int t = wave; t < b.n_seq; t += 8) {
-        if (!slot_present(b, b.seq_data[t])) continue;
-        const int e = b.seq_enc[t];
-        int prev_row = 0;
-        for (int u = 0, pr = 0; u < b.n_seq; ++u) {
-            if (!slot_present(b, b.seq_data[u])) continue;
-            if (b.seq_enc[u] == e) prev_row = pr;
-            pr = b.seq_enc[u] + 1;
-        }
-        const float* so = a.states + ((int64_t)e * a.maxB + row0) * S;
-        const float* si = prev_row ? a.states + ((int64_t)(prev_row - 1) * a.maxB + row0) * S : nullptr;
-        const lp dd = Df + e * TB * ldS;
-        for (int rr = 0; rr < TB; ++rr)
-            for (int c = lane; c < S; c += 64) {
-                float v = 0.f;
-                if (rr < nrows) {
-                    const float x0 = g_ld(so + (int64_t)rr * S + c);
-                    const float x1 = si ? g_ld(si + (int64_t)rr * S + c) : g_ld(a.init + c);
-                    v = x0 - x1;
-                }
-                lds_st(dd + rr * ldS + c, v);
-            }
     }
     __syncthreads();
 
-    // ---- phase B': G_out(e) = carry + DG[e+1] + cS d_e ;  carry' = G_out W_s - cS d_e
-    int cur = 0;
-    auto chain_step = [&](f32x4 (&wc)[8], f32x4 (&wn)[8], int t, int t_prv) {
-        const int e = b.seq_enc[t];
-        const lp Go = DG + (e + 1) * TB * ldS;
-        const clp dd = Df + e * TB * ldS;
-        const clp G = sG[cur];
-        const lp Gn = sG[cur ^ 1];
-        for (int rr = wave; rr < TB; rr += 8)
-            for (int c = lane; c < S; c += 64)
-                lds_st(Go + rr * ldS + c, lds_ld(G + rr * ldS + c) + lds_ld(Go + rr * ldS + c) + cS * lds_ld(dd + rr * ldS + c));
-        __syncthreads();
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (wave < ntS) consume_t<8>(acc, Go, ldS, 0, wc, 0, T0);
-        if (t_prv >= 0 && wave < ntS) {
-            const ParEnc& p2 = a.enc[b.seq_enc[t_prv]];
-            issue_t<8>(wn, a.pack + p2.pkb[p2.Lh], T0, ntS, wave, 0);
-        }
-        const int col = 16 * wave + i;
-        if (wave < ntS && col < S) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int row = 4 * q + k;
-                lds_st(Gn + row * ldS + col, acc[k] - cS * lds_ld(dd + row * ldS + col));
-            }
-        }
-        __syncthreads();
-        cur ^= 1;
-    };
+    // ---- phase B': carry' = G_out W_s - cS d_e, and the NEXT row's G_out is formed in the same
+    //      epilogue (in place, in DG): one barrier per chain step
     {
+        auto chain_step = [&](f32x4 (&wc)[8], f32x4 (&wn)[8], int t, int t_prv) {
+            const int e = b.seq_enc[t];
+            const clp Go = DG + (e + 1) * TB * ldS;
+            const clp dd = Df + e * TB * ldS;
+            const int r_nxt = t_prv >= 0 ? b.seq_enc[t_prv] + 1 : 0;
+            const lp Gx = DG + r_nxt * TB * ldS;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (wave < ntS) consume_t<8>(acc, Go, ldS, 0, wc, 0, T0);
+            if (t_prv >= 0 && wave < ntS) {
+                const ParEnc& p2 = a.enc[b.seq_enc[t_prv]];
+                issue_t<8>(wn, a.pack + p2.pkb[p2.Lh], T0, ntS, wave, 0);
+            }
+            const int col = 16 * wave + i;
+            if (wave < ntS && col < S) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = 4 * q + k;
+                    const float carry = acc[k] - cS * lds_ld(dd + row * ldS + col);
+                    lds_st(Gx + row * ldS + col, lds_ld(Gx + row * ldS + col) + carry);
+                }
+            }
+            __syncthreads();
+        };
         bool flip = false;
         for (int t = t_last; t >= 0;) {
             int t_prv = t - 1;
@@ -2121,13 +2148,7 @@ __global__ __launch_bounds__(NT8) void k_bwd8(const ParArgs a, const mmn_batch b
             t = t_prv;
         }
     }
-    {   // row 0: dS0 = carry + DG[0]
-        const clp G = sG[cur];
-        for (int rr = wave; rr < TB; rr += 8)
-            for (int c = lane; c < S; c += 64) lds_st(DG + rr * ldS + c, lds_ld(G + rr * ldS + c) + lds_ld(DG + rr * ldS + c));
-    }
-    __syncthreads();
-    // ---- stores: dS[e] = G_out(e), dS[E] = dS0 (final since the barrier above); fire and forget
+    // ---- stores: dS[e] = G_out(e), dS[E] = dS0 (final since the last barrier); fire and forget
     for (int r = 0; r < R; ++r) {
         if (!row_executed(b, r)) continue;
         const int idx = r == 0 ? E : r - 1;
@@ -2935,7 +2956,7 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     {   // ---- 8-wave fast tier: eligibility + kernel-argument descriptor
         ParArgs& a = pl->pa;
         memset(&a, 0, sizeof(a));
-        bool ok = pl->par_ok && h.E <= 8 && h.D <= MMN_MAX_DECODERS && h.S <= 128;
+        bool ok = pl->par_ok && h.E <= 8 && h.D <= MMN_MAX_DECODERS && h.S <= 128 && (h.S % 4) == 0;
         bool aligned16 = (h.S % 16) == 0;
         for (int e = 0; e < h.E && ok; ++e) {
             const mmn_encoder& enc = m->enc[e];

@@ -413,15 +413,26 @@ __global__ __launch_bounds__(NT) void k_prepare(const DevPlan* __restrict__ P, m
         if (__any(bad) && (threadIdx.x & 63) == 0) const_cast<int32_t*>(b.nan_flags)[slot] = 1;
         return;
     }
-    // ---- repack: one thread per pack element
+    // ---- repack: one thread per pack element; the task table is read into LDS once per block
+    // (searching it in global memory was ~6 dependent round trips per thread)
+    constexpr int MAXPT = 2 * MMN_MAX_ENCODERS * MMN_MAX_LAYERS + MMN_MAX_ENCODERS + MMN_MAX_DECODERS;
+    __shared__ PackTask stk[MAXPT];
+    const int npt = min(p.n_ptasks, MAXPT);
+    {
+        const int nw = npt * (int)(sizeof(PackTask) / 4);
+        const int32_t* src = reinterpret_cast<const int32_t*>(p.ptasks);
+        int32_t* dst = reinterpret_cast<int32_t*>(stk);
+        for (int k = threadIdx.x; k < nw; k += NT) dst[k] = src[k];
+    }
+    __syncthreads();
     const int64_t g = (int64_t)(blockIdx.x - scan_blocks) * NT + threadIdx.x;
     if (g >= p.n_pack_elems) return;
-    int lo = 0, hi = p.n_ptasks - 1;
+    int lo = 0, hi = npt - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (p.ptasks[mid].start <= g) lo = mid; else hi = mid - 1;
+        if (stk[mid].start <= g) lo = mid; else hi = mid - 1;
     }
-    const PackTask tk = p.ptasks[lo];
+    const PackTask tk = stk[lo];
     const int local = (int)(g - tk.start);
     const int c = local & 3, lane = (local >> 2) & 63, ft = local >> 8;
     const int ct = ft / tk.T, t = ft - ct * tk.T;
@@ -2333,7 +2344,7 @@ __device__ __forceinline__ void wgrad_tile(const DevPlan& p, const WTask& tk, co
 
     auto run = [&](auto fast_tag) {
         constexpr bool FA = decltype(fast_tag)::value;
-        constexpr int DEPTH = 4;                          // k-steps (4 rows each) in flight
+        constexpr int DEPTH = (MT * NTL >= 16) ? 6 : 8;   // k-steps (4 rows each) in flight
         float a[DEPTH][MT], bb[DEPTH][NTL];
         auto ld = [&](float (&av)[MT], float (&bv)[NTL], int r) {
             const int row = r + q;
@@ -2475,54 +2486,68 @@ __device__ __forceinline__ void epoch_accumulate_block(const DevPlan& p, float a
     for (int r = threadIdx.x; r < R; r += NT) ep[RD + E + 5 * RD + r] += (double)st[RD + E + 5 * RD + r];
 }
 
-__global__ __launch_bounds__(NT) void k_reduce(const DevPlan* __restrict__ P, int batch, int batch_global,
-                                               int n_tiles, int grad_blocks, int want_grads, int accumulate,
-                                               float alpha, float beta, int32_t* nan_flags) {
+constexpr int NTR = 1024;     // k_reduce block size
+constexpr int MAXSEG = 2 * MMN_MAX_ENCODERS * MMN_MAX_LAYERS + 1 + 2 * MMN_MAX_DECODERS;
+
+__global__ __launch_bounds__(NTR) void k_reduce(const DevPlan* __restrict__ P, int batch, int batch_global,
+                                                int n_tiles, int grad_blocks, int want_grads, int accumulate,
+                                                float alpha, float beta, int32_t* nan_flags) {
     const DevPlan& p = *P;
     if ((int)blockIdx.x < grad_blocks) {
         if (!want_grads) return;
-        // segment starts into LDS once (the binary search was 6 dependent global round trips)
-        __shared__ long long sstart[320];   // >= 1 + 2*16*8 + 2*8 segments
-        const int nseg = min(p.n_segs, 320);
-        for (int k = threadIdx.x; k < nseg; k += NT) sstart[k] = p.segs[k].start;
+        // the segment table goes to LDS once per block: no dependent global reads before the partials
+        __shared__ Seg sseg[MAXSEG];
+        const int nseg = min(p.n_segs, MAXSEG);
+        {
+            const int nw = nseg * (int)(sizeof(Seg) / 4);
+            const int32_t* src = reinterpret_cast<const int32_t*>(p.segs);
+            int32_t* dst = reinterpret_cast<int32_t*>(sseg);
+            for (int k = threadIdx.x; k < nw; k += NTR) dst[k] = src[k];
+        }
         __syncthreads();
-        const int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x;
+        const int64_t idx = (int64_t)blockIdx.x * NTR + threadIdx.x;
         if (idx >= p.n_grad_elems) return;
         int lo = 0, hi = nseg - 1;
         while (lo < hi) {                                   // last segment with start <= idx
             const int mid = (lo + hi + 1) >> 1;
-            if (sstart[mid] <= idx) lo = mid; else hi = mid - 1;
+            if (sseg[mid].start <= idx) lo = mid; else hi = mid - 1;
         }
-        const Seg sg = p.segs[lo];
+        const Seg sg = sseg[lo];
         const int local = (int)(idx - sg.start);
         const int m = local / sg.kdiv, n = local - m * sg.kdiv;
         const float* src = p.slabs + sg.slab_base + (int64_t)(sg.row_off + m) * sg.ntot + n + sg.coff;
         float sum = 0.f;
         int k = 0;
-        for (; k + 8 <= sg.n_partials; k += 8) {            // 8 independent loads in flight, fixed order
-            float v[8];
+        for (; k + 16 <= sg.n_partials; k += 16) {          // 16 independent loads in flight, fixed order
+            float v[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = g_ld(src + (int64_t)(k + j) * sg.pstride);
+            for (int j = 0; j < 16; ++j) v[j] = g_ld(src + (int64_t)(k + j) * sg.pstride);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sum += v[j];
+            for (int j = 0; j < 16; ++j) sum += v[j];
+        }
+        for (; k + 4 <= sg.n_partials; k += 4) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = g_ld(src + (int64_t)(k + j) * sg.pstride);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += v[j];
         }
         for (; k < sg.n_partials; ++k) sum += g_ld(src + (int64_t)k * sg.pstride);
         g_st(sg.dst + local, sum);
         return;
     }
-    // stats block.  Float partials (loss cells, state change): 8 threads per quantity sum disjoint
-    // tile chunks with independent loads, then a fixed-order 8-way sum.  Integer counters were
-    // accumulated with atomics by k_chain_fwd: read, publish, re-zero.
+    // stats block: 8 threads per quantity (loss cells, state change, 5 counters per cell) sum
+    // disjoint tile chunks with independent loads, then a fixed-order 8-way sum
     const int R = p.R, D = p.D, E = p.E, S = p.S;
     const int RD = R * D;
     float* st = p.stats;
     const float Bg = (float)batch_global;
-    __shared__ float spart[32][8];
-    const int nfq = RD + E;
-    for (int qb = 0; qb < nfq; qb += 32) {
+    __shared__ float spart[NTR / 8][8];
+    const int nq = RD + E + 5 * RD;
+    for (int qb = 0; qb < nq; qb += NTR / 8) {
         const int qd = qb + (threadIdx.x >> 3), ch = threadIdx.x & 7;
         float fs = 0.f;
-        if (qd < nfq) {
+        if (qd < nq) {
             const int per = (n_tiles + 7) >> 3;
             const int t0 = ch * per, t1 = min(n_tiles, t0 + per);
             if (qd < RD) {
@@ -2530,51 +2555,39 @@ __global__ __launch_bounds__(NT) void k_reduce(const DevPlan* __restrict__ P, in
 #pragma unroll 8
                     for (int t = t0; t < t1; ++t) fs += g_ld(p.lossp + (int64_t)t * RD + qd);
                 }
-            } else {
+            } else if (qd < RD + E) {
                 const int e = qd - RD;
                 if (p.exec_flags[e + 1]) {
 #pragma unroll 8
                     for (int t = t0; t < t1; ++t) fs += g_ld(p.scp + (int64_t)t * E + e);
                 }
+            } else {
+                const int c = qd - RD - E;
+                const int k = c / RD, cell = c - k * RD;
+                if (p.exec_flags[cell / D]) {
+                    const int32_t* src = p.cnt + (int64_t)cell * 5 + k;
+                    int v = 0;
+#pragma unroll 8
+                    for (int t = t0; t < t1; ++t) v += g_ldi(src + (int64_t)t * RD * 5);
+                    fs = (float)v;                          // exact: per-chunk counts are far below 2^24
+                }
             }
         }
         spart[threadIdx.x >> 3][ch] = fs;
         __syncthreads();
-        if (qd < nfq && ch == 0) {
+        if (qd < nq && ch == 0) {
             const float* sp = spart[threadIdx.x >> 3];
             const float tot = (((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7])));
-            st[qd] = qd < RD ? tot / Bg : tot / (Bg * (float)S);
+            st[qd] = qd < RD ? tot / Bg : (qd < RD + E ? tot / (Bg * (float)S) : tot);
         }
         __syncthreads();
     }
-    __shared__ int ipart[32][8];
-    for (int qb = 0; qb < 5 * RD; qb += 32) {
-        const int c = qb + (threadIdx.x >> 3), ch = threadIdx.x & 7;
-        int v = 0;
-        if (c < 5 * RD) {
-            const int k = c / RD, cell = c - k * RD;
-            const int per = (n_tiles + 7) >> 3;
-            const int t0 = ch * per, t1 = min(n_tiles, t0 + per);
-            if (p.exec_flags[cell / D]) {
-                const int32_t* src = p.cnt + (int64_t)cell * 5 + k;
-#pragma unroll 8
-                for (int t = t0; t < t1; ++t) v += g_ldi(src + (int64_t)t * RD * 5);
-            }
-        }
-        ipart[threadIdx.x >> 3][ch] = v;
-        __syncthreads();
-        if (c < 5 * RD && ch == 0) {
-            const int* ip = ipart[threadIdx.x >> 3];
-            st[RD + E + c] = (float)(ip[0] + ip[1] + ip[2] + ip[3] + ip[4] + ip[5] + ip[6] + ip[7]);
-        }
-        __syncthreads();
-    }
-    for (int r = threadIdx.x; r < R; r += NT) st[RD + E + 5 * RD + r] = p.exec_flags[r] ? (float)batch : 0.f;
+    for (int r = threadIdx.x; r < R; r += NTR) st[RD + E + 5 * RD + r] = p.exec_flags[r] ? (float)batch : 0.f;
     if (nan_flags && threadIdx.x < MMN_MAX_ENCODERS) nan_flags[threadIdx.x] = 0;
     if (accumulate) {
         __threadfence_block();
         __syncthreads();
-        epoch_accumulate_block(p, alpha, beta);
+        if (threadIdx.x < NT) epoch_accumulate_block(p, alpha, beta);
     }
 }
 
@@ -2656,7 +2669,7 @@ int pick_width(int n) { return n >= 64 ? 4 : (n >= 32 ? 2 : 1); }
 void build_layout(const mmn_model& m, int maxB, Layout& L) {
     const int S = m.state_size, E = m.n_encoders, D = m.n_decoders, R = E + 1;
     L.max_tiles = (maxB + 15) / 16;
-    int ks = (maxB + 255) / 256;
+    int ks = (maxB + 511) / 512;            // row-range splits: 512 rows per workgroup, 128 per wave
     if (ks < 1) ks = 1;
     if (ks > 16) ks = 16;
     L.KS = ks;
@@ -2935,7 +2948,7 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     h.n_pack_elems = L.pack_elems;
     for (PackTask& t : L.ptasks) t.dst = h.pack + reinterpret_cast<intptr_t>(t.dst);   // offset -> address
     pl->dev = reinterpret_cast<DevPlan*>(ws + L.off_plan);
-    pl->grad_blocks = (int)((L.n_grad_elems + NT - 1) / NT);
+    pl->grad_blocks = (int)((L.n_grad_elems + NTR - 1) / NTR);
     {
         int maxF = 1;
         bool ok = h.S <= 128;
@@ -3151,7 +3164,7 @@ static int launch_reduce(mmn_plan* p, const mmn_batch* b, int want_grads, int ac
                          void* stream) {
     const int rt = rt_for(p, b);
     const int tiles = (b->batch + 16 * rt - 1) / (16 * rt);
-    hipLaunchKernelGGL(k_reduce, dim3(p->grad_blocks + 1), dim3(NT), 0, static_cast<hipStream_t>(stream), p->dev, b->batch,
+    hipLaunchKernelGGL(k_reduce, dim3(p->grad_blocks + 1), dim3(NTR), 0, static_cast<hipStream_t>(stream), p->dev, b->batch,
                        b->batch_global, tiles, p->grad_blocks, want_grads, accumulate, alpha, beta,
                        const_cast<int32_t*>(b->nan_flags));
     HIP_TRY(hipGetLastError());

@@ -155,6 +155,12 @@ int mmn_prepare(mmn_plan* p, const mmn_batch* b, int want_grads, void* stream);
 /* (a) alone. */
 int mmn_nan_scan(mmn_plan* p, const mmn_batch* b, void* stream);
 
+/* Which device kernel mmn_chain_fwd (backward = 0) / mmn_chain_bwd (backward = 1) launches for this
+ * plan and batch: "k_fwd8"/"k_bwd8" (8-wave tier for MIMIC-like shapes), "k_chain_fwd_par"/
+ * "k_chain_bwd_par" (4-wave parallel-phase tier) or "k_chain_fwd"/"k_chain_bwd" (any shape).  For
+ * matching rocprof rows. */
+const char* mmn_chain_kernel_name(mmn_plan* p, const mmn_batch* b, int backward);
+
 /* Forward chain, one launch: init-state broadcast (state.py:29-32), every executed encoder
  * (mlp_encoder.py:74-80), state-change partials (multimodn.py:174), all D decoders on all E+1
  * states with CrossEntropy-over-sigmoids, argmax and confusion counts (decoders.py:19-20,

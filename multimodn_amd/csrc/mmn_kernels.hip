@@ -3087,6 +3087,13 @@ static int rt_for(const mmn_plan* p, const mmn_batch* b) {
     return rt;
 }
 
+const char* mmn_chain_kernel_name(mmn_plan* p, const mmn_batch* b, int backward) {
+    if (!p || !b) return "";
+    if (use_fast8(p, b)) return backward ? "k_bwd8" : "k_fwd8";
+    if (p->par_ok) return backward ? "k_chain_bwd_par" : "k_chain_fwd_par";
+    return backward ? "k_chain_bwd" : "k_chain_fwd";
+}
+
 int mmn_prepare(mmn_plan* p, const mmn_batch* b, int want_grads, void* stream) {
     int rc = check_batch(p, b);
     if (rc != MMN_OK) return rc;

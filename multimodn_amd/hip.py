@@ -26,7 +26,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 ABI_SYMBOLS = (
     "mmn_version", "mmn_error_string", "mmn_last_hip_error", "mmn_stats_floats", "mmn_epoch_doubles",
     "mmn_workspace_bytes", "mmn_plan_create", "mmn_plan_destroy", "mmn_nan_flags", "mmn_prepare",
-    "mmn_nan_scan", "mmn_chain_fwd",
+    "mmn_nan_scan", "mmn_chain_kernel_name", "mmn_chain_fwd",
     "mmn_chain_bwd", "mmn_wgrad", "mmn_reduce", "mmn_epoch_accumulate", "mmn_train_step",
     "mmn_eval_step", "mmn_epoch_reset", "mmn_epoch_read", "mmn_debug_buffer",
 )
@@ -103,6 +103,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_prepare.argtypes = [vp, C.POINTER(Batch), i32, vp]
     lib.mmn_nan_scan.restype = i32
     lib.mmn_nan_scan.argtypes = [vp, C.POINTER(Batch), vp]
+    lib.mmn_chain_kernel_name.restype = C.c_char_p
+    lib.mmn_chain_kernel_name.argtypes = [vp, C.POINTER(Batch), i32]
     lib.mmn_chain_fwd.restype = i32
     lib.mmn_chain_fwd.argtypes = [vp, C.POINTER(Batch), f32, f32, i32, vp]
     lib.mmn_chain_bwd.restype = i32

@@ -1,8 +1,8 @@
 """Diagnostic: per-phase timestamps of one k_chain_fwd workgroup (MMN_STAMPS=1)."""
 import os, sys
 os.environ["MMN_STAMPS"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import multimodn_amd as mm
 from helpers import build_torch_model

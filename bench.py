@@ -192,13 +192,15 @@ def main():
     b0 = batches[0]
     fwd_name = lib.mmn_chain_kernel_name(plan, C.byref(b0), 0).decode()
     bwd_name = lib.mmn_chain_kernel_name(plan, C.byref(b0), 1).decode()
-    kern = {
-        "k_prepare": lambda b: lib.mmn_prepare(plan, C.byref(b), 1, stream),
-        fwd_name: lambda b: lib.mmn_chain_fwd(plan, C.byref(b), alpha, beta, 1, stream),
-        bwd_name: lambda b: lib.mmn_chain_bwd(plan, C.byref(b), beta, stream),
-        "k_wgrad": lambda b: lib.mmn_wgrad(plan, C.byref(b), stream),
-        "k_reduce": lambda b: lib.mmn_reduce(plan, C.byref(b), stream),
-    }
+    fused_name = lib.mmn_chain_kernel_name(plan, C.byref(b0), 2).decode()
+    kern = {"k_prepare": lambda b: lib.mmn_prepare(plan, C.byref(b), 1, stream)}
+    if fused_name:        # forward + backward chain in one launch (what mmn_train_step uses)
+        kern[fused_name] = lambda b: lib.mmn_chain_fwd_bwd(plan, C.byref(b), alpha, beta, stream)
+    else:
+        kern[fwd_name] = lambda b: lib.mmn_chain_fwd(plan, C.byref(b), alpha, beta, 1, stream)
+        kern[bwd_name] = lambda b: lib.mmn_chain_bwd(plan, C.byref(b), beta, stream)
+    kern["k_wgrad"] = lambda b: lib.mmn_wgrad(plan, C.byref(b), stream)
+    kern["k_reduce"] = lambda b: lib.mmn_reduce(plan, C.byref(b), stream)
     REP, ROUNDS = 20, 5
     avg_us = {}
     for name, fn in kern.items():
@@ -215,7 +217,10 @@ def main():
             times.append(e0.elapsed_time(e1) * 1e3 / REP)
         avg_us[name] = float(np.median(times))
     flp = flops_per_sample(spec)
-    fl = {fwd_name: flp["k_chain_fwd"], bwd_name: flp["k_chain_bwd"], "k_wgrad": flp["k_wgrad"]}
+    if fused_name:
+        fl = {fused_name: flp["k_chain_fwd"] + flp["k_chain_bwd"], "k_wgrad": flp["k_wgrad"]}
+    else:
+        fl = {fwd_name: flp["k_chain_fwd"], bwd_name: flp["k_chain_bwd"], "k_wgrad": flp["k_wgrad"]}
     dominant = max(fl, key=lambda k: avg_us[k])
     achieved = fl[dominant] * B / (avg_us[dominant] * 1e-6) / 1e12
     traffic = None

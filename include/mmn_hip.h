@@ -158,7 +158,7 @@ int mmn_nan_scan(mmn_plan* p, const mmn_batch* b, void* stream);
 /* Which device kernel mmn_chain_fwd (backward = 0) / mmn_chain_bwd (backward = 1) launches for this
  * plan and batch: "k_fwd8"/"k_bwd8" (8-wave tier for MIMIC-like shapes), "k_chain_fwd_par"/
  * "k_chain_bwd_par" (4-wave parallel-phase tier) or "k_chain_fwd"/"k_chain_bwd" (any shape).  For
- * matching rocprof rows. */
+ * matching rocprof rows.  backward = 2 asks for the fused forward+backward kernel ("k_fb8" or ""). */
 const char* mmn_chain_kernel_name(mmn_plan* p, const mmn_batch* b, int backward);
 
 /* Forward chain, one launch: init-state broadcast (state.py:29-32), every executed encoder
@@ -170,6 +170,12 @@ int mmn_chain_fwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float stat
 
 /* Reverse chain (the activation-gradient half of loss.backward(), multimodn.py:203). */
 int mmn_chain_bwd(mmn_plan* p, const mmn_batch* b, float state_change_penalty_x001, void* stream);
+
+/* Forward + reverse chain.  ONE launch (k_fb8) when the 8-wave tier applies and E <= 4: the state
+ * tiles, dz and hidden activations then stay in LDS between the two halves; otherwise the two
+ * launches above.  (mmn_chain_kernel_name(p, b, 2) names the fused kernel, "" if it does not apply.) */
+int mmn_chain_fwd_bwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float state_change_penalty_x001,
+                      void* stream);
 
 /* Weight/bias/init-state gradients as split-K partial slabs (the other half of :203). */
 int mmn_wgrad(mmn_plan* p, const mmn_batch* b, void* stream);

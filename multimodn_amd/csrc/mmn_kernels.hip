@@ -2247,6 +2247,494 @@ __global__ __launch_bounds__(NT8) void k_bwd8(const ParArgs a, const mmn_batch b
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_fb8: forward AND backward chain of one 16-row tile in ONE launch (8-wave tier, E <= 4).
+// The backward chain of a row tile only needs that tile's own forward results, so the state
+// tiles, dz and the hidden activations never leave LDS between the two halves: no second kernel
+// prologue, no global round trip for states / dz / hid, act' fused into the GEMM epilogues.
+// Global stores of states / hid / dz / dS / dpre remain (k_wgrad consumes them), fire and forget.
+// ------------------------------------------------------------------------------------------------
+struct Fb8Lds { int sSt, sU, sW, wstride, oX, oH0, oH1, sDzA, sZ, sRed, total; };
+__host__ __device__ inline Fb8Lds fb8_lds(int R, int ldS, int ldH, int ldX) {
+    Fb8Lds L;
+    int o = 0;
+    L.sSt = o; o += R * 16 * ldS;          // state tiles 0..E (live for the whole kernel)
+    L.sU = o; o += R * 16 * ldS;           // forward: u_e tiles; backward: DG -> G_out tiles
+    L.oX = 0; L.oH0 = 16 * ldX; L.oH1 = L.oH0 + 16 * ldH;
+    L.wstride = L.oH1 + 16 * ldH;
+    L.sW = o; o += 4 * L.wstride;          // per wave pair: x tile, h0, h1 (kept for the backward half)
+    L.sDzA = o; o += R * 16 * LDZ;         // dz tiles of all rows
+    L.sZ = o; o += R * 16 * 16;
+    L.sRed = o; o += 8 * 8 + 16;
+    L.total = o;
+    return L;
+}
+
+__device__ __forceinline__ int prev_row_of(const mmn_batch& b, int e) {
+    int prev_row = 0;
+    for (int u = 0, pr = 0; u < b.n_seq; ++u) {
+        if (!slot_present(b, b.seq_data[u])) continue;
+        if (b.seq_enc[u] == e) prev_row = pr;
+        pr = b.seq_enc[u] + 1;
+    }
+    return prev_row;
+}
+
+__global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b, float cL, float cS) {
+    constexpr int TB = 16;
+    constexpr int want_grads = 1;
+    extern __shared__ __attribute__((aligned(16))) float smem_generic[];
+    const lp smem = (lp)smem_generic;
+    const int S = a.S, E = a.E, D = a.D, R = a.R, ldS = a.ldS, ldH = a.ldH, ldX = a.ldX;
+    const Fb8Lds L = fb8_lds(R, ldS, ldH, ldX);
+    const lp sDzA = smem + L.sDzA;
+    const int tile = blockIdx.x, row0 = tile * TB;
+    const int nrows = min(TB, b.batch - row0);
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int i = lane & 15, q = lane >> 4;
+    const int g = wave >> 1, half = wave & 1;
+    const lp St = smem + L.sSt;
+    const lp Ut = smem + L.sU;
+    const lp sZ = smem + L.sZ;
+    const lp sRed = smem + L.sRed;
+    const lp sXg = smem + L.sW + g * L.wstride + L.oX;
+    lp sHg[2] = {smem + L.sW + g * L.wstride + L.oH0, smem + L.sW + g * L.wstride + L.oH1};
+    int stamp_k = 0;
+    const int stamp_block = 7;
+    STAMP8();
+    if (a.needs_zero) {                                    // K-padding columns must be finite
+        for (int idx = threadIdx.x; idx < L.total; idx += NT8) lds_st(smem + idx, 0.f);
+        __syncthreads();
+    } else {                                               // dz tiles: unwritten entries must read as zero
+        for (int idx = threadIdx.x; idx < R * 16 * LDZ; idx += NT8) lds_st(sDzA + idx, 0.f);
+    }
+    for (int r = wave; r < TB; r += 8)                     // state row 0 = init state (state.py:29-32)
+        for (int c = lane; c < S; c += 64) lds_st(St + r * ldS + c, g_ld(a.init + c));
+    if (tile == 0 && threadIdx.x == 0) {                   // which state rows exist this step
+        g_sti(a.exec_flags, 1);
+        for (int e = 0; e < E; ++e) g_sti(a.exec_flags + e + 1, 0);
+        int prev = 0;
+        for (int t = 0; t < b.n_seq; ++t) {
+            if (!slot_present(b, b.seq_data[t])) continue;
+            const int e = b.seq_enc[t];
+            g_sti(a.exec_flags + e + 1, 1);
+            g_sti(a.prev_row + e, prev);
+            prev = e + 1;
+        }
+    }
+    const int ntS = (S + 15) >> 4, T0 = a.S16 >> 4;
+    // decoder fragments: wave r evaluates state row r (R <= 8)
+    f32x4 wd[8];
+    {
+        const bool rowok = i < 2 * D;
+        const float* w = a.dec_w[rowok ? (i >> 1) : 0] + (rowok ? (i & 1) * S : 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                      // clamped address + select: no branch around a load
+            const int k = 16 * j + 4 * q;
+            const bool ok = rowok && k < S && j < T0;
+            const f32x4 v = g_ld4(w + (ok ? k : 0));
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            wd[j] = ok ? v : z;
+        }
+    }
+    // targets / decoder biases of this thread's (row r, decoder d, batch row) triple, first pass
+    int y_pre = 0;
+    float bd0_pre = 0.f, bd1_pre = 0.f;
+    {
+        const int idx = threadIdx.x;
+        const bool valid = idx < R * D * TB;
+        const int r = valid ? idx / (D * TB) : 0;
+        const int rem = idx - r * D * TB;
+        const int d = valid ? rem / TB : 0, row = rem & (TB - 1);
+        const bool ok = valid && row < nrows;
+        y_pre = (int)*(const MMN_AS1 int64_t*)(b.y + (ok ? ((int64_t)row0 + row) * D + d : 0));
+        bd0_pre = g_ld(a.dec_b[d]);
+        bd1_pre = g_ld(a.dec_b[d] + 1);
+    }
+    // chain step 0's W_s fragments (tile = wave) land during phase A
+    f32x4 wsA[8], wsB[8];
+    const int t_first = next_exec(b, 0);
+    if (t_first < b.n_seq && wave < ntS) {
+        const ParEnc& pe = a.enc[b.seq_enc[t_first]];
+        issue_t<8>(wsA, a.pack + pe.pkf[pe.Lh], T0 + ((pe.HL + 15) >> 4), ntS, wave, 0);
+    }
+    STAMP8();
+
+    // ---- phase A: u_e = W_x h_e + b for every executed encoder; wave pair g takes encoder t = tb + g
+    for (int tb = 0; tb < b.n_seq; tb += 4) {
+        const int t = tb + g;
+        const bool act = t < b.n_seq && slot_present(b, b.seq_data[min(t, b.n_seq - 1)]);
+        const int e = act ? b.seq_enc[t] : 0;
+        const ParEnc& pe = a.enc[e];
+        const int Lh = pe.Lh, F = pe.F, HL = pe.HL, akind = pe.akind;
+        int Lmax = 0;                                       // barrier count must be uniform over the workgroup
+        for (int k = 0; k < 4; ++k)
+            if (tb + k < b.n_seq && slot_present(b, b.seq_data[tb + k])) Lmax = max(Lmax, a.enc[b.seq_enc[tb + k]].Lh);
+        const int f4 = round_up(F, 16) >> 2;               // float4 per image row (<= 32)
+        const int TU = (HL + 15) >> 4;
+        const float* pkU = a.pack + pe.pkf[Lh];
+        // -- request everything this wave will consume in this round
+        f32x4 xr[4], h0q[8], h1q[2], uq[2][4][2];
+        float hb0 = 0.f, hb1 = 0.f, ub[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        if (act) {
+            const int slot = b.seq_data[t];
+            const float* xg = b.x[slot] + (int64_t)row0 * b.ldx[slot];
+            const int64_t ldx = b.ldx[slot];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                  // this half's 8 rows of the x tile
+                const int idx = lane + 64 * k;
+                const int row = 8 * half + idx / f4, c = (idx % f4) << 2;
+                const bool ok = idx < 8 * f4 && row < nrows && c < F;
+                const f32x4 v = g_ld4(xg + (ok ? (int64_t)row * ldx + c : 0));
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                xr[k] = ok ? v : z;
+            }
+            if (Lh >= 1) {
+                issue_t<8>(h0q, a.pack + pe.pkf[0], (pe.in[0] + 15) >> 4, (pe.out[0] + 15) >> 4, half, 0);
+                hb0 = g_ld(pe.bias[0] + min(16 * half + i, pe.out[0] - 1));
+            }
+            if (Lh >= 2) {
+                issue_t<2>(h1q, a.pack + pe.pkf[1], (pe.in[1] + 15) >> 4, (pe.out[1] + 15) >> 4, half, 0);
+                hb1 = g_ld(pe.bias[1] + min(16 * half + i, pe.out[1] - 1));
+            }
+            const PB BU = make_pb(pkU, S, S, HL);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int nn[2] = {16 * (4 * half + 2 * pr), 16 * (4 * half + 2 * pr + 1)};
+                if (nn[0] < S) {
+                    issue_b<4>(uq[pr], BU, nn, BU.T0);
+                    ub[pr][0] = g_ld(pe.bias[Lh] + min(nn[0] + i, S - 1));
+                    ub[pr][1] = g_ld(pe.bias[Lh] + min(nn[1] + i, S - 1));
+                }
+            }
+            // -- x -> the pair's LDS image
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = lane + 64 * k;
+                if (idx < 8 * f4) lds_st4(sXg + (8 * half + idx / f4) * ldX + ((idx % f4) << 2), xr[k]);
+            }
+        }
+        __syncthreads();
+        if (Lmax >= 1) {                                   // hidden layer 0 (mlp_encoder.py:75-76), tile = half
+            if (act && Lh >= 1 && 16 * half < pe.out[0]) {
+                const int N = pe.out[0], T = (pe.in[0] + 15) >> 4;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                consume_t<8>(acc, sXg, ldX, 0, h0q, 0, T);
+                const int col = 16 * half + i;
+                if (col < N) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) lds_st(sHg[0] + (4 * q + k) * ldH + col, act_fwd(acc[k] + hb0, akind));
+                }
+            }
+            __syncthreads();
+            if (act && Lh >= 1 && want_grads) {            // each half stores 8 rows of the tile
+                const int N = pe.out[0];
+                const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
+                wave_store_tile(a.hid + pe.hid[0] + (int64_t)(row0 + r0) * N, sHg[0] + r0 * ldH, ldH, nr, N);
+            }
+        }
+        if (Lmax >= 2) {
+            if (act && Lh >= 2 && 16 * half < pe.out[1]) {
+                const int N = pe.out[1], T = (pe.in[1] + 15) >> 4;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                consume_t<2>(acc, sHg[0], ldH, 0, h1q, 0, T);
+                const int col = 16 * half + i;
+                if (col < N) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) lds_st(sHg[1] + (4 * q + k) * ldH + col, act_fwd(acc[k] + hb1, akind));
+                }
+            }
+            __syncthreads();
+            if (act && Lh >= 2 && want_grads) {
+                const int N = pe.out[1];
+                const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
+                wave_store_tile(a.hid + pe.hid[1] + (int64_t)(row0 + r0) * N, sHg[1] + r0 * ldH, ldH, nr, N);
+            }
+        }
+        if (act) {                                         // u_e = W_x h + b (mlp_encoder.py:78), this half's 4 tiles
+            clp in = Lh == 0 ? (clp)sXg : (clp)sHg[Lh - 1];
+            const int ldin = Lh == 0 ? ldX : ldH;
+            const lp U = Ut + e * TB * ldS;
+            const PB BU = make_pb(pkU, S, S, HL);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int nn[2] = {16 * (4 * half + 2 * pr), 16 * (4 * half + 2 * pr + 1)};
+                if (nn[0] < S) {
+                    f32x4 acc[2][1];
+                    zero_acc<1>(acc);
+                    consume_b<1, 4>(acc, ASrc{in, ldin, in, ldin}, BU, uq[pr], BU.T0, BU.T0 + TU, nn[1] < S);
+                    run_epilogue<1>(acc, nn, S, [&](int row, int col, int c, float v) {
+                        if (col < S) lds_st(U + row * ldS + col, v + ub[pr][c]);
+                    });
+                }
+            }
+        }
+        __syncthreads();                                    // scratch is reused by the next round
+    }
+    STAMP8();
+
+    // ---- phase B: s' = W_s s + u_e; one column tile per wave, fragments one step ahead
+    int cur = 0;
+    auto chain_step = [&](f32x4 (&wc)[8], f32x4 (&wn)[8], int t, int t_nxt) {
+        const int e = b.seq_enc[t];
+        const clp sC = St + cur * TB * ldS;
+        const lp sN = St + (e + 1) * TB * ldS;
+        const clp U = Ut + e * TB * ldS;
+        float scacc = 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (wave < ntS) consume_t<8>(acc, sC, ldS, 0, wc, 0, T0);
+        if (t_nxt < b.n_seq && wave < ntS) {
+            const ParEnc& p2 = a.enc[b.seq_enc[t_nxt]];
+            issue_t<8>(wn, a.pack + p2.pkf[p2.Lh], T0 + ((p2.HL + 15) >> 4), ntS, wave, 0);
+        }
+        const int col = 16 * wave + i;
+        if (wave < ntS && col < S) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = 4 * q + k;
+                const float ns = acc[k] + lds_ld(U + row * ldS + col);
+                const float dlt = ns - lds_ld(sC + row * ldS + col);
+                if (row < nrows) scacc += dlt * dlt;              // multimodn.py:174
+                lds_st(sN + row * ldS + col, ns);
+            }
+        }
+        scacc = wave_sum(scacc);
+        if (lane == 0) lds_st(sRed + 8 * e + wave, scacc);
+        __syncthreads();
+        if (want_grads) {                                   // each wave stores two rows of the new state tile
+            for (int r = wave; r < nrows; r += 8)
+                for (int c = lane * 4; c < S; c += 256) {
+                    if (((S & 3) == 0)) g_st4(a.states + ((int64_t)e * a.maxB + row0 + r) * S + c, lds_ld4(sN + r * ldS + c));
+                    else for (int k = 0; k < 4 && c + k < S; ++k) g_st(a.states + ((int64_t)e * a.maxB + row0 + r) * S + c + k, lds_ld(sN + r * ldS + c + k));
+                }
+        }
+        cur = e + 1;
+    };
+    {
+        bool flip = false;
+        for (int t = t_first; t < b.n_seq;) {
+            const int t_nxt = next_exec(b, t + 1);
+            if (!flip) chain_step(wsA, wsB, t, t_nxt); else chain_step(wsB, wsA, t, t_nxt);
+            flip = !flip;
+            t = t_nxt;
+        }
+    }
+    STAMP8();
+    // backward chain, first step: W_s^T fragments (tile = wave) land during the decoder grid
+    f32x4 wcA[8], wcB[8];
+    int t_last = b.n_seq - 1;
+    while (t_last >= 0 && !slot_present(b, b.seq_data[t_last])) --t_last;
+    if (t_last >= 0 && wave < ntS) {
+        const ParEnc& pe = a.enc[b.seq_enc[t_last]];
+        issue_t<8>(wcA, a.pack + pe.pkb[pe.Lh], T0, ntS, wave, 0);
+    }
+    // dh fragments of this pair's encoder (hidden-layer backward), requested early as well
+    const int tC = g;                                       // E <= 4: one encoder per wave pair
+    const bool actC0 = tC < b.n_seq && slot_present(b, b.seq_data[min(tC, max(b.n_seq - 1, 0))]);
+    const int eC = actC0 ? b.seq_enc[tC] : 0;
+    const ParEnc& peC = a.enc[eC];
+    const bool actC = actC0 && peC.Lh >= 1;
+    f32x4 hqC[2][8], h1qC[2];
+    if (actC) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (16 * (half + 2 * k) < peC.HL) issue_t<8>(hqC[k], a.pack + peC.pkh, T0, (peC.HL + 15) >> 4, half + 2 * k, 0);
+        if (peC.Lh >= 2 && 16 * half < peC.in[1])
+            issue_t<2>(h1qC, a.pack + peC.pkb[1], (peC.out[1] + 15) >> 4, (peC.in[1] + 15) >> 4, half, 0);
+    }
+
+    // ---- phase C: all decoders on all state rows (decoders.py:19-20, multimodn.py:141-157,176-191)
+    if (wave < R && row_executed(b, wave)) {
+        const clp sS = St + wave * TB * ldS;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        consume_t<8>(z, sS, ldS, 0, wd, 0, T0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lds_st(sZ + (wave * TB + q * 4 + k) * 16 + i, z[k]);
+    }
+    __syncthreads();
+    const int total = R * D * TB;
+    for (int base = 0; base < total; base += NT8) {
+        const int idx = base + threadIdx.x;
+        const bool valid = idx < total;
+        const int r = valid ? idx / (D * TB) : 0;
+        const int rem = idx - r * D * TB;
+        const int d = valid ? rem / TB : 0, row = rem & (TB - 1);
+        const bool live = valid && row < nrows && row_executed(b, r);
+        float lossv = 0.f;
+        int correct = 0, tp = 0, tn = 0, fp = 0, fn = 0;
+        if (live) {
+            const float* bd = a.dec_b[d];
+            const float za = (base == 0 ? bd0_pre : g_ld(bd)) + lds_ld(sZ + (r * TB + row) * 16 + 2 * d);
+            const float zb = (base == 0 ? bd1_pre : g_ld(bd + 1)) + lds_ld(sZ + (r * TB + row) * 16 + 2 * d + 1);
+            const int64_t grow = (int64_t)row0 + row;
+            const int y = base == 0 ? y_pre : (int)*(const MMN_AS1 int64_t*)(b.y + grow * D + d);
+            const float o0 = 1.0f / (1.0f + expf(-za));
+            const float o1 = 1.0f / (1.0f + expf(-zb));
+            const float mx = fmaxf(o0, o1);
+            const float lse = mx + logf(expf(o0 - mx) + expf(o1 - mx));
+            lossv = lse - (y ? o1 : o0);
+            const int pred = o1 > o0 ? 1 : 0;      // torch.max: first index wins ties
+            correct = pred == y;
+            tp = pred & y; tn = (1 - pred) & (1 - y); fp = pred & (1 - y); fn = (1 - pred) & y;
+            if (want_grads) {
+                const float g0 = expf(o0 - lse) - (y == 0 ? 1.0f : 0.0f);
+                const float g1 = expf(o1 - lse) - (y == 1 ? 1.0f : 0.0f);
+                f32x2 dzv;
+                dzv.x = cL * g0 * o0 * (1.0f - o0);
+                dzv.y = cL * g1 * o1 * (1.0f - o1);
+                g_st2(a.dz + ((int64_t)r * a.maxB + grow) * (2 * D) + 2 * d, dzv);
+                lds_st(sDzA + (r * TB + row) * LDZ + 2 * d, dzv.x);
+                lds_st(sDzA + (r * TB + row) * LDZ + 2 * d + 1, dzv.y);
+            }
+        }
+#pragma unroll
+        for (int off = TB / 2; off >= 1; off >>= 1) lossv += __shfl_xor(lossv, off);
+        const unsigned long long mc = __ballot(correct), mtp = __ballot(tp), mtn = __ballot(tn),
+                                 mfp = __ballot(fp), mfn = __ballot(fn);
+        if (valid && row == 0) {
+            const int sh = lane & ~(TB - 1);
+            const int64_t cell = (int64_t)tile * (R * D) + r * D + d;
+            g_st(a.lossp + cell, lossv);
+            int32_t* cp = a.cnt + cell * 5;
+            g_sti(cp + 0, __popcll((mc >> sh) & 0xFFFFull));
+            g_sti(cp + 1, __popcll((mtp >> sh) & 0xFFFFull));
+            g_sti(cp + 2, __popcll((mtn >> sh) & 0xFFFFull));
+            g_sti(cp + 3, __popcll((mfp >> sh) & 0xFFFFull));
+            g_sti(cp + 4, __popcll((mfn >> sh) & 0xFFFFull));
+        }
+    }
+    for (int e = threadIdx.x; e < E; e += NT8) {            // state-change partials, fixed order
+        float s = 0.f;
+        for (int w = 0; w < 8; ++w) s += lds_ld(sRed + 8 * e + w);
+        g_st(a.scp + (int64_t)tile * E + e, s);
+    }
+    __syncthreads();                                        // dz tiles complete; u_e tiles dead
+    STAMP8();
+
+    // ======================= backward half =======================
+    const lp DG = smem + L.sU;                              // R tiles: decoder grad -> G_out, in place
+    // ---- phase A': wave r owns state row r: DG[r] = dz[r] Wdec + cS (s_r - s_prev(r))
+    if (wave < R && row_executed(b, wave)) {
+        const int r = wave;
+        const lp out = DG + r * TB * ldS;
+        const clp sr = St + r * TB * ldS;
+        const clp sp = St + (r >= 1 ? prev_row_of(b, r - 1) : 0) * TB * ldS;
+        const clp dzt = sDzA + r * TB * LDZ;
+        const PB Bdz = make_pb(a.pack + a.pkd, S, 2 * D, 0);      // W' = Wdec^T [S x 2D]
+        wave_layer(ASrc{dzt, LDZ, dzt, LDZ}, Bdz, 0, Bdz.T, [&](int row, int col, float v) {
+            if (col < S) {
+                const float dlt = r >= 1 ? lds_ld(sr + row * ldS + col) - lds_ld(sp + row * ldS + col) : 0.f;
+                lds_st(out + row * ldS + col, (row < nrows) ? v + cS * dlt : 0.f);
+            }
+        });
+    }
+    __syncthreads();
+    // ---- phase B': carry' = G_out W_s - cS d_e; the next row's G_out is formed in the same epilogue
+    {
+        auto chain_step = [&](f32x4 (&wc)[8], f32x4 (&wn)[8], int t, int t_prv) {
+            const int e = b.seq_enc[t];
+            const clp Go = DG + (e + 1) * TB * ldS;
+            const clp so = St + (e + 1) * TB * ldS;
+            const clp sp = St + (t_prv >= 0 ? b.seq_enc[t_prv] + 1 : 0) * TB * ldS;   // state that fed encoder e
+            const int r_nxt = t_prv >= 0 ? b.seq_enc[t_prv] + 1 : 0;
+            const lp Gx = DG + r_nxt * TB * ldS;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (wave < ntS) consume_t<8>(acc, Go, ldS, 0, wc, 0, T0);
+            if (t_prv >= 0 && wave < ntS) {
+                const ParEnc& p2 = a.enc[b.seq_enc[t_prv]];
+                issue_t<8>(wn, a.pack + p2.pkb[p2.Lh], T0, ntS, wave, 0);
+            }
+            const int col = 16 * wave + i;
+            if (wave < ntS && col < S) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = 4 * q + k;
+                    const float dlt = row < nrows ? lds_ld(so + row * ldS + col) - lds_ld(sp + row * ldS + col) : 0.f;
+                    lds_st(Gx + row * ldS + col, lds_ld(Gx + row * ldS + col) + (acc[k] - cS * dlt));
+                }
+            }
+            __syncthreads();
+        };
+        bool flip = false;
+        for (int t = t_last; t >= 0;) {
+            int t_prv = t - 1;
+            while (t_prv >= 0 && !slot_present(b, b.seq_data[t_prv])) --t_prv;
+            if (!flip) chain_step(wcA, wcB, t, t_prv); else chain_step(wcB, wcA, t, t_prv);
+            flip = !flip;
+            t = t_prv;
+        }
+    }
+    // ---- stores: dS[e] = G_out(e), dS[E] = dS0 (final since the last barrier); fire and forget
+    for (int r = 0; r < R; ++r) {
+        if (!row_executed(b, r)) continue;
+        const int idx = r == 0 ? E : r - 1;
+        for (int rr = wave; rr < nrows; rr += 8)
+            for (int c = lane * 4; c < S; c += 256) {
+                if ((S & 3) == 0) g_st4(a.dS + ((int64_t)idx * a.maxB + row0 + rr) * S + c, lds_ld4(DG + (r * TB + rr) * ldS + c));
+                else for (int k = 0; k < 4 && c + k < S; ++k) g_st(a.dS + ((int64_t)idx * a.maxB + row0 + rr) * S + c + k, lds_ld(DG + (r * TB + rr) * ldS + c + k));
+            }
+    }
+    // ---- phase C': hidden-layer backward of this pair's encoder; h_0 / h_1 are still in the pair's
+    //      LDS scratch, so act' is applied in the GEMM epilogue and dpre overwrites h in place
+    {
+        int LmaxC = 0;
+        for (int k = 0; k < 4; ++k)
+            if (k < b.n_seq && slot_present(b, b.seq_data[k])) LmaxC = max(LmaxC, a.enc[b.seq_enc[k]].Lh);
+        if (LmaxC >= 1) {
+            const int Lh = peC.Lh, HL = peC.HL, akind = peC.akind;
+            if (actC) {
+                const clp Go = DG + (eC + 1) * TB * ldS;
+                const lp hb = sHg[Lh - 1];                  // h_{Lh-1} in, dpre_{Lh-1} out
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int tl = half + 2 * k;
+                    if (16 * tl < HL) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        consume_t<8>(acc, Go, ldS, 0, hqC[k], 0, T0);
+                        const int col = 16 * tl + i;
+                        if (col < HL) {
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk) {
+                                const int row = 4 * q + kk;
+                                const float h = lds_ld(hb + row * ldH + col);
+                                lds_st(hb + row * ldH + col, row < nrows ? acc[kk] * act_grad_from_out(h, akind) : 0.f);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (actC) {
+                const int N = peC.out[Lh - 1];
+                const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
+                wave_store_tile(a.dpre + peC.hid[Lh - 1] + (int64_t)(row0 + r0) * N, sHg[Lh - 1] + r0 * ldH, ldH, nr, N);
+            }
+            if (LmaxC >= 2) {
+                if (actC && Lh >= 2 && 16 * half < peC.in[1]) {   // dpre_0 = (dpre_1 W_1) .* act'(h_0), tile = half
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    consume_t<2>(acc, sHg[1], ldH, 0, h1qC, 0, (peC.out[1] + 15) >> 4);
+                    const int col = 16 * half + i;
+                    if (col < peC.in[1]) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const int row = 4 * q + kk;
+                            const float h = lds_ld(sHg[0] + row * ldH + col);
+                            lds_st(sHg[0] + row * ldH + col, row < nrows ? acc[kk] * act_grad_from_out(h, akind) : 0.f);
+                        }
+                    }
+                }
+                __syncthreads();
+                if (actC && Lh >= 2) {
+                    const int N = peC.out[0];
+                    const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
+                    wave_store_tile(a.dpre + peC.hid[0] + (int64_t)(row0 + r0) * N, sHg[0] + r0 * ldH, ldH, nr, N);
+                }
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // k_wgrad: C[M x ncols] = A[rows x M]^T * In[rows x ncols] over a row range -> partial slab.
 // No LDS in the main loop: lane (i, q) loads MT consecutive A columns and NT consecutive In columns
 // of row r+q, i.e. the 16*MT x 16*NT output tile is made of MT x NT INTERLEAVED 16x16 MFMA tiles
@@ -2609,8 +3097,8 @@ struct mmn_plan {
     size_t par_lds_fwd, par_lds_bwd;
     int par_ok;
     ParArgs pa;              // kernel-argument descriptor of the 8-wave fast tier
-    size_t f8_lds_fwd, f8_lds_bwd;
-    int f8_ok;
+    size_t f8_lds_fwd, f8_lds_bwd, fb8_lds_bytes;
+    int f8_ok, fb8_ok;
     int grad_blocks;
     int rt_override;
 };
@@ -3006,9 +3494,14 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
         const char* fe = getenv("MMN_FAST8");
         if (fe && atoi(fe) == 0) ok = false;
         pl->f8_ok = ok ? 1 : 0;
+        pl->fb8_lds_bytes = sizeof(float) * (size_t)fb8_lds(h.R, h.ldS, h.ldH, h.ldX).total;
+        {
+            const char* fb = getenv("MMN_FUSED");
+            pl->fb8_ok = (ok && h.E <= 4 && pl->fb8_lds_bytes <= 160 * 1024 && !(fb && atoi(fb) == 0)) ? 1 : 0;
+        }
         if (getenv("MMN_VERBOSE"))
-            fprintf(stderr, "[mmn] fast8: ok=%d lds fwd=%zu bwd=%zu needs_zero=%d sizeof(ParArgs)=%zu\n", pl->f8_ok,
-                    pl->f8_lds_fwd, pl->f8_lds_bwd, a.needs_zero, sizeof(ParArgs));
+            fprintf(stderr, "[mmn] fast8: ok=%d fused=%d lds fwd=%zu bwd=%zu fused=%zu needs_zero=%d sizeof(ParArgs)=%zu\n",
+                    pl->f8_ok, pl->fb8_ok, pl->f8_lds_fwd, pl->f8_lds_bwd, pl->fb8_lds_bytes, a.needs_zero, sizeof(ParArgs));
     }
     pl->lds_bytes[0] = 0;
     for (int rt = 1; rt <= 2; ++rt) pl->lds_bytes[rt] = sizeof(float) * (size_t)chain_lds(16 * rt, h.ldS, h.ldH).total;
@@ -3032,6 +3525,9 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
             (e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)) != hipSuccess)
             return fail(e);
     }
+    if (pl->fb8_ok &&
+        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fb8), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)pl->fb8_lds_bytes)) != hipSuccess) return fail(e);
     if (pl->f8_ok) {
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd8), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)pl->f8_lds_fwd)) != hipSuccess) return fail(e);
@@ -3089,6 +3585,7 @@ static int rt_for(const mmn_plan* p, const mmn_batch* b) {
 
 const char* mmn_chain_kernel_name(mmn_plan* p, const mmn_batch* b, int backward) {
     if (!p || !b) return "";
+    if (backward == 2) return (use_fast8(p, b) && p->fb8_ok) ? "k_fb8" : "";
     if (use_fast8(p, b)) return backward ? "k_bwd8" : "k_fwd8";
     if (p->par_ok) return backward ? "k_chain_bwd_par" : "k_chain_fwd_par";
     return backward ? "k_chain_bwd" : "k_chain_fwd";
@@ -3155,6 +3652,22 @@ int mmn_chain_bwd(mmn_plan* p, const mmn_batch* b, float sc_pen_x001, void* stre
     return MMN_OK;
 }
 
+int mmn_chain_fwd_bwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float sc_pen_x001, void* stream) {
+    int rc = check_batch(p, b);
+    if (rc != MMN_OK) return rc;
+    if (use_fast8(p, b) && p->fb8_ok) {                    // one launch for both chains
+        const int tiles = (b->batch + 15) / 16;
+        const float cL = err_penalty / ((float)p->m.n_decoders * (float)(p->m.n_encoders + 1) * (float)b->batch_global);
+        mmn_batch bb = *b;
+        hipLaunchKernelGGL(k_fb8, dim3(tiles), dim3(NT8), p->fb8_lds_bytes, static_cast<hipStream_t>(stream), p->pa, bb, cL,
+                           sc_coeff(p, b, sc_pen_x001));
+        HIP_TRY(hipGetLastError());
+        return MMN_OK;
+    }
+    if ((rc = mmn_chain_fwd(p, b, err_penalty, sc_pen_x001, 1, stream)) != MMN_OK) return rc;
+    return mmn_chain_bwd(p, b, sc_pen_x001, stream);
+}
+
 int mmn_wgrad(mmn_plan* p, const mmn_batch* b, void* stream) {
     int rc = check_batch(p, b);
     if (rc != MMN_OK) return rc;
@@ -3196,8 +3709,7 @@ int mmn_train_step(mmn_plan* p, const mmn_batch* b, float err_penalty, float sc_
                    void* stream) {
     int rc = mmn_prepare(p, b, 1, stream);
     if (rc != MMN_OK) return rc;
-    if ((rc = mmn_chain_fwd(p, b, err_penalty, sc_pen_x001, 1, stream)) != MMN_OK) return rc;
-    if ((rc = mmn_chain_bwd(p, b, sc_pen_x001, stream)) != MMN_OK) return rc;
+    if ((rc = mmn_chain_fwd_bwd(p, b, err_penalty, sc_pen_x001, stream)) != MMN_OK) return rc;
     if ((rc = mmn_wgrad(p, b, stream)) != MMN_OK) return rc;
     return launch_reduce(p, b, 1, accumulate_epoch, err_penalty, sc_pen_x001, stream);
 }

@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "mmn_version", "mmn_error_string", "mmn_last_hip_error", "mmn_stats_floats", "mmn_epoch_doubles",
     "mmn_workspace_bytes", "mmn_plan_create", "mmn_plan_destroy", "mmn_nan_flags", "mmn_prepare",
     "mmn_nan_scan", "mmn_chain_kernel_name", "mmn_chain_fwd",
-    "mmn_chain_bwd", "mmn_wgrad", "mmn_reduce", "mmn_epoch_accumulate", "mmn_train_step",
+    "mmn_chain_bwd", "mmn_chain_fwd_bwd", "mmn_wgrad", "mmn_reduce", "mmn_epoch_accumulate", "mmn_train_step",
     "mmn_eval_step", "mmn_epoch_reset", "mmn_epoch_read", "mmn_debug_buffer",
 )
 
@@ -109,6 +109,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_chain_fwd.argtypes = [vp, C.POINTER(Batch), f32, f32, i32, vp]
     lib.mmn_chain_bwd.restype = i32
     lib.mmn_chain_bwd.argtypes = [vp, C.POINTER(Batch), f32, vp]
+    lib.mmn_chain_fwd_bwd.restype = i32
+    lib.mmn_chain_fwd_bwd.argtypes = [vp, C.POINTER(Batch), f32, f32, vp]
     lib.mmn_wgrad.restype = i32
     lib.mmn_wgrad.argtypes = [vp, C.POINTER(Batch), vp]
     lib.mmn_reduce.restype = i32

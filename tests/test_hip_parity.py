@@ -68,7 +68,7 @@ def check_against(stats, grads, ref: O.StepResult, tol_loss=1e-5, tol_grad=2e-5,
             assert rel_err(grads[n].reshape(g.shape), g) < tol_grad, (n, rel_err(grads[n].reshape(g.shape), g))
 
 
-@pytest.mark.parametrize("mode", ["fast8", "par16", "seq16"])
+@pytest.mark.parametrize("mode", ["fused8", "fast8", "par16", "seq16"])
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_first_step_matches_reference_golden(lib, name, mode, monkeypatch):
     set_mode(monkeypatch, mode)
@@ -120,17 +120,19 @@ def test_training_matches_reference_golden(lib, name):
         assert rel_err(sd[n], w) < tol, (n, rel_err(sd[n], w))
 
 
-KERNEL_MODES = {"fast8": ("1", "1", "1"), "par16": ("1", "1", "0"), "seq16": ("1", "0", "0"), "seq32": ("2", "0", "0")}
+KERNEL_MODES = {"fused8": ("1", "1", "1", "1"), "fast8": ("1", "1", "1", "0"), "par16": ("1", "1", "0", "0"),
+                "seq16": ("1", "0", "0", "0"), "seq32": ("2", "0", "0", "0")}
 
 
 def set_mode(monkeypatch, mode):
     """Kernel tier, read at plan creation: 8-wave fast tier (MIMIC-like shapes; other shapes fall
     through to the next tier), 4-wave parallel-phase kernels, or the sequential chain kernels with
     16- / 32-row tiles."""
-    rt, par, fast8 = KERNEL_MODES[mode]
+    rt, par, fast8, fused = KERNEL_MODES[mode]
     monkeypatch.setenv("MMN_RT", rt)
     monkeypatch.setenv("MMN_PAR", par)
     monkeypatch.setenv("MMN_FAST8", fast8)
+    monkeypatch.setenv("MMN_FUSED", fused)          # forward+backward chain in one launch (E <= 4)
 
 
 @pytest.mark.parametrize("mode", list(KERNEL_MODES))
@@ -158,6 +160,24 @@ def test_mimic_like_shapes_ragged(lib, B, mode, monkeypatch):
     params = O.init_params(spec, 9)
     xs, y = O.synthetic_batches(spec, B, B, seed=4)[0]
     order = [3, 0, 4, 1, 2]
+    batch = ([xs[e] for e in order], y, np.tile(np.array(order, np.int64), (B, 1)))
+    model = build_torch_model(spec, params, "cuda", lib)
+    stats, grads, _ = run_step(model, batch)
+    ref = O.forward_backward(params, spec, batch[0], batch[1], batch[2])
+    check_against(stats, grads, ref)
+
+
+@pytest.mark.parametrize("mode", ["fused8", "fast8"])
+@pytest.mark.parametrize("B", [1, 9, 16, 23, 130])
+def test_fused_chain_shapes_ragged(lib, B, mode, monkeypatch):
+    """E <= 4 so that the fused forward+backward kernel applies: hidden depths 2, 0, 1, 2."""
+    set_mode(monkeypatch, mode)
+    spec = O.ModelSpec(48, [O.EncoderSpec(32, (32, 16), O.ACT_RELU), O.EncoderSpec(16, (), O.ACT_RELU),
+                            O.EncoderSpec(64, (32,), O.ACT_SIGMOID), O.EncoderSpec(128, (16, 32), O.ACT_IDENTITY)],
+                       4, 1.0, 0.6)
+    params = O.init_params(spec, 9)
+    xs, y = O.synthetic_batches(spec, B, B, seed=4)[0]
+    order = [3, 0, 1, 2]
     batch = ([xs[e] for e in order], y, np.tile(np.array(order, np.int64), (B, 1)))
     model = build_torch_model(spec, params, "cuda", lib)
     stats, grads, _ = run_step(model, batch)

@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--resident-batches", type=int, default=8)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay also for N>1")
+    ap.add_argument("--optimizer", choices=("hip", "torch"), default="hip",
+                    help="hip: multimodn_amd.optim.Adam (one k_adam launch); torch: torch.optim.Adam(fused, capturable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -112,9 +114,13 @@ def main():
     if world > 1:
         model.enable_data_parallel()
     eng = model._get_engine(B)
-    # per-tensor fused Adam: torch's multi-tensor apply gives one block per 64K-element chunk, so
-    # the 31 separate tensors (15 us) beat one flat 96K-element tensor (2 blocks, 75 us measured)
-    opt = torch.optim.Adam(list(model.parameters()), 1e-3, fused=True, capturable=True)
+    if args.optimizer == "hip":
+        # optimizer.step() as one k_adam launch over the flat parameter / gradient buffers
+        opt = mm.optim.Adam(list(model.parameters()), 1e-3)
+    else:
+        # torch's multi-tensor fused Adam (one block per 64K-element chunk per tensor: 15 us for the
+        # 31 tensors, plus a foreach add for the step counters)
+        opt = torch.optim.Adam(list(model.parameters()), 1e-3, fused=True, capturable=True)
 
     # synthetic data resident in HBM (weak scaling: every rank its own B rows per step)
     host = O.synthetic_batches(spec, B * args.resident_batches, B, seed=100 + rank, learnable=True)
@@ -201,6 +207,9 @@ def main():
         kern[bwd_name] = lambda b: lib.mmn_chain_bwd(plan, C.byref(b), beta, stream)
     kern["k_wgrad"] = lambda b: lib.mmn_wgrad(plan, C.byref(b), stream)
     kern["k_reduce"] = lambda b: lib.mmn_reduce(plan, C.byref(b), stream)
+    if args.optimizer == "hip":
+        adam_desc = opt.descriptor(opt._runs[0][0], opt.param_groups[0])   # the launch opt.step() makes
+        kern["k_adam"] = lambda b: lib.mmn_adam_step(C.byref(adam_desc), stream)
     REP, ROUNDS = 20, 5
     avg_us = {}
     for name, fn in kern.items():
@@ -244,7 +253,8 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "MIMIC-shaped tabular: 4 modalities x 64 features, hidden (32,32) relu, 3 binary tasks, "
-                               "state_dim 128, batch 4096 per GPU, Adam(fused) lr 1e-3, penalties 1.0/0.3",
+                               "state_dim 128, batch 4096 per GPU, Adam lr 1e-3, penalties 1.0/0.3",
+                   "optimizer": "multimodn_amd.optim.Adam (k_adam)" if args.optimizer == "hip" else "torch.optim.Adam(fused, capturable)",
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
                    "launch": "hipGraph replay" if graphs is not None else "eager",
                    "samples_per_sec_per_gpu": value / world},

@@ -196,6 +196,34 @@ int mmn_train_step(mmn_plan* p, const mmn_batch* b, float err_penalty, float sta
 /* Forward-only step for test()/predict() (multimodn.py:255-419): fwd + reduce (+ accumulate). */
 int mmn_eval_step(mmn_plan* p, const mmn_batch* b, int accumulate_epoch, void* stream);
 
+/* optimizer.step() (multimodn.py:204) for torch.optim.Adam as the reference pipelines build it
+ * (titanic_mlp_pipeline.py:74), over FLAT buffers: one launch (k_adam) for the whole model.
+ * All pointers are device memory owned by the caller; params/grads/exp_avg/exp_avg_sq hold n
+ * floats each and are 16-byte aligned.  The n_seg tensors that make up the flat buffers are
+ * [seg_start[i], seg_start[i+1]) (seg_start[0] = 0, seg_start[n_seg] = n).  steps holds
+ * mmn_adam_blocks(n) identical rows of n_seg floats: tensor i's step count (float, like torch's
+ * state["step"]); every workgroup reads and advances its own row, so a captured launch can be
+ * replayed and no workgroup waits on another.  Row 0 is the one to read; to set the counters
+ * (load_state_dict) write every row.  seg_skip (may be NULL): seg_skip[i] != 0 -> tensor i has
+ * grad None this step and is left untouched (no moment decay, no step increment), torch's
+ * behaviour for the encoders the reference skips on a NaN batch (multimodn.py:168).
+ * amsgrad / decoupled weight decay are not implemented. */
+typedef struct mmn_adam {
+    float* params;
+    const float* grads;
+    float* exp_avg;
+    float* exp_avg_sq;
+    float* steps;
+    const int32_t* seg_start;
+    const int32_t* seg_skip;
+    int64_t n;
+    double lr, beta1, beta2, eps, weight_decay;   /* doubles: torch evaluates 1 - beta^t in double */
+    int32_t n_seg;
+    int32_t maximize;
+} mmn_adam;
+int mmn_adam_blocks(int64_t n);      /* rows of `steps`; 0 if n is out of range */
+int mmn_adam_step(const mmn_adam* d, void* stream);
+
 /* Epoch accumulators (device, inside the workspace): reset at epoch start, read at epoch end.
  * mmn_epoch_read synchronises the stream.  Layout of `out` (doubles): err_sum[R*D], sc_sum[E],
  * n_correct[R*D], tp[R*D], tn[R*D], fp[R*D], fn[R*D] (the four accumulated in fp32 like the

@@ -8,10 +8,11 @@ from .history import MultiModNHistory
 from .datasets import MultiModDataset, PartitionDataset, FeatureWiseDataset, JointDatasets
 from .multimodn import MultiModN
 from .engine import HipChainEngine, UnsupportedModelError
+from . import optim
 
 __all__ = [
     "InitState", "TrainableInitState", "StaticInitState", "MultiModEncoder", "MLPEncoder", "SLPEncoder",
     "LinearEncoder", "LogisticEncoder", "MultiModDecoder", "ClassDecoder", "LogisticDecoder",
     "MultiModNHistory", "MultiModDataset", "PartitionDataset", "FeatureWiseDataset", "JointDatasets",
-    "MultiModN", "HipChainEngine", "UnsupportedModelError",
+    "MultiModN", "HipChainEngine", "UnsupportedModelError", "optim",
 ]

@@ -3103,6 +3103,111 @@ struct mmn_plan {
     int rt_override;
 };
 
+// =====================================================================================
+// k_adam: optimizer.step() of the training loop (multimodn.py:204) for torch.optim.Adam as the
+// reference pipelines build it, over the FLAT parameter / gradient / moment buffers: one launch
+// for the whole model instead of a multi-tensor apply (one block per 64K-element chunk) plus a
+// foreach add for the step counters.  HBM-bound: 16 B read + 12 B written per parameter.
+//   - per-tensor step counters live on the device (hipGraph replay).  Every block keeps its OWN
+//     copy of the n_seg counters (row blockIdx of `steps`; row 0 is the one callers read) and
+//     advances it itself, so no block ever waits on another: no ticket, no fence, one memory
+//     round trip per launch;
+//   - a tensor whose gradient is None this step (encoder skipped on a NaN batch) is left
+//     untouched: no moment decay, no step increment - torch.optim.Adam's behaviour.
+// =====================================================================================
+constexpr int ADAM_NT = 256;
+constexpr int ADAM_MAX_SEG = 512;
+
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v;
+    float* steps; const int* seg_start; const int* seg_skip;
+    int n, n_seg;
+    double lr, b1, b2;
+    float eps, wd;
+    int maximize;
+};
+
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, float omb1, float b2, float omb2,
+                                          float eps, float wd, float step_size, float bc2s, int maximize) {
+    if (maximize) g = -g;
+    if (wd != 0.f) g = fmaf(wd, p, g);
+    m = fmaf(g - m, omb1, m);                             // lerp(m, g, 1 - beta1)
+    v = fmaf(b2, v, omb2 * g * g);
+    const float denom = sqrtf(v) / bc2s + eps;
+    p -= step_size * (m / denom);
+}
+
+// beta^t for an integer step count, in double (torch evaluates the bias corrections in double)
+__device__ __forceinline__ double ipow(double b, unsigned t) {
+    double r = 1.0;
+    while (t) {
+        if (t & 1u) r *= b;
+        b *= b;
+        t >>= 1;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(ADAM_NT) void k_adam(const AdamArgs a) {
+    __shared__ int s_start[ADAM_MAX_SEG + 1];
+    __shared__ float s_ss[ADAM_MAX_SEG], s_bc2s[ADAM_MAX_SEG];
+    const int tid = threadIdx.x;
+    float* my_steps = a.steps + (size_t)blockIdx.x * a.n_seg;
+    const int base = (blockIdx.x * ADAM_NT + tid) * 4;
+    const bool full = base + 3 < a.n;
+    // the data loads do not depend on the segment table: issue them first
+    float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = p4, m4 = p4, v4 = p4;
+    if (full) {
+        p4 = *reinterpret_cast<const float4*>(a.p + base);
+        g4 = *reinterpret_cast<const float4*>(a.g + base);
+        m4 = *reinterpret_cast<const float4*>(a.m + base);
+        v4 = *reinterpret_cast<const float4*>(a.v + base);
+    }
+    for (int i = tid; i <= a.n_seg; i += ADAM_NT) s_start[i] = a.seg_start[i];
+    for (int i = tid; i < a.n_seg; i += ADAM_NT) {
+        const int skip = a.seg_skip ? a.seg_skip[i] : 0;
+        const float t0 = my_steps[i];
+        const unsigned t = (unsigned)t0 + 1u;
+        if (!skip) my_steps[i] = t0 + 1.f;
+        const double bc1 = 1.0 - ipow(a.b1, t);
+        const double bc2 = 1.0 - ipow(a.b2, t);
+        s_ss[i] = skip ? -1.f : (float)(a.lr / bc1);
+        s_bc2s[i] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    const float omb1 = (float)(1.0 - a.b1), b2 = (float)a.b2, omb2 = (float)(1.0 - a.b2);
+    if (base < a.n) {
+        int lo = 0, hi = a.n_seg - 1;                      // last segment whose start <= base
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_start[mid] <= base) lo = mid; else hi = mid - 1;
+        }
+        int seg = lo;
+        if (full) {
+            float* pp = &p4.x; const float* gp = &g4.x; float* mp = &m4.x; float* vp = &v4.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                while (base + j >= s_start[seg + 1]) ++seg;
+                const float ss = s_ss[seg];
+                if (ss >= 0.f) adam_elem(pp[j], gp[j], mp[j], vp[j], omb1, b2, omb2, a.eps, a.wd, ss, s_bc2s[seg], a.maximize);
+            }
+            *reinterpret_cast<float4*>(a.p + base) = p4;
+            *reinterpret_cast<float4*>(a.m + base) = m4;
+            *reinterpret_cast<float4*>(a.v + base) = v4;
+        } else {
+            for (int i = base; i < a.n; ++i) {
+                while (i >= s_start[seg + 1]) ++seg;
+                const float ss = s_ss[seg];
+                if (ss >= 0.f) {
+                    float pv = a.p[i], mv = a.m[i], vv = a.v[i];
+                    adam_elem(pv, a.g[i], mv, vv, omb1, b2, omb2, a.eps, a.wd, ss, s_bc2s[seg], a.maximize);
+                    a.p[i] = pv; a.m[i] = mv; a.v[i] = vv;
+                }
+            }
+        }
+    }
+}
+
 static thread_local int g_last_hip = 0;
 #define HIP_TRY(expr)                                   \
     do {                                                \
@@ -3719,6 +3824,30 @@ int mmn_eval_step(mmn_plan* p, const mmn_batch* b, int accumulate_epoch, void* s
     if (rc != MMN_OK) return rc;
     if ((rc = mmn_chain_fwd(p, b, 1.0f, 0.0f, 0, stream)) != MMN_OK) return rc;
     return launch_reduce(p, b, 0, accumulate_epoch, 1.0f, 0.0f, stream);
+}
+
+int mmn_adam_blocks(int64_t n) {
+    if (n < 1 || n > 0x7fffffff - 4 * ADAM_NT) return 0;
+    return (int)((n + 4 * ADAM_NT - 1) / (4 * ADAM_NT));
+}
+
+int mmn_adam_step(const mmn_adam* d, void* stream) {
+    if (!d || !d->params || !d->grads || !d->exp_avg || !d->exp_avg_sq || !d->steps || !d->seg_start)
+        return MMN_ERR_ARG;
+    if (d->n < 1 || d->n > 0x7fffffff - 4 * ADAM_NT || d->n_seg < 1 || d->n_seg > ADAM_MAX_SEG) return MMN_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(d->params) | reinterpret_cast<uintptr_t>(d->grads) |
+         reinterpret_cast<uintptr_t>(d->exp_avg) | reinterpret_cast<uintptr_t>(d->exp_avg_sq)) & 15)
+        return MMN_ERR_ARG;
+    AdamArgs a;
+    a.p = d->params; a.g = d->grads; a.m = d->exp_avg; a.v = d->exp_avg_sq;
+    a.steps = d->steps; a.seg_start = d->seg_start; a.seg_skip = d->seg_skip;
+    a.n = (int)d->n; a.n_seg = d->n_seg;
+    a.lr = d->lr; a.b1 = d->beta1; a.b2 = d->beta2; a.eps = (float)d->eps; a.wd = (float)d->weight_decay;
+    a.maximize = d->maximize;
+    const int blocks = mmn_adam_blocks(d->n);
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(ADAM_NT), 0, static_cast<hipStream_t>(stream), a);
+    HIP_TRY(hipGetLastError());
+    return MMN_OK;
 }
 
 int mmn_epoch_reset(mmn_plan* p, void* stream) {

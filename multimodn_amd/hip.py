@@ -15,6 +15,7 @@ MAX_ENCODERS = 16
 MAX_DECODERS = 8
 MAX_LAYERS = 8
 MAX_DIM = 256
+ADAM_MAX_SEG = 512
 VERSION = 100
 
 ACT_IDENTITY, ACT_RELU, ACT_SIGMOID = 0, 1, 2
@@ -28,7 +29,7 @@ ABI_SYMBOLS = (
     "mmn_workspace_bytes", "mmn_plan_create", "mmn_plan_destroy", "mmn_nan_flags", "mmn_prepare",
     "mmn_nan_scan", "mmn_chain_kernel_name", "mmn_chain_fwd",
     "mmn_chain_bwd", "mmn_chain_fwd_bwd", "mmn_wgrad", "mmn_reduce", "mmn_epoch_accumulate", "mmn_train_step",
-    "mmn_eval_step", "mmn_epoch_reset", "mmn_epoch_read", "mmn_debug_buffer",
+    "mmn_eval_step", "mmn_adam_blocks", "mmn_adam_step", "mmn_epoch_reset", "mmn_epoch_read", "mmn_debug_buffer",
 )
 
 
@@ -58,6 +59,14 @@ class Batch(C.Structure):
                 ("batch", C.c_int32), ("batch_global", C.c_int32), ("n_seq", C.c_int32),
                 ("reserved", C.c_int32),
                 ("seq_data", C.c_int32 * MAX_ENCODERS), ("seq_enc", C.c_int32 * MAX_ENCODERS)]
+
+
+class AdamDesc(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("grads", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("steps", C.c_void_p), ("seg_start", C.c_void_p), ("seg_skip", C.c_void_p),
+                ("n", C.c_int64),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("weight_decay", C.c_double), ("n_seg", C.c_int32), ("maximize", C.c_int32)]
 
 
 class MmnError(RuntimeError):
@@ -121,6 +130,10 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_train_step.argtypes = [vp, C.POINTER(Batch), f32, f32, i32, vp]
     lib.mmn_eval_step.restype = i32
     lib.mmn_eval_step.argtypes = [vp, C.POINTER(Batch), i32, vp]
+    lib.mmn_adam_blocks.restype = i32
+    lib.mmn_adam_blocks.argtypes = [C.c_int64]
+    lib.mmn_adam_step.restype = i32
+    lib.mmn_adam_step.argtypes = [C.POINTER(AdamDesc), vp]
     lib.mmn_epoch_reset.restype = i32
     lib.mmn_epoch_reset.argtypes = [vp, vp]
     lib.mmn_epoch_read.restype = i32

@@ -1,0 +1,123 @@
+"""k_adam (mmn_adam_step) against torch.optim.Adam on the same gradients: the optimizer.step() of
+the reference's batch loop (multimodn.py:204).  Parameters and moments within 1e-5 relative (fp32),
+step counters exact, skipped tensors bit-identical."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def make_flat(shapes, seed):
+    g = torch.Generator().manual_seed(seed)
+    n = sum(int(np.prod(s)) for s in shapes)
+    flat = torch.randn(n, generator=g).cuda()
+    gflat = torch.zeros(n, device="cuda")
+    ps, gs, off = [], [], 0
+    for s in shapes:
+        k = int(np.prod(s))
+        p = torch.nn.Parameter(flat[off:off + k].view(s))
+        ps.append(p)
+        gs.append(gflat[off:off + k].view(s))
+        off += k
+    return flat, gflat, ps, gs
+
+
+SHAPES = [(128,), (32, 64), (32,), (2, 128), (2,), (3,), (128, 160), (128,), (5, 7), (1,)]
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_matches_torch_adam_with_skipped_tensors(wd):
+    import multimodn_amd as mm
+    flat, gflat, ps, gs = make_flat(SHAPES, 0)
+    ref_ps = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = mm.optim.Adam(ps, 3e-3, betas=(0.8, 0.99), eps=1e-7, weight_decay=wd)
+    ref = torch.optim.Adam(ref_ps, 3e-3, betas=(0.8, 0.99), eps=1e-7, weight_decay=wd)
+    gen = torch.Generator().manual_seed(1)
+    for it in range(12):
+        gflat.copy_(torch.randn(gflat.numel(), generator=gen).cuda() * (10.0 ** (it % 3 - 1)))
+        skip = {1, 2} if it in (3, 4, 7) else ({6} if it == 5 else set())
+        for i, (p, g, rp) in enumerate(zip(ps, gs, ref_ps)):
+            p.grad = None if i in skip else g
+            rp.grad = None if i in skip else g.clone()
+        before = [p.detach().clone() for p in ps]
+        rbefore = [rp.detach().clone() for rp in ref_ps]
+        opt.step()
+        ref.step()
+        for i, (p, rp, b, rb) in enumerate(zip(ps, ref_ps, before, rbefore)):
+            upd, rupd = (p.detach() - b).cpu().numpy(), (rp.detach() - rb).cpu().numpy()
+            if i in skip:
+                assert np.array_equal(upd, np.zeros_like(upd))
+            else:
+                # parameters to fp32 rounding; the update itself (a difference of O(1) values, so
+                # it carries the parameters' rounding: 2.4e-7 / 2e-3) to 5e-4
+                assert rel_err(p.detach().cpu().numpy(), rp.detach().cpu().numpy()) < 1e-6, (it, i)
+                assert rel_err(upd, rupd) < 5e-4, (it, i, rel_err(upd, rupd))
+    for p, rp in zip(ps, ref_ps):
+        assert float(opt.state[p]["step"]) == float(ref.state[rp]["step"])
+        assert rel_err(opt.state[p]["exp_avg"].cpu().numpy(), ref.state[rp]["exp_avg"].cpu().numpy()) < 1e-5
+        assert rel_err(opt.state[p]["exp_avg_sq"].cpu().numpy(), ref.state[rp]["exp_avg_sq"].cpu().numpy()) < 1e-5
+
+
+def test_state_dict_round_trip_and_scattered_params():
+    """state_dict layout equals torch.optim.Adam's (checkpoints move both ways); parameters that
+    are NOT adjacent in memory still work (one launch per run)."""
+    import multimodn_amd as mm
+    ps = [torch.nn.Parameter(torch.randn(s).cuda()) for s in [(8, 4), (4,), (16,)]]
+    ref_ps = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt, ref = mm.optim.Adam(ps, 1e-2), torch.optim.Adam(ref_ps, 1e-2)
+    for it in range(3):
+        for p, rp in zip(ps, ref_ps):
+            p.grad = torch.randn_like(p)
+            rp.grad = p.grad.clone()
+        opt.step()
+        ref.step()
+    sd = opt.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    # torch's optimizer state -> ours, then continue in lock step
+    opt2 = mm.optim.Adam(ps, 1e-2)
+    opt2.load_state_dict(ref.state_dict())
+    for it in range(3):
+        grads = [torch.randn_like(p) for p in ps]      # fresh buffers: the runs must follow them
+        for p, rp, g in zip(ps, ref_ps, grads):
+            p.grad = g
+            rp.grad = g.clone()
+        opt2.step()
+        ref.step()
+    for p, rp in zip(ps, ref_ps):
+        assert rel_err(p.detach().cpu().numpy(), rp.detach().cpu().numpy()) < 1e-5
+        assert float(opt2.state[p]["step"]) == 6.0
+
+
+def test_graph_replay_advances_steps():
+    import multimodn_amd as mm
+    flat, gflat, ps, gs = make_flat([(64, 32), (32,)], 2)
+    ref_ps = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt, ref = mm.optim.Adam(ps, 1e-3), torch.optim.Adam(ref_ps, 1e-3)
+    for p, g in zip(ps, gs):
+        p.grad = g
+    gflat.normal_()
+    opt.step()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            opt.step()
+    torch.cuda.current_stream().wait_stream(side)
+    for rp, g in zip(ref_ps, gs):
+        rp.grad = g.clone()
+    ref.step()                       # the eager step above (capture itself does not execute)
+    for it in range(4):
+        gflat.normal_()
+        for rp, g in zip(ref_ps, gs):
+            rp.grad = g.clone()
+        graph.replay()
+        ref.step()
+    torch.cuda.synchronize()
+    assert float(opt.state[ps[0]]["step"]) == 5.0
+    for p, rp in zip(ps, ref_ps):
+        assert rel_err(p.detach().cpu().numpy(), rp.detach().cpu().numpy()) < 1e-5

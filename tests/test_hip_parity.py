@@ -90,12 +90,15 @@ def test_first_step_matches_reference_golden(lib, name, mode, monkeypatch):
     check_against(stats, grads, ref)
 
 
+@pytest.mark.parametrize("optimizer", ["torch", "hip"])
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
-def test_training_matches_reference_golden(lib, name):
-    """Whole train_epoch loops through the public surface: History arrays and trained weights."""
+def test_training_matches_reference_golden(lib, name, optimizer):
+    """Whole train_epoch loops through the public surface: History arrays and trained weights,
+    with torch's Adam (what the reference pipelines build) and with the one-launch HIP Adam."""
     g = Golden(name)
     model = build_torch_model(g.spec, g.init_params(), "cuda", lib)
-    opt = torch.optim.Adam(list(model.parameters()), g.cfg["lr"])
+    Adam = torch.optim.Adam if optimizer == "torch" else lib.optim.Adam
+    opt = Adam(list(model.parameters()), g.cfg["lr"])
     hist = lib.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
     crit = torch.nn.CrossEntropyLoss()
     loader = []

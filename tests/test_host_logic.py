@@ -165,3 +165,15 @@ def test_history_results_table(tmp_path):
     assert df["State change loss"].tolist() == [0.25, 0.25] and df["Train loss"].tolist() == [4.0, 5.0]
     h.save_results(tmp_path / "r.csv")
     assert (tmp_path / "r.csv").read_text().startswith("Target,State change loss,Train loss")
+
+
+def test_hip_adam_refuses_cpu_parameters():
+    """No torch-op fallback for optimizer.step(): CPU parameters raise instead of silently running."""
+    import multimodn_amd as mm
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    opt = mm.optim.Adam([p], 1e-3)
+    with pytest.raises(mm.hip.MmnError):
+        opt.step()
+    with pytest.raises(NotImplementedError):
+        mm.optim.Adam([p], amsgrad=True)

@@ -40,6 +40,7 @@
 #include <string.h>
 #include <new>
 #include <type_traits>
+#include <algorithm>
 #include <vector>
 
 #include "mmn_hip.h"
@@ -82,9 +83,32 @@ struct WTask {
 };
 
 struct WItem {
-    int32_t task, m0, n0, ks;          // n0 relative to the source `src`
+    int32_t task, m0, n0, ks, nks;     // n0 relative to the source `src`; ks of nks row-range splits
     int16_t mt, nt;                    // interleave widths (1, 2 or 4): tile = 16*mt x 16*nt
     int16_t src, bias;                 // src 0: in0, 1: in1, 2: none (bias only)
+};
+
+// One k_wgrad work item, fully resolved at plan creation: a workgroup reads ONE record (a
+// wave-uniform, scalar load) and knows its operands, instead of chasing plan -> item -> task ->
+// flags through four dependent global loads.
+enum { IN_INIT = 5 };
+struct WRec {
+    int64_t a_off;                      // float offset of A inside its region (dpre / dS / dz)
+    int64_t in_off;                     // float offset of the In source inside its region (hid / states)
+    int64_t slab_off;                   // float offset of this item's partial output inside the slabs
+    int32_t a_kind, lda, M, m0;
+    int32_t in_kind, in_enc, ldi, ncols;
+    int32_t n0, ntot, col_off, gate;
+    int32_t ks;
+    int16_t mt, nt, has_in, bias;
+    int32_t nks;                        // row-range splits of this item's task
+};
+struct WgArgs {
+    const WRec* recs;
+    const float* dpre; const float* dS; const float* dz; const float* states; const float* hid; const float* init;
+    float* slabs;
+    long long* stamps;
+    int32_t maxB, S;
 };
 
 struct Seg {                            // one gradient tensor
@@ -122,7 +146,7 @@ struct DevPlan {
     int32_t* nan_flags;       // [MMN_MAX_ENCODERS] NaN-found flag per data slot
     float* slabs; float* stats; double* epoch;
     long long* stamps;        // diagnostic phase timestamps (MMN_STAMPS=1), else nullptr
-    WTask* tasks; WItem* items; Seg* segs; PackTask* ptasks;
+    WTask* tasks; WItem* items; Seg* segs; PackTask* ptasks; WRec* recs;
     int32_t n_tasks, n_items, n_segs, n_ptasks;
     int64_t n_grad_elems, n_pack_elems;
 };
@@ -181,6 +205,35 @@ __device__ __forceinline__ float act_grad_from_out(float h, int kind) {
 
 __device__ __forceinline__ bool slot_present(const mmn_batch& b, int slot) {
     return b.nan_flags == nullptr || g_ldi(b.nan_flags + slot) == 0;
+}
+
+// The NaN flags of all data slots as one wave-uniform bit mask (bit = slot present), fetched ONCE
+// per kernel: a per-use global load would sit behind every outstanding weight prefetch (vmcnt is
+// in order), i.e. cost a full memory round trip at each phase boundary.
+__device__ __forceinline__ unsigned present_mask(const mmn_batch& b) {
+    if (b.nan_flags == nullptr) return 0xFFFFu;
+    const int v = g_ldi(b.nan_flags + (threadIdx.x & 15));
+    return (unsigned)(__ballot(v == 0) & 0xFFFFull);
+}
+__device__ __forceinline__ bool slot_present(unsigned pm, int slot) { return (pm >> slot) & 1u; }
+__device__ __forceinline__ int next_exec(const mmn_batch& b, unsigned pm, int t) {
+    while (t < b.n_seq && !slot_present(pm, b.seq_data[t])) ++t;
+    return t;
+}
+__device__ __forceinline__ bool row_executed(const mmn_batch& b, unsigned pm, int r) {
+    if (r == 0) return true;
+    for (int t = 0; t < b.n_seq; ++t)
+        if (b.seq_enc[t] == r - 1) return slot_present(pm, b.seq_data[t]);
+    return false;
+}
+__device__ __forceinline__ int prev_row_of(const mmn_batch& b, unsigned pm, int e) {
+    int prev_row = 0;
+    for (int u = 0, pr = 0; u < b.n_seq; ++u) {
+        if (!slot_present(pm, b.seq_data[u])) continue;
+        if (b.seq_enc[u] == e) prev_row = pr;
+        pr = b.seq_enc[u] + 1;
+    }
+    return prev_row;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -1737,6 +1790,7 @@ __global__ __launch_bounds__(NT8) void k_fwd8(const ParArgs a, const mmn_batch b
     constexpr int TB = 16;
     extern __shared__ __attribute__((aligned(16))) float smem_generic[];
     const lp smem = (lp)smem_generic;
+    const unsigned pm = present_mask(b);
     const int S = a.S, E = a.E, D = a.D, R = a.R, ldS = a.ldS, ldH = a.ldH, ldX = a.ldX;
     const Par8Lds L = par8_lds(R, E, ldS, ldH, ldX, false);
     const int tile = blockIdx.x, row0 = tile * TB;
@@ -1764,7 +1818,7 @@ __global__ __launch_bounds__(NT8) void k_fwd8(const ParArgs a, const mmn_batch b
         for (int e = 0; e < E; ++e) g_sti(a.exec_flags + e + 1, 0);
         int prev = 0;
         for (int t = 0; t < b.n_seq; ++t) {
-            if (!slot_present(b, b.seq_data[t])) continue;
+            if (!slot_present(pm, b.seq_data[t])) continue;
             const int e = b.seq_enc[t];
             g_sti(a.exec_flags + e + 1, 1);
             g_sti(a.prev_row + e, prev);
@@ -1802,7 +1856,7 @@ __global__ __launch_bounds__(NT8) void k_fwd8(const ParArgs a, const mmn_batch b
     }
     // chain step 0's W_s fragments (tile = wave) land during phase A
     f32x4 wsA[8], wsB[8];
-    const int t_first = next_exec(b, 0);
+    const int t_first = next_exec(b, pm, 0);
     if (t_first < b.n_seq && wave < ntS) {
         const ParEnc& pe = a.enc[b.seq_enc[t_first]];
         issue_t<8>(wsA, a.pack + pe.pkf[pe.Lh], T0 + ((pe.HL + 15) >> 4), ntS, wave, 0);
@@ -1812,13 +1866,13 @@ __global__ __launch_bounds__(NT8) void k_fwd8(const ParArgs a, const mmn_batch b
     // ---- phase A: u_e = W_x h_e + b for every executed encoder; wave pair g takes encoder t = tb + g
     for (int tb = 0; tb < b.n_seq; tb += 4) {
         const int t = tb + g;
-        const bool act = t < b.n_seq && slot_present(b, b.seq_data[min(t, b.n_seq - 1)]);
+        const bool act = t < b.n_seq && slot_present(pm, b.seq_data[min(t, b.n_seq - 1)]);
         const int e = act ? b.seq_enc[t] : 0;
         const ParEnc& pe = a.enc[e];
         const int Lh = pe.Lh, F = pe.F, HL = pe.HL, akind = pe.akind;
         int Lmax = 0;                                       // barrier count must be uniform over the workgroup
         for (int k = 0; k < 4; ++k)
-            if (tb + k < b.n_seq && slot_present(b, b.seq_data[tb + k])) Lmax = max(Lmax, a.enc[b.seq_enc[tb + k]].Lh);
+            if (tb + k < b.n_seq && slot_present(pm, b.seq_data[tb + k])) Lmax = max(Lmax, a.enc[b.seq_enc[tb + k]].Lh);
         const int f4 = round_up(F, 16) >> 2;               // float4 per image row (<= 32)
         const int TU = (HL + 15) >> 4;
         const float* pkU = a.pack + pe.pkf[Lh];
@@ -1962,7 +2016,7 @@ __global__ __launch_bounds__(NT8) void k_fwd8(const ParArgs a, const mmn_batch b
     {
         bool flip = false;
         for (int t = t_first; t < b.n_seq;) {
-            const int t_nxt = next_exec(b, t + 1);
+            const int t_nxt = next_exec(b, pm, t + 1);
             if (!flip) chain_step(wsA, wsB, t, t_nxt); else chain_step(wsB, wsA, t, t_nxt);
             flip = !flip;
             t = t_nxt;
@@ -1971,7 +2025,7 @@ __global__ __launch_bounds__(NT8) void k_fwd8(const ParArgs a, const mmn_batch b
     STAMP8();
 
     // ---- phase C: all decoders on all state rows (decoders.py:19-20, multimodn.py:141-157,176-191)
-    if (wave < R && row_executed(b, wave)) {
+    if (wave < R && row_executed(b, pm, wave)) {
         const clp sS = St + wave * TB * ldS;
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         consume_t<8>(z, sS, ldS, 0, wd, 0, T0);
@@ -1986,7 +2040,7 @@ __global__ __launch_bounds__(NT8) void k_fwd8(const ParArgs a, const mmn_batch b
         const int r = valid ? idx / (D * TB) : 0;
         const int rem = idx - r * D * TB;
         const int d = valid ? rem / TB : 0, row = rem & (TB - 1);
-        const bool live = valid && row < nrows && row_executed(b, r);
+        const bool live = valid && row < nrows && row_executed(b, pm, r);
         float lossv = 0.f;
         int correct = 0, tp = 0, tn = 0, fp = 0, fn = 0;
         if (live) {
@@ -2040,6 +2094,7 @@ __global__ __launch_bounds__(NT8) void k_bwd8(const ParArgs a, const mmn_batch b
     constexpr int TB = 16;
     extern __shared__ __attribute__((aligned(16))) float smem_generic[];
     const lp smem = (lp)smem_generic;
+    const unsigned pm = present_mask(b);
     const int S = a.S, E = a.E, D = a.D, R = a.R, ldS = a.ldS, ldH = a.ldH, ldX = a.ldX;
     const Par8Lds L = par8_lds(R, E, ldS, ldH, ldX, true);
     const int tile = blockIdx.x, row0 = tile * TB;
@@ -2059,7 +2114,7 @@ __global__ __launch_bounds__(NT8) void k_bwd8(const ParArgs a, const mmn_batch b
     // first chain step's W_s^T fragments (tile = wave)
     f32x4 wcA[8], wcB[8];
     int t_last = b.n_seq - 1;
-    while (t_last >= 0 && !slot_present(b, b.seq_data[t_last])) --t_last;
+    while (t_last >= 0 && !slot_present(pm, b.seq_data[t_last])) --t_last;
     if (t_last >= 0 && wave < ntS) {
         const ParEnc& pe = a.enc[b.seq_enc[t_last]];
         issue_t<8>(wcA, a.pack + pe.pkb[pe.Lh], T0, ntS, wave, 0);
@@ -2067,7 +2122,7 @@ __global__ __launch_bounds__(NT8) void k_bwd8(const ParArgs a, const mmn_batch b
 
     // ---- phase A': wave r owns state row r: d_e = s_out - s_in (e = r - 1), then
     //      DG[r] = dz[r] Wdec + cS d_e  (everything the chain adds to the carried gradient at row r)
-    if (wave < R && row_executed(b, wave)) {
+    if (wave < R && row_executed(b, pm, wave)) {
         const int r = wave;
         const lp out = DG + r * TB * ldS;
         // requests first, all branch-free
@@ -2086,7 +2141,7 @@ __global__ __launch_bounds__(NT8) void k_bwd8(const ParArgs a, const mmn_batch b
         if (r >= 1) {
             int prev_row = 0;
             for (int u = 0, pr = 0; u < b.n_seq; ++u) {
-                if (!slot_present(b, b.seq_data[u])) continue;
+                if (!slot_present(pm, b.seq_data[u])) continue;
                 if (b.seq_enc[u] == e) prev_row = pr;
                 pr = b.seq_enc[u] + 1;
             }
@@ -2153,7 +2208,7 @@ __global__ __launch_bounds__(NT8) void k_bwd8(const ParArgs a, const mmn_batch b
         bool flip = false;
         for (int t = t_last; t >= 0;) {
             int t_prv = t - 1;
-            while (t_prv >= 0 && !slot_present(b, b.seq_data[t_prv])) --t_prv;
+            while (t_prv >= 0 && !slot_present(pm, b.seq_data[t_prv])) --t_prv;
             if (!flip) chain_step(wcA, wcB, t, t_prv); else chain_step(wcB, wcA, t, t_prv);
             flip = !flip;
             t = t_prv;
@@ -2161,7 +2216,7 @@ __global__ __launch_bounds__(NT8) void k_bwd8(const ParArgs a, const mmn_batch b
     }
     // ---- stores: dS[e] = G_out(e), dS[E] = dS0 (final since the last barrier); fire and forget
     for (int r = 0; r < R; ++r) {
-        if (!row_executed(b, r)) continue;
+        if (!row_executed(b, pm, r)) continue;
         const int idx = r == 0 ? E : r - 1;
         for (int rr = wave; rr < nrows; rr += 8)
             for (int c = lane * 4; c < S; c += 256) {
@@ -2173,14 +2228,14 @@ __global__ __launch_bounds__(NT8) void k_bwd8(const ParArgs a, const mmn_batch b
     // ---- phase C': hidden-layer backward; wave pair g takes encoder t = tb + g, halves split the tiles
     for (int tb = 0; tb < b.n_seq; tb += 4) {
         const int t = tb + g;
-        const bool act0 = t < b.n_seq && slot_present(b, b.seq_data[min(t, b.n_seq - 1)]);
+        const bool act0 = t < b.n_seq && slot_present(pm, b.seq_data[min(t, b.n_seq - 1)]);
         const int e = act0 ? b.seq_enc[t] : 0;
         const ParEnc& pe = a.enc[e];
         const int Lh = pe.Lh, HL = pe.HL, akind = pe.akind;
         const bool act = act0 && Lh >= 1;
         int Lmax = 0;
         for (int k = 0; k < 4; ++k)
-            if (tb + k < b.n_seq && slot_present(b, b.seq_data[tb + k])) Lmax = max(Lmax, a.enc[b.seq_enc[tb + k]].Lh);
+            if (tb + k < b.n_seq && slot_present(pm, b.seq_data[tb + k])) Lmax = max(Lmax, a.enc[b.seq_enc[tb + k]].Lh);
         if (Lmax == 0) continue;
         const clp Go = DG + (e + 1) * TB * ldS;
         // dh = G_out W_x : tile = half of the <= 2 tiles of HL... HL may be up to 64 -> tiles half, half+2
@@ -2269,21 +2324,45 @@ __host__ __device__ inline Fb8Lds fb8_lds(int R, int ldS, int ldH, int ldX) {
     return L;
 }
 
-__device__ __forceinline__ int prev_row_of(const mmn_batch& b, int e) {
-    int prev_row = 0;
-    for (int u = 0, pr = 0; u < b.n_seq; ++u) {
-        if (!slot_present(b, b.seq_data[u])) continue;
-        if (b.seq_enc[u] == e) prev_row = pr;
-        pr = b.seq_enc[u] + 1;
+// Executed-sequence summary, wave-uniform (SGPRs), computed once per kernel from the kernarg
+// sequence and the NaN mask: everything the phases ask ("is row r live", "which row fed encoder
+// e", "k-th executed encoder") becomes a shift and a mask instead of a loop of scalar loads.
+struct ExecInfo {
+    unsigned rowmask;                 // bit r: state row r exists this step (bit 0 always)
+    int n;                            // executed encoders
+    unsigned long long enc, slot;     // 4 bits per executed step k: encoder id / data slot
+    unsigned long long prev;          // 4 bits per state row r >= 1: the row that fed encoder r-1
+    unsigned long long next;          // 4 bits per state row r: the row it feeds (0 = none)
+    __device__ __forceinline__ int e(int k) const { return (int)((enc >> (4 * k)) & 15ull); }
+    __device__ __forceinline__ int s(int k) const { return (int)((slot >> (4 * k)) & 15ull); }
+    __device__ __forceinline__ int prev_row(int r) const { return (int)((prev >> (4 * r)) & 15ull); }
+    __device__ __forceinline__ int next_row(int r) const { return (int)((next >> (4 * r)) & 15ull); }
+    __device__ __forceinline__ bool row(int r) const { return (rowmask >> r) & 1u; }
+};
+__device__ __forceinline__ ExecInfo exec_info(const mmn_batch& b, unsigned pm) {
+    ExecInfo x;
+    x.rowmask = 1u; x.n = 0; x.enc = 0ull; x.slot = 0ull; x.prev = 0ull; x.next = 0ull;
+    int prev = 0;
+    for (int t = 0; t < b.n_seq; ++t) {
+        const int slot = b.seq_data[t];
+        if (!slot_present(pm, slot)) continue;
+        const int e = b.seq_enc[t];
+        x.rowmask |= 2u << e;
+        x.prev |= (unsigned long long)prev << (4 * (e + 1));
+        x.next |= (unsigned long long)(e + 1) << (4 * prev);
+        x.enc |= (unsigned long long)e << (4 * x.n);
+        x.slot |= (unsigned long long)slot << (4 * x.n);
+        ++x.n;
+        prev = e + 1;
     }
-    return prev_row;
+    return x;
 }
 
 __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b, float cL, float cS) {
     constexpr int TB = 16;
-    constexpr int want_grads = 1;
     extern __shared__ __attribute__((aligned(16))) float smem_generic[];
     const lp smem = (lp)smem_generic;
+    const unsigned pm = present_mask(b);                   // first load in the queue
     const int S = a.S, E = a.E, D = a.D, R = a.R, ldS = a.ldS, ldH = a.ldH, ldX = a.ldX;
     const Fb8Lds L = fb8_lds(R, ldS, ldH, ldX);
     const lp sDzA = smem + L.sDzA;
@@ -2301,39 +2380,53 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
     int stamp_k = 0;
     const int stamp_block = 7;
     STAMP8();
-    if (a.needs_zero) {                                    // K-padding columns must be finite
-        for (int idx = threadIdx.x; idx < L.total; idx += NT8) lds_st(smem + idx, 0.f);
-        __syncthreads();
-    } else {                                               // dz tiles: unwritten entries must read as zero
-        for (int idx = threadIdx.x; idx < R * 16 * LDZ; idx += NT8) lds_st(sDzA + idx, 0.f);
-    }
-    for (int r = wave; r < TB; r += 8)                     // state row 0 = init state (state.py:29-32)
-        for (int c = lane; c < S; c += 64) lds_st(St + r * ldS + c, g_ld(a.init + c));
-    if (tile == 0 && threadIdx.x == 0) {                   // which state rows exist this step
-        g_sti(a.exec_flags, 1);
-        for (int e = 0; e < E; ++e) g_sti(a.exec_flags + e + 1, 0);
-        int prev = 0;
-        for (int t = 0; t < b.n_seq; ++t) {
-            if (!slot_present(b, b.seq_data[t])) continue;
-            const int e = b.seq_enc[t];
-            g_sti(a.exec_flags + e + 1, 1);
-            g_sti(a.prev_row + e, prev);
-            prev = e + 1;
-        }
-    }
     const int ntS = (S + 15) >> 4, T0 = a.S16 >> 4;
-    // decoder fragments: wave r evaluates state row r (R <= 8)
-    f32x4 wd[8];
+
+    // ---- requests, in the order they are needed (the memory pipe returns in order).  Wave pair g
+    //      owns sequence position g (n_seq <= E <= 4); whether that slot is present is only known
+    //      once the mask has landed, so the x tile and the pair's weights are requested regardless.
+    const int tA = min(g, max(b.n_seq - 1, 0));
+    const int slotA = b.seq_data[tA], eA = b.seq_enc[tA];
+    const ParEnc& pe = a.enc[eA];
+    const int Lh = pe.Lh, F = pe.F, HL = pe.HL, akind = pe.akind;
+    const int f4 = round_up(F, 16) >> 2;                   // float4 per image row (<= 32)
+    const int TU = (HL + 15) >> 4;
+    const float* pkU = a.pack + pe.pkf[Lh];
+    const bool inA = g < b.n_seq;
+    // Every request below is UNCONDITIONAL (clamped / dummy addresses, never a branch around a
+    // load): only then does hipcc keep counted vmcnt waits, i.e. lets a wave consume an early
+    // fragment while later prefetches are still in flight.
+    const int l0 = min(0, Lh), l1 = min(1, Lh);            // layers this encoder does not have alias lower ones
+    f32x4 xr[4], h0q[8], h1q[2], uq[2][4][2];
+    float hb0 = 0.f, hb1 = 0.f, ub[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     {
-        const bool rowok = i < 2 * D;
-        const float* w = a.dec_w[rowok ? (i >> 1) : 0] + (rowok ? (i & 1) * S : 0);
+        const float* xg = b.x[slotA] + (int64_t)row0 * b.ldx[slotA];
+        const int64_t ldx = b.ldx[slotA];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {                      // clamped address + select: no branch around a load
-            const int k = 16 * j + 4 * q;
-            const bool ok = rowok && k < S && j < T0;
-            const f32x4 v = g_ld4(w + (ok ? k : 0));
+        for (int k = 0; k < 4; ++k) {                      // this half's 8 rows of the x tile
+            const int idx = lane + 64 * k;
+            const int row = 8 * half + idx / f4, c = (idx % f4) << 2;
+            const bool ok = idx < 8 * f4 && row < nrows && c < F;
+            const f32x4 v = g_ld4(xg + (ok ? (int64_t)row * ldx + c : 0));
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            wd[j] = ok ? v : z;
+            xr[k] = ok ? v : z;
+        }
+        issue_t<8>(h0q, a.pack + pe.pkf[l0], (pe.in[l0] + 15) >> 4, (pe.out[l0] + 15) >> 4, half, 0);
+        hb0 = g_ld(pe.bias[l0] + min(16 * half + i, pe.out[l0] - 1));
+        issue_t<2>(h1q, a.pack + pe.pkf[l1], (pe.in[l1] + 15) >> 4, (pe.out[l1] + 15) >> 4, half, 0);
+        hb1 = g_ld(pe.bias[l1] + min(16 * half + i, pe.out[l1] - 1));
+    }
+    float init_v[2];                                       // state row 0 = init state (state.py:29-32)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) init_v[k] = g_ld(a.init + min(lane + 64 * k, S - 1));
+    {
+        const PB BU = make_pb(pkU, S, S, HL);
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int nn[2] = {16 * (4 * half + 2 * pr), 16 * (4 * half + 2 * pr + 1)};
+            issue_b<4>(uq[pr], BU, nn, BU.T0);             // tiles past S re-read the last tile
+            ub[pr][0] = g_ld(pe.bias[Lh] + min(nn[0] + i, S - 1));
+            ub[pr][1] = g_ld(pe.bias[Lh] + min(nn[1] + i, S - 1));
         }
     }
     // targets / decoder biases of this thread's (row r, decoder d, batch row) triple, first pass
@@ -2350,207 +2443,226 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
         bd0_pre = g_ld(a.dec_b[d]);
         bd1_pre = g_ld(a.dec_b[d] + 1);
     }
-    // chain step 0's W_s fragments (tile = wave) land during phase A
-    f32x4 wsA[8], wsB[8];
-    const int t_first = next_exec(b, 0);
-    if (t_first < b.n_seq && wave < ntS) {
-        const ParEnc& pe = a.enc[b.seq_enc[t_first]];
-        issue_t<8>(wsA, a.pack + pe.pkf[pe.Lh], T0 + ((pe.HL + 15) >> 4), ntS, wave, 0);
+
+    // ---- LDS init while the requests fly
+    if (a.needs_zero) {                                    // K-padding columns must be finite
+        for (int idx = threadIdx.x; idx < L.total; idx += NT8) lds_st(smem + idx, 0.f);
+        __syncthreads();
+    } else {                                               // dz tiles: unwritten entries must read as zero
+        for (int idx = threadIdx.x; idx < R * 16 * LDZ; idx += NT8) lds_st(sDzA + idx, 0.f);
     }
+    const ExecInfo X = exec_info(b, pm);                   // waits for the mask only
+    const bool act = inA && slot_present(pm, slotA);
+    int Lmax = 0;                                          // barrier counts must be uniform over the workgroup
+    for (int k = 0; k < X.n; ++k) Lmax = max(Lmax, a.enc[X.e(k)].Lh);
+    if (tile == 0 && threadIdx.x == 0) {                   // which state rows exist this step (k_wgrad / k_reduce)
+        for (int r = 0; r < R; ++r) g_sti(a.exec_flags + r, X.row(r) ? 1 : 0);
+        for (int k = 0; k < X.n; ++k) g_sti(a.prev_row + X.e(k), X.prev_row(X.e(k) + 1));
+    }
+    // chain weights of the first TWO steps (tile = wave); step k+2 is requested as soon as step k
+    // has been consumed, so every fetch has a whole step to land
+    f32x4 wsA[8], wsB[8];
+    auto issue_fwd = [&](f32x4 (&w)[8], int k) {           // past the last step: 8 reads of one hot KB
+        const bool ok = k < X.n;
+        const ParEnc& p2 = a.enc[X.e(ok ? k : 0)];
+        issue_t<8>(w, a.pack + (ok ? p2.pkf[p2.Lh] : 0), ok ? T0 + ((p2.HL + 15) >> 4) : 1, ok ? ntS : 1, wave, 0);
+    };
+    issue_fwd(wsA, 0);
+    issue_fwd(wsB, 1);
+    {                                                      // x -> the pair's LDS image
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = lane + 64 * k;
+            if (idx < 8 * f4) lds_st4(sXg + (8 * half + idx / f4) * ldX + ((idx % f4) << 2), xr[k]);
+        }
+    }
+    for (int r = wave; r < TB; r += 8)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (lane + 64 * k < S) lds_st(St + r * ldS + lane + 64 * k, init_v[k]);
+    __syncthreads();
     STAMP8();
 
-    // ---- phase A: u_e = W_x h_e + b for every executed encoder; wave pair g takes encoder t = tb + g
-    for (int tb = 0; tb < b.n_seq; tb += 4) {
-        const int t = tb + g;
-        const bool act = t < b.n_seq && slot_present(b, b.seq_data[min(t, b.n_seq - 1)]);
-        const int e = act ? b.seq_enc[t] : 0;
-        const ParEnc& pe = a.enc[e];
-        const int Lh = pe.Lh, F = pe.F, HL = pe.HL, akind = pe.akind;
-        int Lmax = 0;                                       // barrier count must be uniform over the workgroup
-        for (int k = 0; k < 4; ++k)
-            if (tb + k < b.n_seq && slot_present(b, b.seq_data[tb + k])) Lmax = max(Lmax, a.enc[b.seq_enc[tb + k]].Lh);
-        const int f4 = round_up(F, 16) >> 2;               // float4 per image row (<= 32)
-        const int TU = (HL + 15) >> 4;
-        const float* pkU = a.pack + pe.pkf[Lh];
-        // -- request everything this wave will consume in this round
-        f32x4 xr[4], h0q[8], h1q[2], uq[2][4][2];
-        float hb0 = 0.f, hb1 = 0.f, ub[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-        if (act) {
-            const int slot = b.seq_data[t];
-            const float* xg = b.x[slot] + (int64_t)row0 * b.ldx[slot];
-            const int64_t ldx = b.ldx[slot];
+    // ---- phase A: u_e = W_x h_e + b of this pair's encoder
+    if (Lmax >= 1) {                                       // hidden layer 0 (mlp_encoder.py:75-76), tile = half
+        if (act && Lh >= 1 && 16 * half < pe.out[0]) {
+            const int N = pe.out[0], T = (pe.in[0] + 15) >> 4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            consume_t<8>(acc, sXg, ldX, 0, h0q, 0, T);
+            const int col = 16 * half + i;
+            if (col < N) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {                  // this half's 8 rows of the x tile
-                const int idx = lane + 64 * k;
-                const int row = 8 * half + idx / f4, c = (idx % f4) << 2;
-                const bool ok = idx < 8 * f4 && row < nrows && c < F;
-                const f32x4 v = g_ld4(xg + (ok ? (int64_t)row * ldx + c : 0));
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                xr[k] = ok ? v : z;
-            }
-            if (Lh >= 1) {
-                issue_t<8>(h0q, a.pack + pe.pkf[0], (pe.in[0] + 15) >> 4, (pe.out[0] + 15) >> 4, half, 0);
-                hb0 = g_ld(pe.bias[0] + min(16 * half + i, pe.out[0] - 1));
-            }
-            if (Lh >= 2) {
-                issue_t<2>(h1q, a.pack + pe.pkf[1], (pe.in[1] + 15) >> 4, (pe.out[1] + 15) >> 4, half, 0);
-                hb1 = g_ld(pe.bias[1] + min(16 * half + i, pe.out[1] - 1));
-            }
-            const PB BU = make_pb(pkU, S, S, HL);
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int nn[2] = {16 * (4 * half + 2 * pr), 16 * (4 * half + 2 * pr + 1)};
-                if (nn[0] < S) {
-                    issue_b<4>(uq[pr], BU, nn, BU.T0);
-                    ub[pr][0] = g_ld(pe.bias[Lh] + min(nn[0] + i, S - 1));
-                    ub[pr][1] = g_ld(pe.bias[Lh] + min(nn[1] + i, S - 1));
-                }
-            }
-            // -- x -> the pair's LDS image
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int idx = lane + 64 * k;
-                if (idx < 8 * f4) lds_st4(sXg + (8 * half + idx / f4) * ldX + ((idx % f4) << 2), xr[k]);
+                for (int k = 0; k < 4; ++k) lds_st(sHg[0] + (4 * q + k) * ldH + col, act_fwd(acc[k] + hb0, akind));
             }
         }
         __syncthreads();
-        if (Lmax >= 1) {                                   // hidden layer 0 (mlp_encoder.py:75-76), tile = half
-            if (act && Lh >= 1 && 16 * half < pe.out[0]) {
-                const int N = pe.out[0], T = (pe.in[0] + 15) >> 4;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                consume_t<8>(acc, sXg, ldX, 0, h0q, 0, T);
-                const int col = 16 * half + i;
-                if (col < N) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) lds_st(sHg[0] + (4 * q + k) * ldH + col, act_fwd(acc[k] + hb0, akind));
-                }
-            }
-            __syncthreads();
-            if (act && Lh >= 1 && want_grads) {            // each half stores 8 rows of the tile
-                const int N = pe.out[0];
-                const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
-                wave_store_tile(a.hid + pe.hid[0] + (int64_t)(row0 + r0) * N, sHg[0] + r0 * ldH, ldH, nr, N);
-            }
+        STAMP8();
+        if (act && Lh >= 1) {                              // each half stores 8 rows of the tile
+            const int N = pe.out[0];
+            const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
+            wave_store_tile(a.hid + pe.hid[0] + (int64_t)(row0 + r0) * N, sHg[0] + r0 * ldH, ldH, nr, N);
         }
-        if (Lmax >= 2) {
-            if (act && Lh >= 2 && 16 * half < pe.out[1]) {
-                const int N = pe.out[1], T = (pe.in[1] + 15) >> 4;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                consume_t<2>(acc, sHg[0], ldH, 0, h1q, 0, T);
-                const int col = 16 * half + i;
-                if (col < N) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) lds_st(sHg[1] + (4 * q + k) * ldH + col, act_fwd(acc[k] + hb1, akind));
-                }
-            }
-            __syncthreads();
-            if (act && Lh >= 2 && want_grads) {
-                const int N = pe.out[1];
-                const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
-                wave_store_tile(a.hid + pe.hid[1] + (int64_t)(row0 + r0) * N, sHg[1] + r0 * ldH, ldH, nr, N);
-            }
-        }
-        if (act) {                                         // u_e = W_x h + b (mlp_encoder.py:78), this half's 4 tiles
-            clp in = Lh == 0 ? (clp)sXg : (clp)sHg[Lh - 1];
-            const int ldin = Lh == 0 ? ldX : ldH;
-            const lp U = Ut + e * TB * ldS;
-            const PB BU = make_pb(pkU, S, S, HL);
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int nn[2] = {16 * (4 * half + 2 * pr), 16 * (4 * half + 2 * pr + 1)};
-                if (nn[0] < S) {
-                    f32x4 acc[2][1];
-                    zero_acc<1>(acc);
-                    consume_b<1, 4>(acc, ASrc{in, ldin, in, ldin}, BU, uq[pr], BU.T0, BU.T0 + TU, nn[1] < S);
-                    run_epilogue<1>(acc, nn, S, [&](int row, int col, int c, float v) {
-                        if (col < S) lds_st(U + row * ldS + col, v + ub[pr][c]);
-                    });
-                }
-            }
-        }
-        __syncthreads();                                    // scratch is reused by the next round
     }
+    if (Lmax >= 2) {
+        if (act && Lh >= 2 && 16 * half < pe.out[1]) {
+            const int N = pe.out[1], T = (pe.in[1] + 15) >> 4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            consume_t<2>(acc, sHg[0], ldH, 0, h1q, 0, T);
+            const int col = 16 * half + i;
+            if (col < N) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lds_st(sHg[1] + (4 * q + k) * ldH + col, act_fwd(acc[k] + hb1, akind));
+            }
+        }
+        __syncthreads();
+        STAMP8();
+        if (act && Lh >= 2) {
+            const int N = pe.out[1];
+            const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
+            wave_store_tile(a.hid + pe.hid[1] + (int64_t)(row0 + r0) * N, sHg[1] + r0 * ldH, ldH, nr, N);
+        }
+    }
+    if (act) {                                             // u_e = W_x h + b (mlp_encoder.py:78), this half's 4 tiles
+        clp in = Lh == 0 ? (clp)sXg : (clp)sHg[Lh - 1];
+        const int ldin = Lh == 0 ? ldX : ldH;
+        const lp U = Ut + eA * TB * ldS;
+        const PB BU = make_pb(pkU, S, S, HL);
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int nn[2] = {16 * (4 * half + 2 * pr), 16 * (4 * half + 2 * pr + 1)};
+            if (nn[0] < S) {
+                f32x4 acc[2][1];
+                zero_acc<1>(acc);
+                consume_b<1, 4>(acc, ASrc{in, ldin, in, ldin}, BU, uq[pr], BU.T0, BU.T0 + TU, nn[1] < S);
+                run_epilogue<1>(acc, nn, S, [&](int row, int col, int c, float v) {
+                    if (col < S) lds_st(U + row * ldS + col, v + ub[pr][c]);
+                });
+            }
+        }
+    }
+    // decoder fragments: wave r evaluates state row r (R <= 8); needed in phase C
+    f32x4 wd[8];
+    {
+        const bool rowok = i < 2 * D;
+        const float* w = a.dec_w[rowok ? (i >> 1) : 0] + (rowok ? (i & 1) * S : 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                      // clamped address + select: no branch around a load
+            const int k = 16 * j + 4 * q;
+            const bool ok = rowok && k < S && j < T0;
+            const f32x4 v = g_ld4(w + (ok ? k : 0));
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            wd[j] = ok ? v : z;
+        }
+    }
+    __syncthreads();
     STAMP8();
 
-    // ---- phase B: s' = W_s s + u_e; one column tile per wave, fragments one step ahead
+    // ---- phase B: s' = W_s s + u_e; one column tile per wave.  The accumulator starts from the u_e
+    //      tile, so the epilogue is the LDS write of the new state tile alone; the state-change sums
+    //      and the global copies of the tiles (for k_wgrad) happen off this critical path.
     int cur = 0;
-    auto chain_step = [&](f32x4 (&wc)[8], f32x4 (&wn)[8], int t, int t_nxt) {
-        const int e = b.seq_enc[t];
+    auto store_state = [&](int e) {                         // each wave stores two rows of state tile e+1
+        const clp sN = St + (e + 1) * TB * ldS;
+        for (int r = wave; r < nrows; r += 8)
+            for (int c = lane * 4; c < S; c += 256) {
+                if (((S & 3) == 0)) g_st4(a.states + ((int64_t)e * a.maxB + row0 + r) * S + c, lds_ld4(sN + r * ldS + c));
+                else for (int kk = 0; kk < 4 && c + kk < S; ++kk) g_st(a.states + ((int64_t)e * a.maxB + row0 + r) * S + c + kk, lds_ld(sN + r * ldS + c + kk));
+            }
+    };
+    auto chain_step = [&](f32x4 (&wc)[8], int k) {
+        const int e = X.e(k);
         const clp sC = St + cur * TB * ldS;
         const lp sN = St + (e + 1) * TB * ldS;
         const clp U = Ut + e * TB * ldS;
-        float scacc = 0.f;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int col = 16 * wave + i, colc = min(col, S - 1);
+        f32x4 acc;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc[kk] = lds_ld(U + (4 * q + kk) * ldS + colc);
         if (wave < ntS) consume_t<8>(acc, sC, ldS, 0, wc, 0, T0);
-        if (t_nxt < b.n_seq && wave < ntS) {
-            const ParEnc& p2 = a.enc[b.seq_enc[t_nxt]];
-            issue_t<8>(wn, a.pack + p2.pkf[p2.Lh], T0 + ((p2.HL + 15) >> 4), ntS, wave, 0);
-        }
-        const int col = 16 * wave + i;
+        issue_fwd(wc, k + 2);
+        if (k > 0) store_state(X.e(k - 1));                 // the previous tile, underneath the MFMAs
         if (wave < ntS && col < S) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int row = 4 * q + k;
-                const float ns = acc[k] + lds_ld(U + row * ldS + col);
-                const float dlt = ns - lds_ld(sC + row * ldS + col);
-                if (row < nrows) scacc += dlt * dlt;              // multimodn.py:174
-                lds_st(sN + row * ldS + col, ns);
-            }
+            for (int kk = 0; kk < 4; ++kk) lds_st(sN + (4 * q + kk) * ldS + col, acc[kk]);
         }
-        scacc = wave_sum(scacc);
-        if (lane == 0) lds_st(sRed + 8 * e + wave, scacc);
         __syncthreads();
-        if (want_grads) {                                   // each wave stores two rows of the new state tile
-            for (int r = wave; r < nrows; r += 8)
-                for (int c = lane * 4; c < S; c += 256) {
-                    if (((S & 3) == 0)) g_st4(a.states + ((int64_t)e * a.maxB + row0 + r) * S + c, lds_ld4(sN + r * ldS + c));
-                    else for (int k = 0; k < 4 && c + k < S; ++k) g_st(a.states + ((int64_t)e * a.maxB + row0 + r) * S + c + k, lds_ld(sN + r * ldS + c + k));
-                }
-        }
+        STAMP8();
         cur = e + 1;
     };
-    {
-        bool flip = false;
-        for (int t = t_first; t < b.n_seq;) {
-            const int t_nxt = next_exec(b, t + 1);
-            if (!flip) chain_step(wsA, wsB, t, t_nxt); else chain_step(wsB, wsA, t, t_nxt);
-            flip = !flip;
-            t = t_nxt;
+    if (X.n >= 1) {                                        // nested, not a loop: each wait sees one straight path
+        chain_step(wsA, 0);
+        if (X.n >= 2) {
+            chain_step(wsB, 1);
+            if (X.n >= 3) {
+                chain_step(wsA, 2);
+                if (X.n >= 4) chain_step(wsB, 3);
+            }
         }
     }
     STAMP8();
-    // backward chain, first step: W_s^T fragments (tile = wave) land during the decoder grid
-    f32x4 wcA[8], wcB[8];
-    int t_last = b.n_seq - 1;
-    while (t_last >= 0 && !slot_present(b, b.seq_data[t_last])) --t_last;
-    if (t_last >= 0 && wave < ntS) {
-        const ParEnc& pe = a.enc[b.seq_enc[t_last]];
-        issue_t<8>(wcA, a.pack + pe.pkb[pe.Lh], T0, ntS, wave, 0);
+    // ---- phase C: all decoders on all state rows (decoders.py:19-20, multimodn.py:141-157,176-191);
+    //      waves 0..R-1 take one row each, the others the state-change sums (multimodn.py:174)
+    if (wave < R) {
+        if (X.row(wave)) {
+            const clp sS = St + wave * TB * ldS;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            consume_t<8>(z, sS, ldS, 0, wd, 0, T0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lds_st(sZ + (wave * TB + q * 4 + k) * 16 + i, z[k]);
+        }
     }
-    // dh fragments of this pair's encoder (hidden-layer backward), requested early as well
-    const int tC = g;                                       // E <= 4: one encoder per wave pair
-    const bool actC0 = tC < b.n_seq && slot_present(b, b.seq_data[min(tC, max(b.n_seq - 1, 0))]);
-    const int eC = actC0 ? b.seq_enc[tC] : 0;
-    const ParEnc& peC = a.enc[eC];
-    const bool actC = actC0 && peC.Lh >= 1;
+    // sum over the tile of (s_r - s_prev(r))^2, fixed order: lane -> (row = lane / 4, 4 column
+    // groups), then a butterfly; rows are dealt to the waves that have no decoder row (or to all
+    // waves when R == 8)
+    {
+        const int nidle = R < 8 ? 8 - R : 8, first = R < 8 ? R : 0;
+        if (wave >= first) {
+            for (int r = 1 + (wave - first); r < R; r += nidle) {
+                if (!X.row(r)) continue;
+                const clp sr = St + r * TB * ldS, sp = St + X.prev_row(r) * TB * ldS;
+                const int row = lane >> 2;
+                float sc = 0.f;
+                if (row < nrows) {
+                    for (int c = (lane & 3) * 4; c < S; c += 16) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            if (c + kk < S) {
+                                const float dlt = lds_ld(sr + row * ldS + c + kk) - lds_ld(sp + row * ldS + c + kk);
+                                sc += dlt * dlt;
+                            }
+                        }
+                    }
+                }
+                sc = wave_sum(sc);
+                if (lane == 0) g_st(a.scp + (int64_t)tile * E + (r - 1), sc);
+            }
+        }
+    }
+    if (X.n >= 1) store_state(X.e(X.n - 1));                // the last state tile
+    // ---- backward requests: the Wdec^T fragment of this wave's column tile (one k-step: 2D <= 16),
+    //      the W_s^T fragments of the first two reverse steps (tile = wave) and the dh fragments of
+    //      this pair's encoder; they land during the decoder grid
+    f32x4 wcA[8], wcB[8];
+    auto issue_bwd = [&](f32x4 (&w)[8], int j) {            // j-th reverse step = executed step n-1-j
+        const bool ok = j < X.n;
+        const ParEnc& p2 = a.enc[X.e(ok ? X.n - 1 - j : 0)];
+        issue_t<8>(w, a.pack + (ok ? p2.pkb[p2.Lh] : 0), ok ? T0 : 1, ok ? ntS : 1, wave, 0);
+    };
+    f32x4 wdzq[1];
+    issue_t<1>(wdzq, a.pack + a.pkd, 1, ntS, wave, 0);
+    issue_bwd(wcA, 0);
+    issue_bwd(wcB, 1);
+    const bool actC = act && Lh >= 1;                       // E <= 4: one encoder per wave pair
     f32x4 hqC[2][8], h1qC[2];
-    if (actC) {
+    {
+        const bool okh = Lh >= 1, ok1 = Lh >= 2;
 #pragma unroll
         for (int k = 0; k < 2; ++k)
-            if (16 * (half + 2 * k) < peC.HL) issue_t<8>(hqC[k], a.pack + peC.pkh, T0, (peC.HL + 15) >> 4, half + 2 * k, 0);
-        if (peC.Lh >= 2 && 16 * half < peC.in[1])
-            issue_t<2>(h1qC, a.pack + peC.pkb[1], (peC.out[1] + 15) >> 4, (peC.in[1] + 15) >> 4, half, 0);
-    }
-
-    // ---- phase C: all decoders on all state rows (decoders.py:19-20, multimodn.py:141-157,176-191)
-    if (wave < R && row_executed(b, wave)) {
-        const clp sS = St + wave * TB * ldS;
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        consume_t<8>(z, sS, ldS, 0, wd, 0, T0);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) lds_st(sZ + (wave * TB + q * 4 + k) * 16 + i, z[k]);
+            issue_t<8>(hqC[k], a.pack + (okh ? pe.pkh : 0), okh ? T0 : 1, okh ? (HL + 15) >> 4 : 1, half + 2 * k, 0);
+        issue_t<2>(h1qC, a.pack + (ok1 ? pe.pkb[1] : 0), ok1 ? (pe.out[1] + 15) >> 4 : 1, ok1 ? (pe.in[1] + 15) >> 4 : 1, half, 0);
     }
     __syncthreads();
+    STAMP8();
     const int total = R * D * TB;
     for (int base = 0; base < total; base += NT8) {
         const int idx = base + threadIdx.x;
@@ -2558,7 +2670,7 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
         const int r = valid ? idx / (D * TB) : 0;
         const int rem = idx - r * D * TB;
         const int d = valid ? rem / TB : 0, row = rem & (TB - 1);
-        const bool live = valid && row < nrows && row_executed(b, r);
+        const bool live = valid && row < nrows && X.row(r);
         float lossv = 0.f;
         int correct = 0, tp = 0, tn = 0, fp = 0, fn = 0;
         if (live) {
@@ -2575,16 +2687,14 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
             const int pred = o1 > o0 ? 1 : 0;      // torch.max: first index wins ties
             correct = pred == y;
             tp = pred & y; tn = (1 - pred) & (1 - y); fp = pred & (1 - y); fn = (1 - pred) & y;
-            if (want_grads) {
-                const float g0 = expf(o0 - lse) - (y == 0 ? 1.0f : 0.0f);
-                const float g1 = expf(o1 - lse) - (y == 1 ? 1.0f : 0.0f);
-                f32x2 dzv;
-                dzv.x = cL * g0 * o0 * (1.0f - o0);
-                dzv.y = cL * g1 * o1 * (1.0f - o1);
-                g_st2(a.dz + ((int64_t)r * a.maxB + grow) * (2 * D) + 2 * d, dzv);
-                lds_st(sDzA + (r * TB + row) * LDZ + 2 * d, dzv.x);
-                lds_st(sDzA + (r * TB + row) * LDZ + 2 * d + 1, dzv.y);
-            }
+            const float g0 = expf(o0 - lse) - (y == 0 ? 1.0f : 0.0f);
+            const float g1 = expf(o1 - lse) - (y == 1 ? 1.0f : 0.0f);
+            f32x2 dzv;
+            dzv.x = cL * g0 * o0 * (1.0f - o0);
+            dzv.y = cL * g1 * o1 * (1.0f - o1);
+            g_st2(a.dz + ((int64_t)r * a.maxB + grow) * (2 * D) + 2 * d, dzv);
+            lds_st(sDzA + (r * TB + row) * LDZ + 2 * d, dzv.x);
+            lds_st(sDzA + (r * TB + row) * LDZ + 2 * d + 1, dzv.y);
         }
 #pragma unroll
         for (int off = TB / 2; off >= 1; off >>= 1) lossv += __shfl_xor(lossv, off);
@@ -2602,135 +2712,138 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
             g_sti(cp + 4, __popcll((mfn >> sh) & 0xFFFFull));
         }
     }
-    for (int e = threadIdx.x; e < E; e += NT8) {            // state-change partials, fixed order
-        float s = 0.f;
-        for (int w = 0; w < 8; ++w) s += lds_ld(sRed + 8 * e + w);
-        g_st(a.scp + (int64_t)tile * E + e, s);
-    }
+    for (int e = threadIdx.x; e < E; e += NT8)              // encoders that did not run: zero state change
+        if (!X.row(e + 1)) g_st(a.scp + (int64_t)tile * E + e, 0.f);
     __syncthreads();                                        // dz tiles complete; u_e tiles dead
     STAMP8();
 
     // ======================= backward half =======================
     const lp DG = smem + L.sU;                              // R tiles: decoder grad -> G_out, in place
-    // ---- phase A': wave r owns state row r: DG[r] = dz[r] Wdec + cS (s_r - s_prev(r))
-    if (wave < R && row_executed(b, wave)) {
-        const int r = wave;
-        const lp out = DG + r * TB * ldS;
-        const clp sr = St + r * TB * ldS;
-        const clp sp = St + (r >= 1 ? prev_row_of(b, r - 1) : 0) * TB * ldS;
-        const clp dzt = sDzA + r * TB * LDZ;
-        const PB Bdz = make_pb(a.pack + a.pkd, S, 2 * D, 0);      // W' = Wdec^T [S x 2D]
-        wave_layer(ASrc{dzt, LDZ, dzt, LDZ}, Bdz, 0, Bdz.T, [&](int row, int col, float v) {
-            if (col < S) {
-                const float dlt = r >= 1 ? lds_ld(sr + row * ldS + col) - lds_ld(sp + row * ldS + col) : 0.f;
-                lds_st(out + row * ldS + col, (row < nrows) ? v + cS * dlt : 0.f);
-            }
-        });
-    }
-    __syncthreads();
-    // ---- phase B': carry' = G_out W_s - cS d_e; the next row's G_out is formed in the same epilogue
-    {
-        auto chain_step = [&](f32x4 (&wc)[8], f32x4 (&wn)[8], int t, int t_prv) {
-            const int e = b.seq_enc[t];
-            const clp Go = DG + (e + 1) * TB * ldS;
-            const clp so = St + (e + 1) * TB * ldS;
-            const clp sp = St + (t_prv >= 0 ? b.seq_enc[t_prv] + 1 : 0) * TB * ldS;   // state that fed encoder e
-            const int r_nxt = t_prv >= 0 ? b.seq_enc[t_prv] + 1 : 0;
-            const lp Gx = DG + r_nxt * TB * ldS;
+    // ---- phase A': DG[r] = dz[r] Wdec + cS (s_r - s_prev(r)) - cS (s_next(r) - s_r): the decoder
+    //      gradient plus BOTH state-change terms that touch row r, so the reverse chain only adds
+    //      the carry.  Wave w forms column tile w of every executed row from ONE Wdec^T fragment.
+    if (wave < ntS) {
+        const int col = 16 * wave + i;
+        for (int r = 0; r < R; ++r) {
+            if (!X.row(r)) continue;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (wave < ntS) consume_t<8>(acc, Go, ldS, 0, wc, 0, T0);
-            if (t_prv >= 0 && wave < ntS) {
-                const ParEnc& p2 = a.enc[b.seq_enc[t_prv]];
-                issue_t<8>(wn, a.pack + p2.pkb[p2.Lh], T0, ntS, wave, 0);
-            }
-            const int col = 16 * wave + i;
-            if (wave < ntS && col < S) {
+            consume_t<1>(acc, sDzA + r * TB * LDZ, LDZ, 0, wdzq, 0, 1);
+            const lp out = DG + r * TB * ldS;
+            const clp sr = St + r * TB * ldS;
+            const clp sp = St + X.prev_row(r) * TB * ldS;
+            const int rn = X.next_row(r);
+            const clp sn = St + rn * TB * ldS;
+            if (col < S) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int row = 4 * q + k;
-                    const float dlt = row < nrows ? lds_ld(so + row * ldS + col) - lds_ld(sp + row * ldS + col) : 0.f;
-                    lds_st(Gx + row * ldS + col, lds_ld(Gx + row * ldS + col) + (acc[k] - cS * dlt));
+                    const float sv = lds_ld(sr + row * ldS + col);
+                    float dlt = r >= 1 ? sv - lds_ld(sp + row * ldS + col) : 0.f;
+                    if (rn) dlt -= lds_ld(sn + row * ldS + col) - sv;
+                    lds_st(out + row * ldS + col, (row < nrows) ? acc[k] + cS * dlt : 0.f);
                 }
             }
-            __syncthreads();
-        };
-        bool flip = false;
-        for (int t = t_last; t >= 0;) {
-            int t_prv = t - 1;
-            while (t_prv >= 0 && !slot_present(b, b.seq_data[t_prv])) --t_prv;
-            if (!flip) chain_step(wcA, wcB, t, t_prv); else chain_step(wcB, wcA, t, t_prv);
-            flip = !flip;
-            t = t_prv;
         }
     }
-    // ---- stores: dS[e] = G_out(e), dS[E] = dS0 (final since the last barrier); fire and forget
-    for (int r = 0; r < R; ++r) {
-        if (!row_executed(b, r)) continue;
-        const int idx = r == 0 ? E : r - 1;
+    __syncthreads();
+    STAMP8();
+    // ---- phase B': G_out(prev row) += G_out(e) W_s; the accumulator starts from the target tile.
+    //      G_out(e) is final when its step starts: its rows go out as dS[e] underneath the MFMAs.
+    auto store_row = [&](int r, int idx) {
         for (int rr = wave; rr < nrows; rr += 8)
             for (int c = lane * 4; c < S; c += 256) {
                 if ((S & 3) == 0) g_st4(a.dS + ((int64_t)idx * a.maxB + row0 + rr) * S + c, lds_ld4(DG + (r * TB + rr) * ldS + c));
                 else for (int k = 0; k < 4 && c + k < S; ++k) g_st(a.dS + ((int64_t)idx * a.maxB + row0 + rr) * S + c + k, lds_ld(DG + (r * TB + rr) * ldS + c + k));
             }
-    }
-    // ---- phase C': hidden-layer backward of this pair's encoder; h_0 / h_1 are still in the pair's
-    //      LDS scratch, so act' is applied in the GEMM epilogue and dpre overwrites h in place
+    };
     {
-        int LmaxC = 0;
-        for (int k = 0; k < 4; ++k)
-            if (k < b.n_seq && slot_present(b, b.seq_data[k])) LmaxC = max(LmaxC, a.enc[b.seq_enc[k]].Lh);
-        if (LmaxC >= 1) {
-            const int Lh = peC.Lh, HL = peC.HL, akind = peC.akind;
-            if (actC) {
-                const clp Go = DG + (eC + 1) * TB * ldS;
-                const lp hb = sHg[Lh - 1];                  // h_{Lh-1} in, dpre_{Lh-1} out
+        auto chain_step = [&](f32x4 (&wc)[8], int j) {
+            const int e = X.e(X.n - 1 - j);
+            const int r_nxt = X.prev_row(e + 1);            // state that fed encoder e
+            const clp Go = DG + (e + 1) * TB * ldS;
+            const lp Gx = DG + r_nxt * TB * ldS;
+            const int col = 16 * wave + i, colc = min(col, S - 1);
+            f32x4 acc;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int tl = half + 2 * k;
-                    if (16 * tl < HL) {
-                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                        consume_t<8>(acc, Go, ldS, 0, hqC[k], 0, T0);
-                        const int col = 16 * tl + i;
-                        if (col < HL) {
+            for (int k = 0; k < 4; ++k) acc[k] = lds_ld(Gx + (4 * q + k) * ldS + colc);
+            if (wave < ntS) consume_t<8>(acc, Go, ldS, 0, wc, 0, T0);
+            issue_bwd(wc, j + 2);
+            store_row(e + 1, e);
+            if (wave < ntS && col < S) {
 #pragma unroll
-                            for (int kk = 0; kk < 4; ++kk) {
-                                const int row = 4 * q + kk;
-                                const float h = lds_ld(hb + row * ldH + col);
-                                lds_st(hb + row * ldH + col, row < nrows ? acc[kk] * act_grad_from_out(h, akind) : 0.f);
-                            }
-                        }
-                    }
-                }
+                for (int k = 0; k < 4; ++k) lds_st(Gx + (4 * q + k) * ldS + col, acc[k]);
             }
             __syncthreads();
-            if (actC) {
-                const int N = peC.out[Lh - 1];
-                const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
-                wave_store_tile(a.dpre + peC.hid[Lh - 1] + (int64_t)(row0 + r0) * N, sHg[Lh - 1] + r0 * ldH, ldH, nr, N);
-            }
-            if (LmaxC >= 2) {
-                if (actC && Lh >= 2 && 16 * half < peC.in[1]) {   // dpre_0 = (dpre_1 W_1) .* act'(h_0), tile = half
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    consume_t<2>(acc, sHg[1], ldH, 0, h1qC, 0, (peC.out[1] + 15) >> 4);
-                    const int col = 16 * half + i;
-                    if (col < peC.in[1]) {
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            const int row = 4 * q + kk;
-                            const float h = lds_ld(sHg[0] + row * ldH + col);
-                            lds_st(sHg[0] + row * ldH + col, row < nrows ? acc[kk] * act_grad_from_out(h, akind) : 0.f);
-                        }
-                    }
-                }
-                __syncthreads();
-                if (actC && Lh >= 2) {
-                    const int N = peC.out[0];
-                    const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
-                    wave_store_tile(a.dpre + peC.hid[0] + (int64_t)(row0 + r0) * N, sHg[0] + r0 * ldH, ldH, nr, N);
+            STAMP8();
+        };
+        if (X.n >= 1) {
+            chain_step(wcA, 0);
+            if (X.n >= 2) {
+                chain_step(wcB, 1);
+                if (X.n >= 3) {
+                    chain_step(wcA, 2);
+                    if (X.n >= 4) chain_step(wcB, 3);
                 }
             }
         }
     }
+    store_row(0, E);                                        // dS0 (final since the last barrier)
+    STAMP8();
+    // ---- phase C': hidden-layer backward of this pair's encoder; h_0 / h_1 are still in the pair's
+    //      LDS scratch, so act' is applied in the GEMM epilogue and dpre overwrites h in place
+    if (Lmax >= 1) {
+        if (actC) {
+            const clp Go = DG + (eA + 1) * TB * ldS;
+            const lp hb = sHg[Lh - 1];                      // h_{Lh-1} in, dpre_{Lh-1} out
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int tl = half + 2 * k;
+                if (16 * tl < HL) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    consume_t<8>(acc, Go, ldS, 0, hqC[k], 0, T0);
+                    const int col = 16 * tl + i;
+                    if (col < HL) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const int row = 4 * q + kk;
+                            const float h = lds_ld(hb + row * ldH + col);
+                            lds_st(hb + row * ldH + col, row < nrows ? acc[kk] * act_grad_from_out(h, akind) : 0.f);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        STAMP8();
+        if (actC) {
+            const int N = pe.out[Lh - 1];
+            const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
+            wave_store_tile(a.dpre + pe.hid[Lh - 1] + (int64_t)(row0 + r0) * N, sHg[Lh - 1] + r0 * ldH, ldH, nr, N);
+        }
+        if (Lmax >= 2) {
+            if (actC && Lh >= 2 && 16 * half < pe.in[1]) {   // dpre_0 = (dpre_1 W_1) .* act'(h_0), tile = half
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                consume_t<2>(acc, sHg[1], ldH, 0, h1qC, 0, (pe.out[1] + 15) >> 4);
+                const int col = 16 * half + i;
+                if (col < pe.in[1]) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int row = 4 * q + kk;
+                        const float h = lds_ld(sHg[0] + row * ldH + col);
+                        lds_st(sHg[0] + row * ldH + col, row < nrows ? acc[kk] * act_grad_from_out(h, akind) : 0.f);
+                    }
+                }
+            }
+            __syncthreads();
+            STAMP8();
+            if (actC && Lh >= 2) {
+                const int N = pe.out[0];
+                const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
+                wave_store_tile(a.dpre + pe.hid[0] + (int64_t)(row0 + r0) * N, sHg[0] + r0 * ldH, ldH, nr, N);
+            }
+        }
+    }
+    STAMP8();
 }
 
 
@@ -2744,33 +2857,6 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
 // ------------------------------------------------------------------------------------------------
 struct SrcRef { const float* p; int64_t ld; };
 
-__device__ __forceinline__ SrcRef resolve_in(const DevPlan& p, const mmn_batch& b, int kind, int enc, int idx) {
-    SrcRef s{nullptr, 0};
-    switch (kind) {
-        case IN_X: {
-            int slot = 0;
-            for (int t = 0; t < b.n_seq; ++t) if (b.seq_enc[t] == enc) slot = b.seq_data[t];
-            s.p = b.x[slot]; s.ld = b.ldx[slot];
-            break;
-        }
-        case IN_HID:
-            s.p = p.hid + p.hid_off[enc][idx]; s.ld = p.m.enc[enc].layer[idx].out_dim;
-            break;
-        case IN_STATE_ROW:
-            if (idx == 0) { s.p = p.m.init_state; s.ld = 0; }
-            else { s.p = p.states + (int64_t)(idx - 1) * p.maxB * p.S; s.ld = p.S; }
-            break;
-        case IN_PREV_STATE: {
-            const int r = p.prev_row[enc];
-            if (r == 0) { s.p = p.m.init_state; s.ld = 0; }
-            else { s.p = p.states + (int64_t)(r - 1) * p.maxB * p.S; s.ld = p.S; }
-            break;
-        }
-        default: break;
-    }
-    return s;
-}
-
 // One interleaved operand fragment (V consecutive columns of one row).  FAST (wave-uniform): the
 // tile edge is V-aligned, so a lane is wholly inside or wholly outside; then the load is
 // unconditional from a clamped address and masked by a select (no branch -> counted vmcnt).
@@ -2778,18 +2864,20 @@ template <int V, bool FAST>
 __device__ __forceinline__ void load_frag(float (&dst)[V], const float* __restrict__ base, int64_t row_off, int first,
                                           int limit, bool row_ok) {
     if (FAST) {
-        const bool in = row_ok && (first < limit);
+        // RAW values from a clamped (always valid) address; nothing here depends on the loaded data,
+        // so the load stays in flight until the k-step that consumes it.  Rows past the range are
+        // zeroed on the A side at consume time; columns past the tile edge only feed outputs that
+        // are never stored.
+        (void)row_ok;
         const float* ptr = base + row_off + (first < limit ? first : 0);
         if (V == 4) {
             const f32x4 v = g_ld4(ptr);
-            dst[0] = in ? v.x : 0.f; dst[V > 1 ? 1 : 0] = in ? v.y : 0.f;
-            dst[V > 2 ? 2 : 0] = in ? v.z : 0.f; dst[V > 3 ? 3 : 0] = in ? v.w : 0.f;
+            dst[0] = v.x; dst[V > 1 ? 1 : 0] = v.y; dst[V > 2 ? 2 : 0] = v.z; dst[V > 3 ? 3 : 0] = v.w;
         } else if (V == 2) {
             const f32x2 v = g_ld2(ptr);
-            dst[0] = in ? v.x : 0.f; dst[V > 1 ? 1 : 0] = in ? v.y : 0.f;
+            dst[0] = v.x; dst[V > 1 ? 1 : 0] = v.y;
         } else {
-            const float v = g_ld(ptr);
-            dst[0] = in ? v : 0.f;
+            dst[0] = g_ld(ptr);
         }
     } else {
 #pragma unroll
@@ -2802,12 +2890,12 @@ __device__ __forceinline__ void load_frag(float (&dst)[V], const float* __restri
 }
 
 template <int MT, int NTL>
-__device__ __forceinline__ void wgrad_tile(const DevPlan& p, const WTask& tk, const WItem& it, const float* Ap, int64_t lda,
+__device__ __forceinline__ void wgrad_tile(const WgArgs& w, const WRec& it, const float* Ap, int64_t lda,
                                            SrcRef in, int ncols, int rb, int re, lp sTile, lp sBias) {
     const int lane = threadIdx.x & 63, wave = wave_id();
     const int i = lane & 15, q = lane >> 4;
-    const int M = tk.M;
-    const bool has_in = it.src != 2;
+    const int M = it.M;
+    const bool has_in = it.has_in != 0;
     const bool bias = it.bias != 0;
     f32x4 acc[MT][NTL];
     f32x4 accb[MT];
@@ -2830,9 +2918,13 @@ __device__ __forceinline__ void wgrad_tile(const DevPlan& p, const WTask& tk, co
     const int64_t ldi = has_in ? in.ld : lda;
     const int ilimit = has_in ? ncols : 0;
 
-    auto run = [&](auto fast_tag) {
+    // The loop body below has NO branches (bias is a template flag, k-steps past the range run on
+    // zeroed A fragments, the accumulators of a bias-only item are simply never stored): with a
+    // branch in it hipcc drains every load in flight (vmcnt(0)) at the loop header.
+    auto run = [&](auto fast_tag, auto bias_tag) {
         constexpr bool FA = decltype(fast_tag)::value;
-        constexpr int DEPTH = (MT * NTL >= 16) ? 6 : 8;   // k-steps (4 rows each) in flight
+        constexpr bool BI = decltype(bias_tag)::value;
+        constexpr int DEPTH = 8;                          // k-steps (4 rows each) in flight
         float a[DEPTH][MT], bb[DEPTH][NTL];
         auto ld = [&](float (&av)[MT], float (&bv)[NTL], int r) {
             const int row = r + q;
@@ -2841,14 +2933,16 @@ __device__ __forceinline__ void wgrad_tile(const DevPlan& p, const WTask& tk, co
             load_frag<MT, FA>(av, Ap, (int64_t)rc * lda, mfirst, M, ok);
             load_frag<NTL, FA>(bv, inp, (int64_t)rc * ldi, nfirst, ilimit, ok);
         };
-        auto comp = [&](const float (&av)[MT], const float (&bv)[NTL]) {
-            if (has_in) {
+        auto comp = [&](const float (&av_raw)[MT], const float (&bv)[NTL], int r) {
+            float av[MT];
+            const bool ok = !FA || (r + q < we);           // FAST loads are unmasked: zero the A side of rows past the range
 #pragma unroll
-                for (int c = 0; c < MT; ++c)
+            for (int c = 0; c < MT; ++c) av[c] = ok ? av_raw[c] : 0.f;
 #pragma unroll
-                    for (int d = 0; d < NTL; ++d) acc[c][d] = mfma4(av[c], bv[d], acc[c][d]);
-            }
-            if (bias) {
+            for (int c = 0; c < MT; ++c)
+#pragma unroll
+                for (int d = 0; d < NTL; ++d) acc[c][d] = mfma4(av[c], bv[d], acc[c][d]);
+            if (BI) {
 #pragma unroll
                 for (int c = 0; c < MT; ++c) accb[c] = mfma4(av[c], ones, accb[c]);
             }
@@ -2858,14 +2952,21 @@ __device__ __forceinline__ void wgrad_tile(const DevPlan& p, const WTask& tk, co
         for (int r = wb; r < we; r += 4 * DEPTH) {
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
-                if (r + 4 * k < we) comp(a[k], bb[k]);
+                comp(a[k], bb[k], r + 4 * k);
                 ld(a[k], bb[k], r + 4 * (k + DEPTH));
+                __builtin_amdgcn_sched_barrier(0);        // keep the refill right behind its k-step (the
+                                                          // scheduler otherwise sinks all loads to the loop end)
             }
         }
     };
     if (wb < we) {
-        if (a_fast && i_fast) run(std::true_type{}); else run(std::false_type{});
+        if (a_fast && i_fast) {
+            if (bias) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{});
+        } else {
+            if (bias) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{});
+        }
     }
+    if (w.stamps && blockIdx.x == 200 && threadIdx.x == 0) w.stamps[110] = (long long)wall_clock64();
     // fixed-order sum of the four waves' tiles through LDS, then one coalesced slab write
     const lp mine = sTile + wave * (64 * TILE_LD);
 #pragma unroll
@@ -2881,9 +2982,10 @@ __device__ __forceinline__ void wgrad_tile(const DevPlan& p, const WTask& tk, co
             for (int k = 0; k < 4; ++k) lds_st(sBias + wave * 64 + MT * (4 * q + k) + c, accb[c][k]);
     }
     __syncthreads();
-    float* slab = p.slabs + tk.slab_base + (int64_t)it.ks * tk.pstride;
-    const int ntot = tk.ntot;
-    const int col_off = (it.src == 1 ? tk.k0 : 0) + it.n0;
+    if (w.stamps && blockIdx.x == 200 && threadIdx.x == 0) w.stamps[111] = (long long)wall_clock64();
+    float* slab = w.slabs + it.slab_off;
+    const int ntot = it.ntot;
+    const int col_off = it.col_off;
     if (has_in) {
         constexpr int TW = 16 * NTL, TH = 16 * MT;
         for (int idx = threadIdx.x; idx < TH * TW; idx += NT) {
@@ -2908,35 +3010,53 @@ __device__ __forceinline__ void wgrad_tile(const DevPlan& p, const WTask& tk, co
 
 constexpr int WGRAD_LDS_FLOATS = 4 * 64 * TILE_LD + 4 * 64;
 
-__global__ __launch_bounds__(NT) void k_wgrad(const DevPlan* __restrict__ P, mmn_batch b, int rows_per_split) {
+__global__ __launch_bounds__(NT) void k_wgrad(const WgArgs w, const mmn_batch b) {
     extern __shared__ __attribute__((aligned(16))) float smem_generic[];
     const lp sTile = (lp)smem_generic;
     const lp sBias = sTile + 4 * 64 * TILE_LD;
-    const DevPlan& p = *P;
-    const WItem it = p.items[blockIdx.x];
-    const WTask& tk = p.tasks[it.task];
+    const unsigned pm = present_mask(b);                   // the only dependent global load besides the record
+    long long* const stamps = w.stamps;
+    if (stamps && blockIdx.x == 200 && threadIdx.x == 0) stamps[100] = (long long)wall_clock64();
+    const WRec it = w.recs[blockIdx.x];
+    const int rows_per_split = round_up((b.batch + it.nks - 1) / it.nks, 16);
     int rb = it.ks * rows_per_split, re = min(b.batch, rb + rows_per_split);
-    if (!p.exec_flags[tk.gate] || rb >= re) { rb = 0; re = 0; }       // writes zeros
-    const float* Ap; int64_t lda;
-    if (tk.a_kind == A_DPRE) { Ap = p.dpre + p.hid_off[tk.a_enc][tk.a_idx]; lda = tk.M; }
-    else if (tk.a_kind == A_DS) { Ap = p.dS + (int64_t)tk.a_idx * p.maxB * p.S; lda = p.S; }
-    else { Ap = p.dz + (int64_t)tk.a_idx * p.maxB * (2 * p.D); lda = 2 * p.D; }
+    if (!row_executed(b, pm, it.gate) || rb >= re) { rb = 0; re = 0; }   // writes zeros
+    const float* Ap = (it.a_kind == A_DPRE ? w.dpre : (it.a_kind == A_DS ? w.dS : w.dz)) + it.a_off;
     SrcRef in{nullptr, 0};
-    int ncols = 0;
-    if (it.src == 0) { in = resolve_in(p, b, tk.in0_kind, tk.in0_enc, tk.in0_idx); ncols = tk.k0; }
-    else if (it.src == 1) { in = resolve_in(p, b, tk.in1_kind, tk.in0_enc, 0); ncols = tk.k1; }
-    const int key = it.mt * 8 + it.nt;
-    switch (key) {
-        case 4 * 8 + 4: wgrad_tile<4, 4>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
-        case 4 * 8 + 2: wgrad_tile<4, 2>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
-        case 4 * 8 + 1: wgrad_tile<4, 1>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
-        case 2 * 8 + 4: wgrad_tile<2, 4>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
-        case 2 * 8 + 2: wgrad_tile<2, 2>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
-        case 2 * 8 + 1: wgrad_tile<2, 1>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
-        case 1 * 8 + 4: wgrad_tile<1, 4>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
-        case 1 * 8 + 2: wgrad_tile<1, 2>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
-        default:        wgrad_tile<1, 1>(p, tk, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+    switch (it.in_kind) {
+        case IN_X: {
+            int slot = 0;
+            for (int t = 0; t < b.n_seq; ++t) if (b.seq_enc[t] == it.in_enc) slot = b.seq_data[t];
+            in.p = b.x[slot]; in.ld = b.ldx[slot];
+            break;
+        }
+        case IN_HID: in.p = w.hid + it.in_off; in.ld = it.ldi; break;
+        case IN_STATE_ROW: in.p = w.states + it.in_off; in.ld = it.ldi; break;
+        case IN_INIT: in.p = w.init; in.ld = 0; break;
+        case IN_PREV_STATE: {
+            const int r = prev_row_of(b, pm, it.in_enc);
+            if (r == 0) { in.p = w.init; in.ld = 0; }
+            else { in.p = w.states + (int64_t)(r - 1) * w.maxB * w.S; in.ld = w.S; }
+            break;
+        }
+        default: break;
     }
+    const int ncols = it.ncols;
+    const int64_t lda = it.lda;
+    const int key = it.mt * 8 + it.nt;
+    if (stamps && blockIdx.x == 200 && threadIdx.x == 0) stamps[101] = (long long)wall_clock64();
+    switch (key) {
+        case 4 * 8 + 4: wgrad_tile<4, 4>(w, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        case 4 * 8 + 2: wgrad_tile<4, 2>(w, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        case 4 * 8 + 1: wgrad_tile<4, 1>(w, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        case 2 * 8 + 4: wgrad_tile<2, 4>(w, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        case 2 * 8 + 2: wgrad_tile<2, 2>(w, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        case 2 * 8 + 1: wgrad_tile<2, 1>(w, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        case 1 * 8 + 4: wgrad_tile<1, 4>(w, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        case 1 * 8 + 2: wgrad_tile<1, 2>(w, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+        default:        wgrad_tile<1, 1>(w, it, Ap, lda, in, ncols, rb, re, sTile, sBias); break;
+    }
+    if (stamps && blockIdx.x == 200 && threadIdx.x == 0) stamps[102] = (long long)wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3097,6 +3217,7 @@ struct mmn_plan {
     size_t par_lds_fwd, par_lds_bwd;
     int par_ok;
     ParArgs pa;              // kernel-argument descriptor of the 8-wave fast tier
+    WgArgs wg;               // kernel-argument descriptor of k_wgrad
     size_t f8_lds_fwd, f8_lds_bwd, fb8_lds_bytes;
     int f8_ok, fb8_ok;
     int grad_blocks;
@@ -3240,7 +3361,7 @@ static int validate_model(const mmn_model* m) {
 namespace {
 struct Layout {
     size_t off_plan, off_states, off_hid, off_dpre, off_dz, off_dS, off_pack, off_lossp, off_scp, off_cnt,
-        off_flags, off_slabs, off_epoch, off_stamps, off_tasks, off_items, off_segs, off_ptasks, total;
+        off_flags, off_slabs, off_epoch, off_stamps, off_tasks, off_items, off_segs, off_ptasks, off_recs, total;
     int64_t hid_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
     int64_t pkf_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
     int64_t pkb_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
@@ -3249,6 +3370,7 @@ struct Layout {
     int64_t hid_floats, pack_floats, pack_elems;
     std::vector<WTask> tasks;
     std::vector<WItem> items;
+    std::vector<WRec> recs;         // items with their task resolved: what k_wgrad reads
     std::vector<Seg> segs;
     std::vector<PackTask> ptasks;   // dst = offset until plan creation patches in the workspace address
     int64_t slab_floats, n_grad_elems;
@@ -3262,9 +3384,11 @@ int pick_width(int n) { return n >= 64 ? 4 : (n >= 32 ? 2 : 1); }
 void build_layout(const mmn_model& m, int maxB, Layout& L) {
     const int S = m.state_size, E = m.n_encoders, D = m.n_decoders, R = E + 1;
     L.max_tiles = (maxB + 15) / 16;
-    int ks = (maxB + 511) / 512;            // row-range splits: 512 rows per workgroup, 128 per wave
+    int split_rows = 512;                   // row-range splits: rows per workgroup (a quarter per wave)
+    if (const char* sr = getenv("MMN_WGRAD_ROWS")) { const int v = atoi(sr); if (v >= 64) split_rows = v; }
+    int ks = (maxB + split_rows - 1) / split_rows;
     if (ks < 1) ks = 1;
-    if (ks > 16) ks = 16;
+    if (ks > 64) ks = 64;
     L.KS = ks;
     L.ldS = pick_ld(S);
     int maxh = 16;
@@ -3330,7 +3454,7 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
 
     // ---- wgrad tasks, work items, slabs, gradient segments
     int64_t slab = 0, gstart = 0;
-    auto add_items = [&](int task, int M, int src, int ncols, bool bias_here) {
+    auto add_items = [&](int task, int M, int src, int ncols, bool bias_here, int nks) {
         // tile the [M x ncols] block of one source with interleave widths matched to what is left
         for (int m0 = 0; m0 < M;) {
             const int mt = pick_width(M - m0);
@@ -3338,8 +3462,8 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
             int n0 = 0;
             do {
                 const int nt = src == 2 ? 1 : pick_width(ncols - n0);
-                for (int k = 0; k < ks; ++k)
-                    L.items.push_back(WItem{task, m0, n0, k, (int16_t)mt, (int16_t)nt, (int16_t)src,
+                for (int k = 0; k < nks; ++k)
+                    L.items.push_back(WItem{task, m0, n0, k, nks, (int16_t)mt, (int16_t)nt, (int16_t)src,
                                             (int16_t)(bias_here && first_n ? 1 : 0)});
                 first_n = false;
                 n0 += 16 * nt;
@@ -3361,7 +3485,7 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
         t.slab_base = slab; t.pstride = (int64_t)S;
         const int id = (int)L.tasks.size();
         L.tasks.push_back(t);
-        add_items(id, S, 2, 0, true);
+        add_items(id, S, 2, 0, true, ks);
         add_seg(m.g_init_state, S, slab, t.pstride, ks, 1, 1, 0, 0);
         slab += (int64_t)ks * t.pstride;
     }
@@ -3383,11 +3507,14 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
             t.slab_base = slab; t.pstride = (int64_t)t.M * t.ntot;
             const int id = (int)L.tasks.size();
             L.tasks.push_back(t);
-            add_items(id, t.M, 0, t.k0, true);
-            if (last) add_items(id, t.M, 1, t.k1, false);
-            add_seg(lin.gw, lin.out_dim * lin.in_dim, slab, t.pstride, ks, lin.in_dim, t.ntot, 0, 0);
-            add_seg(lin.gb, lin.out_dim, slab, t.pstride, ks, 1, t.ntot, lin.in_dim, 0);
-            slab += (int64_t)ks * t.pstride;
+            // (per-task split counts are supported; doubling them for the big state-update tiles was
+            // measured slower: every extra work item costs ~5 us of fixed prologue/epilogue)
+            const int kst = ks;
+            add_items(id, t.M, 0, t.k0, true, kst);
+            if (last) add_items(id, t.M, 1, t.k1, false, kst);
+            add_seg(lin.gw, lin.out_dim * lin.in_dim, slab, t.pstride, kst, lin.in_dim, t.ntot, 0, 0);
+            add_seg(lin.gb, lin.out_dim, slab, t.pstride, kst, 1, t.ntot, lin.in_dim, 0);
+            slab += (int64_t)kst * t.pstride;
         }
     }
     // decoders: one task per grid row, all rows share one output of [2D x (S+1)] x (R*ks) partials
@@ -3402,7 +3529,7 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
             t.slab_base = base + (int64_t)r * ks * pstride; t.pstride = pstride;
             const int id = (int)L.tasks.size();
             L.tasks.push_back(t);
-            add_items(id, t.M, 0, S, true);
+            add_items(id, t.M, 0, S, true, ks);
         }
         for (int d = 0; d < D; ++d) {
             add_seg(m.dec[d].gw, 2 * S, base, pstride, R * ks, S, S + 1, 0, 2 * d);
@@ -3412,6 +3539,51 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     }
     L.slab_floats = slab;
     L.n_grad_elems = gstart;
+    // Launch order of the work items.  One workgroup per item; the dispatcher fills the 256 CUs
+    // round-robin, so items beyond the first 256 double up on the CUs that got the first ones.  Put
+    // the cheapest items at both ends (ascending cost, rotated by the overflow count): the CUs that
+    // run two items then run two small ones, not a small one on top of a 64x64 tile.
+    {
+        auto cost = [](const WItem& w) { return (w.src == 2 ? 0 : (int)w.mt * w.nt) + (w.bias ? (int)w.mt : 0); };
+        std::stable_sort(L.items.begin(), L.items.end(), [&](const WItem& x, const WItem& y) { return cost(x) < cost(y); });
+        const size_t n = L.items.size();
+        if (n > 256) {
+            const size_t extra = std::min(n - 256, (size_t)256);
+            std::rotate(L.items.begin(), L.items.begin() + extra, L.items.end());
+        }
+        if (getenv("MMN_VERBOSE")) {
+            int hist[40] = {0};
+            for (const auto& w : L.items) hist[std::min(cost(w), 39)]++;
+            fprintf(stderr, "[mmn] wgrad items: %zu; cost histogram:", n);
+            for (int c = 0; c < 40; ++c) if (hist[c]) fprintf(stderr, " %d:%d", c, hist[c]);
+            fprintf(stderr, "\n");
+        }
+    }
+
+    for (const WItem& it : L.items) {
+        const WTask& t = L.tasks[it.task];
+        WRec r{};
+        r.a_kind = t.a_kind;
+        if (t.a_kind == A_DPRE) { r.a_off = L.hid_off[t.a_enc][t.a_idx]; r.lda = t.M; }
+        else if (t.a_kind == A_DS) { r.a_off = (int64_t)t.a_idx * maxB * S; r.lda = S; }
+        else { r.a_off = (int64_t)t.a_idx * maxB * (2 * D); r.lda = 2 * D; }
+        r.M = t.M; r.m0 = it.m0; r.n0 = it.n0; r.mt = it.mt; r.nt = it.nt; r.bias = it.bias; r.ks = it.ks;
+        r.has_in = it.src != 2 ? 1 : 0;
+        const int kind = it.src == 0 ? t.in0_kind : (it.src == 1 ? t.in1_kind : IN_NONE);
+        r.in_kind = kind; r.in_enc = t.in0_enc; r.in_off = 0; r.ldi = 0;
+        r.ncols = it.src == 0 ? t.k0 : (it.src == 1 ? t.k1 : 0);
+        if (kind == IN_HID) { r.in_off = L.hid_off[t.in0_enc][t.in0_idx]; r.ldi = m.enc[t.in0_enc].layer[t.in0_idx].out_dim; }
+        else if (kind == IN_STATE_ROW) {
+            if (t.in0_idx == 0) r.in_kind = IN_INIT;
+            else { r.in_off = (int64_t)(t.in0_idx - 1) * maxB * S; r.ldi = S; }
+        }
+        r.ntot = t.ntot;
+        r.col_off = (it.src == 1 ? t.k0 : 0) + it.n0;
+        r.gate = t.gate;
+        r.slab_off = t.slab_base + (int64_t)it.ks * t.pstride;
+        r.nks = it.nks;
+        L.recs.push_back(r);
+    }
 
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + (bytes ? bytes : 4), 256); return at; };
@@ -3433,6 +3605,7 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     L.off_items = take(sizeof(WItem) * L.items.size());
     L.off_segs = take(sizeof(Seg) * L.segs.size());
     L.off_ptasks = take(sizeof(PackTask) * L.ptasks.size());
+    L.off_recs = take(sizeof(WRec) * L.items.size());
     L.total = o;
 }
 
@@ -3535,12 +3708,14 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     h.items = reinterpret_cast<WItem*>(ws + L.off_items);
     h.segs = reinterpret_cast<Seg*>(ws + L.off_segs);
     h.ptasks = reinterpret_cast<PackTask*>(ws + L.off_ptasks);
+    h.recs = reinterpret_cast<WRec*>(ws + L.off_recs);
     h.n_tasks = (int)L.tasks.size(); h.n_items = (int)L.items.size(); h.n_segs = (int)L.segs.size();
     h.n_ptasks = (int)L.ptasks.size();
     h.n_grad_elems = L.n_grad_elems;
     h.n_pack_elems = L.pack_elems;
     for (PackTask& t : L.ptasks) t.dst = h.pack + reinterpret_cast<intptr_t>(t.dst);   // offset -> address
     pl->dev = reinterpret_cast<DevPlan*>(ws + L.off_plan);
+    pl->wg = WgArgs{h.recs, h.dpre, h.dS, h.dz, h.states, h.hid, m->init_state, h.slabs, h.stamps, h.maxB, h.S};
     pl->grad_blocks = (int)((L.n_grad_elems + NTR - 1) / NTR);
     {
         int maxF = 1;
@@ -3617,6 +3792,7 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     if ((e = hipMemcpy(pl->dev, &h, sizeof(h), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h.tasks, L.tasks.data(), sizeof(WTask) * L.tasks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h.items, L.items.data(), sizeof(WItem) * L.items.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(h.recs, L.recs.data(), sizeof(WRec) * L.recs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h.segs, L.segs.data(), sizeof(Seg) * L.segs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h.ptasks, L.ptasks.data(), sizeof(PackTask) * L.ptasks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemset(h.epoch, 0, sizeof(double) * mmn_epoch_doubles(m))) != hipSuccess) return fail(e);
@@ -3690,7 +3866,7 @@ static int rt_for(const mmn_plan* p, const mmn_batch* b) {
 
 const char* mmn_chain_kernel_name(mmn_plan* p, const mmn_batch* b, int backward) {
     if (!p || !b) return "";
-    if (backward == 2) return (use_fast8(p, b) && p->fb8_ok) ? "k_fb8" : "";
+    if (backward == 2) return (use_fast8(p, b) && p->fb8_ok && b->n_seq >= 1) ? "k_fb8" : "";
     if (use_fast8(p, b)) return backward ? "k_bwd8" : "k_fwd8";
     if (p->par_ok) return backward ? "k_chain_bwd_par" : "k_chain_fwd_par";
     return backward ? "k_chain_bwd" : "k_chain_fwd";
@@ -3760,7 +3936,7 @@ int mmn_chain_bwd(mmn_plan* p, const mmn_batch* b, float sc_pen_x001, void* stre
 int mmn_chain_fwd_bwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float sc_pen_x001, void* stream) {
     int rc = check_batch(p, b);
     if (rc != MMN_OK) return rc;
-    if (use_fast8(p, b) && p->fb8_ok) {                    // one launch for both chains
+    if (use_fast8(p, b) && p->fb8_ok && b->n_seq >= 1) {   // one launch for both chains
         const int tiles = (b->batch + 15) / 16;
         const float cL = err_penalty / ((float)p->m.n_decoders * (float)(p->m.n_encoders + 1) * (float)b->batch_global);
         mmn_batch bb = *b;
@@ -3776,11 +3952,9 @@ int mmn_chain_fwd_bwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float 
 int mmn_wgrad(mmn_plan* p, const mmn_batch* b, void* stream) {
     int rc = check_batch(p, b);
     if (rc != MMN_OK) return rc;
-    const int ks = p->host.KS;
-    const int rps = round_up((b->batch + ks - 1) / ks, 16);
     mmn_batch bb = *b;
     hipLaunchKernelGGL(k_wgrad, dim3(p->host.n_items), dim3(NT), sizeof(float) * WGRAD_LDS_FLOATS,
-                       static_cast<hipStream_t>(stream), p->dev, bb, rps);
+                       static_cast<hipStream_t>(stream), p->wg, bb);
     HIP_TRY(hipGetLastError());
     return MMN_OK;
 }

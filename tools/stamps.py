@@ -20,7 +20,12 @@ torch.cuda.synchronize()
 ptr = eng.lib.mmn_debug_buffer(eng._plan, 3, 0)
 off = ptr - eng.workspace.data_ptr()
 st = eng.workspace[off:off + 8 * 250].view(torch.int64).cpu().numpy()
+w = st[100:112].copy()
+st = st[:100]
 st = st[st > 0]
 d = np.diff(st) / 100.0   # 100 MHz -> us
+if w[0] > 0:
+    print("k_wgrad block 200: start->item", (w[1] - w[0]) / 100.0, "item->loop end", (w[10] - w[1]) / 100.0,
+          "loop end->lds", (w[11] - w[10]) / 100.0, "lds->end", (w[2] - w[11]) / 100.0, "total", (w[2] - w[0]) / 100.0)
 print("n stamps", len(st), "total us", (st[-1] - st[0]) / 100.0)
 print(" ".join(f"{x:.2f}" for x in d))

@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay also for N>1")
     ap.add_argument("--optimizer", choices=("hip", "torch"), default="hip",
                     help="hip: multimodn_amd.optim.Adam (one k_adam launch); torch: torch.optim.Adam(fused, capturable)")
+    ap.add_argument("--no-fused-adam", action="store_true", help="keep optimizer.step() a separate k_adam launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -131,13 +132,16 @@ def main():
     batches = [eng.make_batch(xs, y, pairs, batch_global=B * world, device_nan_flags=True) for xs, y in resident]
     alpha, beta = float(model.err_penalty), float(model.state_change_penalty)
 
+    fuse_opt = opt if (world == 1 and args.optimizer == "hip" and not args.no_fused_adam) else None
+
     def step(i):
         b = batches[i % len(batches)]
-        eng.local_step(b, alpha, beta, accumulate=(world == 1))
+        # single GPU: Adam rides in the last launch (k_reduce) of the step; N > 1: all-reduce first
+        eng.local_step(b, alpha, beta, accumulate=(world == 1), optimizer=fuse_opt)
         if world > 1:
             dist.all_reduce(eng.reduce_buf)                  # ONE collective per step: grads + stats
             eng.accumulate(alpha, beta)
-        opt.step()
+        opt.step()                                           # no-op when the step was fused
 
     eng.assign_grads(None)
     eng.epoch_reset()
@@ -206,10 +210,14 @@ def main():
         kern[fwd_name] = lambda b: lib.mmn_chain_fwd(plan, C.byref(b), alpha, beta, 1, stream)
         kern[bwd_name] = lambda b: lib.mmn_chain_bwd(plan, C.byref(b), beta, stream)
     kern["k_wgrad"] = lambda b: lib.mmn_wgrad(plan, C.byref(b), stream)
-    kern["k_reduce"] = lambda b: lib.mmn_reduce(plan, C.byref(b), stream)
     if args.optimizer == "hip":
         adam_desc = opt.descriptor(opt._runs[0][0], opt.param_groups[0])   # the launch opt.step() makes
-        kern["k_adam"] = lambda b: lib.mmn_adam_step(C.byref(adam_desc), stream)
+    if fuse_opt is not None:
+        kern["k_reduce"] = lambda b: lib.mmn_reduce_adam(plan, C.byref(b), C.byref(adam_desc), stream)   # + Adam
+    else:
+        kern["k_reduce"] = lambda b: lib.mmn_reduce(plan, C.byref(b), stream)
+        if args.optimizer == "hip":
+            kern["k_adam"] = lambda b: lib.mmn_adam_step(C.byref(adam_desc), stream)
     REP, ROUNDS = 20, 5
     avg_us = {}
     for name, fn in kern.items():
@@ -254,7 +262,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "MIMIC-shaped tabular: 4 modalities x 64 features, hidden (32,32) relu, 3 binary tasks, "
                                "state_dim 128, batch 4096 per GPU, Adam lr 1e-3, penalties 1.0/0.3",
-                   "optimizer": "multimodn_amd.optim.Adam (k_adam)" if args.optimizer == "hip" else "torch.optim.Adam(fused, capturable)",
+                   "optimizer": ("multimodn_amd.optim.Adam fused into k_reduce" if fuse_opt is not None else
+                                 "multimodn_amd.optim.Adam (k_adam)") if args.optimizer == "hip" else "torch.optim.Adam(fused, capturable)",
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
                    "launch": "hipGraph replay" if graphs is not None else "eager",
                    "samples_per_sec_per_gpu": value / world},

@@ -224,6 +224,19 @@ typedef struct mmn_adam {
 int mmn_adam_blocks(int64_t n);      /* rows of `steps`; 0 if n is out of range */
 int mmn_adam_step(const mmn_adam* d, void* stream);
 
+/* mmn_train_step with optimizer.step() fused behind the gradient sum (single GPU: no all-reduce in
+ * between): the last launch forms each gradient element and immediately applies Adam to that
+ * parameter.  The gradients are still written.  Requires the optimizer's flat layout to be the
+ * plan's gradient layout (same tensors in the same order, adam->grads = the address given as
+ * mmn_model.g_init_state, every other gradient pointer contiguous behind it): otherwise
+ * MMN_ERR_UNSUPPORTED and nothing is launched - call mmn_train_step + mmn_adam_step instead.  A
+ * tensor whose encoder did not run this step (NaN batch) is left untouched, as torch leaves
+ * parameters with grad None.  The first call with a new (seg_start, grads) pair reads seg_start back
+ * synchronously: make it outside stream capture.  mmn_reduce_adam is the last launch alone. */
+int mmn_train_step_adam(mmn_plan* p, const mmn_batch* b, float err_penalty, float state_change_penalty_x001,
+                        int accumulate_epoch, const mmn_adam* adam, void* stream);
+int mmn_reduce_adam(mmn_plan* p, const mmn_batch* b, const mmn_adam* adam, void* stream);
+
 /* Epoch accumulators (device, inside the workspace): reset at epoch start, read at epoch end.
  * mmn_epoch_read synchronises the stream.  Layout of `out` (doubles): err_sum[R*D], sc_sum[E],
  * n_correct[R*D], tp[R*D], tn[R*D], fp[R*D], fn[R*D] (the four accumulated in fp32 like the

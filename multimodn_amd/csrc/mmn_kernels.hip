@@ -116,6 +116,7 @@ struct Seg {                            // one gradient tensor
     int64_t start;                      // first flat element index
     int64_t slab_base, pstride;
     int32_t count, n_partials, kdiv, ntot, coff, row_off;
+    int32_t gate, pad;                  // state row that must exist this step for the tensor to have a gradient
 };
 
 // one matrix to repack: value(n, kk) = src[n*ld + col(kk)] (mode 0) or src[col(kk)*ld + n] (mode 1,
@@ -3059,171 +3060,6 @@ __global__ __launch_bounds__(NT) void k_wgrad(const WgArgs w, const mmn_batch b)
     if (stamps && blockIdx.x == 200 && threadIdx.x == 0) stamps[102] = (long long)wall_clock64();
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_reduce: slabs -> gradient tensors (one thread per element); last block: tile partials -> stats
-// (+ optional loss combination / epoch accumulation, + re-zeroing of the NaN flags)
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void epoch_accumulate_block(const DevPlan& p, float alpha, float beta) {
-    const int R = p.R, D = p.D, E = p.E, RD = R * D;
-    float* st = p.stats;
-    double* ep = p.epoch;
-    const int lane = threadIdx.x & 63, wave = wave_id();
-    if (wave == 0) {                                       // fixed-order sums of grid and state change
-        float se = 0.f, ss = 0.f;
-        for (int c = lane; c < RD; c += 64) se += st[c];
-        for (int e = lane; e < E; e += 64) ss += st[RD + e];
-        se = wave_sum(se); ss = wave_sum(ss);
-        if (lane == 0) {
-            const float ge = se / (float)(D * R);          // multimodn.py:194
-            const float gs = ss / (float)E;                // multimodn.py:196
-            float* tail = st + RD + E + 5 * RD + R;
-            tail[0] = ge * alpha + gs * beta;              // multimodn.py:199-202
-            tail[1] = ge; tail[2] = gs; tail[3] = 0.f;
-            ep[RD + E + 5 * RD + R] += 1.0;                // n_steps
-        }
-    }
-    for (int c = threadIdx.x; c < RD; c += NT) {
-        ep[c] += (double)st[c];                                            // err_loss_epoch (f64 += f32)
-        ep[RD + E + c] += (double)st[RD + E + c];                          // n_correct
-        for (int k = 1; k < 5; ++k) {                                      // tp/tn/fp/fn kept in fp32
-            double* a = ep + RD + E + k * RD + c;
-            *a = (double)((float)*a + st[RD + E + k * RD + c]);
-        }
-    }
-    for (int e = threadIdx.x; e < E; e += NT) ep[RD + e] += (double)st[RD + e];
-    for (int r = threadIdx.x; r < R; r += NT) ep[RD + E + 5 * RD + r] += (double)st[RD + E + 5 * RD + r];
-}
-
-constexpr int NTR = 1024;     // k_reduce block size
-constexpr int MAXSEG = 2 * MMN_MAX_ENCODERS * MMN_MAX_LAYERS + 1 + 2 * MMN_MAX_DECODERS;
-
-__global__ __launch_bounds__(NTR) void k_reduce(const DevPlan* __restrict__ P, int batch, int batch_global,
-                                                int n_tiles, int grad_blocks, int want_grads, int accumulate,
-                                                float alpha, float beta, int32_t* nan_flags) {
-    const DevPlan& p = *P;
-    if ((int)blockIdx.x < grad_blocks) {
-        if (!want_grads) return;
-        // the segment table goes to LDS once per block: no dependent global reads before the partials
-        __shared__ Seg sseg[MAXSEG];
-        const int nseg = min(p.n_segs, MAXSEG);
-        {
-            const int nw = nseg * (int)(sizeof(Seg) / 4);
-            const int32_t* src = reinterpret_cast<const int32_t*>(p.segs);
-            int32_t* dst = reinterpret_cast<int32_t*>(sseg);
-            for (int k = threadIdx.x; k < nw; k += NTR) dst[k] = src[k];
-        }
-        __syncthreads();
-        const int64_t idx = (int64_t)blockIdx.x * NTR + threadIdx.x;
-        if (idx >= p.n_grad_elems) return;
-        int lo = 0, hi = nseg - 1;
-        while (lo < hi) {                                   // last segment with start <= idx
-            const int mid = (lo + hi + 1) >> 1;
-            if (sseg[mid].start <= idx) lo = mid; else hi = mid - 1;
-        }
-        const Seg sg = sseg[lo];
-        const int local = (int)(idx - sg.start);
-        const int m = local / sg.kdiv, n = local - m * sg.kdiv;
-        const float* src = p.slabs + sg.slab_base + (int64_t)(sg.row_off + m) * sg.ntot + n + sg.coff;
-        float sum = 0.f;
-        int k = 0;
-        for (; k + 16 <= sg.n_partials; k += 16) {          // 16 independent loads in flight, fixed order
-            float v[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = g_ld(src + (int64_t)(k + j) * sg.pstride);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) sum += v[j];
-        }
-        for (; k + 4 <= sg.n_partials; k += 4) {
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = g_ld(src + (int64_t)(k + j) * sg.pstride);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sum += v[j];
-        }
-        for (; k < sg.n_partials; ++k) sum += g_ld(src + (int64_t)k * sg.pstride);
-        g_st(sg.dst + local, sum);
-        return;
-    }
-    // stats block: 8 threads per quantity (loss cells, state change, 5 counters per cell) sum
-    // disjoint tile chunks with independent loads, then a fixed-order 8-way sum
-    const int R = p.R, D = p.D, E = p.E, S = p.S;
-    const int RD = R * D;
-    float* st = p.stats;
-    const float Bg = (float)batch_global;
-    __shared__ float spart[NTR / 8][8];
-    const int nq = RD + E + 5 * RD;
-    for (int qb = 0; qb < nq; qb += NTR / 8) {
-        const int qd = qb + (threadIdx.x >> 3), ch = threadIdx.x & 7;
-        float fs = 0.f;
-        if (qd < nq) {
-            const int per = (n_tiles + 7) >> 3;
-            const int t0 = ch * per, t1 = min(n_tiles, t0 + per);
-            if (qd < RD) {
-                if (p.exec_flags[qd / D]) {
-#pragma unroll 8
-                    for (int t = t0; t < t1; ++t) fs += g_ld(p.lossp + (int64_t)t * RD + qd);
-                }
-            } else if (qd < RD + E) {
-                const int e = qd - RD;
-                if (p.exec_flags[e + 1]) {
-#pragma unroll 8
-                    for (int t = t0; t < t1; ++t) fs += g_ld(p.scp + (int64_t)t * E + e);
-                }
-            } else {
-                const int c = qd - RD - E;
-                const int k = c / RD, cell = c - k * RD;
-                if (p.exec_flags[cell / D]) {
-                    const int32_t* src = p.cnt + (int64_t)cell * 5 + k;
-                    int v = 0;
-#pragma unroll 8
-                    for (int t = t0; t < t1; ++t) v += g_ldi(src + (int64_t)t * RD * 5);
-                    fs = (float)v;                          // exact: per-chunk counts are far below 2^24
-                }
-            }
-        }
-        spart[threadIdx.x >> 3][ch] = fs;
-        __syncthreads();
-        if (qd < nq && ch == 0) {
-            const float* sp = spart[threadIdx.x >> 3];
-            const float tot = (((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7])));
-            st[qd] = qd < RD ? tot / Bg : (qd < RD + E ? tot / (Bg * (float)S) : tot);
-        }
-        __syncthreads();
-    }
-    for (int r = threadIdx.x; r < R; r += NTR) st[RD + E + 5 * RD + r] = p.exec_flags[r] ? (float)batch : 0.f;
-    if (nan_flags && threadIdx.x < MMN_MAX_ENCODERS) nan_flags[threadIdx.x] = 0;
-    if (accumulate) {
-        __threadfence_block();
-        __syncthreads();
-        if (threadIdx.x < NT) epoch_accumulate_block(p, alpha, beta);
-    }
-}
-
-__global__ __launch_bounds__(NT) void k_epoch_accumulate(const DevPlan* __restrict__ P, float alpha, float beta) {
-    epoch_accumulate_block(*P, alpha, beta);
-}
-
-}  // namespace
-
-// ================================================================================================
-// host side: plan + C ABI
-// ================================================================================================
-struct mmn_plan {
-    mmn_model m;
-    DevPlan host;            // host copy of the device plan
-    DevPlan* dev;            // device address (start of workspace)
-    int max_batch;
-    size_t lds_bytes[3];     // by RT
-    size_t par_lds_fwd, par_lds_bwd;
-    int par_ok;
-    ParArgs pa;              // kernel-argument descriptor of the 8-wave fast tier
-    WgArgs wg;               // kernel-argument descriptor of k_wgrad
-    size_t f8_lds_fwd, f8_lds_bwd, fb8_lds_bytes;
-    int f8_ok, fb8_ok;
-    int grad_blocks;
-    int rt_override;
-};
-
 // =====================================================================================
 // k_adam: optimizer.step() of the training loop (multimodn.py:204) for torch.optim.Adam as the
 // reference pipelines build it, over the FLAT parameter / gradient / moment buffers: one launch
@@ -3328,6 +3164,229 @@ __global__ __launch_bounds__(ADAM_NT) void k_adam(const AdamArgs a) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// k_reduce: slabs -> gradient tensors (one thread per element); last block: tile partials -> stats
+// (+ optional loss combination / epoch accumulation, + re-zeroing of the NaN flags)
+// ------------------------------------------------------------------------------------------------
+template <class PlanLike>
+__device__ __forceinline__ void epoch_accumulate_block(const PlanLike& p, float alpha, float beta) {
+    const int R = p.R, D = p.D, E = p.E, RD = R * D;
+    float* st = p.stats;
+    double* ep = p.epoch;
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    if (wave == 0) {                                       // fixed-order sums of grid and state change
+        float se = 0.f, ss = 0.f;
+        for (int c = lane; c < RD; c += 64) se += st[c];
+        for (int e = lane; e < E; e += 64) ss += st[RD + e];
+        se = wave_sum(se); ss = wave_sum(ss);
+        if (lane == 0) {
+            const float ge = se / (float)(D * R);          // multimodn.py:194
+            const float gs = ss / (float)E;                // multimodn.py:196
+            float* tail = st + RD + E + 5 * RD + R;
+            tail[0] = ge * alpha + gs * beta;              // multimodn.py:199-202
+            tail[1] = ge; tail[2] = gs; tail[3] = 0.f;
+            ep[RD + E + 5 * RD + R] += 1.0;                // n_steps
+        }
+    }
+    for (int c = threadIdx.x; c < RD; c += NT) {
+        ep[c] += (double)st[c];                                            // err_loss_epoch (f64 += f32)
+        ep[RD + E + c] += (double)st[RD + E + c];                          // n_correct
+        for (int k = 1; k < 5; ++k) {                                      // tp/tn/fp/fn kept in fp32
+            double* a = ep + RD + E + k * RD + c;
+            *a = (double)((float)*a + st[RD + E + k * RD + c]);
+        }
+    }
+    for (int e = threadIdx.x; e < E; e += NT) ep[RD + e] += (double)st[RD + e];
+    for (int r = threadIdx.x; r < R; r += NT) ep[RD + E + 5 * RD + r] += (double)st[RD + E + 5 * RD + r];
+}
+
+constexpr int NTR = 1024;     // k_reduce block size
+constexpr int MAXSEG = 2 * MMN_MAX_ENCODERS * MMN_MAX_LAYERS + 1 + 2 * MMN_MAX_DECODERS;
+static_assert(MAXSEG <= ADAM_MAX_SEG, "k_reduce's fused Adam shares the segment tables");
+static_assert(NTR == 4 * ADAM_NT, "k_reduce and k_adam must use the same number of workgroups (step-counter rows)");
+
+// Everything k_reduce reads, in the kernel arguments (no dependent load of the plan first).
+struct RdArgs {
+    const Seg* segs; const float* slabs; const float* lossp; const float* scp; const int32_t* cnt;
+    const int32_t* exec_flags; float* stats; double* epoch;
+    int64_t n_grad_elems;
+    int32_t n_segs, R, D, E, S, pad;
+};
+
+// adam_on: optimizer.step() (multimodn.py:204) fused behind the gradient sum - the thread that has
+// just formed gradient element idx applies Adam to parameter idx (the flat gradient order IS the
+// flat parameter order; the host checks it), with k_adam's arithmetic and per-workgroup step rows.
+// A tensor whose encoder did not run this step has no gradient: it is left untouched.
+__global__ __launch_bounds__(NTR) void k_reduce(const RdArgs r, const AdamArgs ad, int adam_on, int batch, int batch_global,
+                                                int n_tiles, int grad_blocks, int want_grads, int accumulate,
+                                                float alpha, float beta, int32_t* nan_flags) {
+    __shared__ int s_exec[MMN_MAX_ENCODERS + 1];
+    if ((int)blockIdx.x < grad_blocks) {
+        if (!want_grads) return;
+        const int tid = threadIdx.x;
+        const int64_t idx = (int64_t)blockIdx.x * NTR + tid;
+        const bool mine = idx < r.n_grad_elems;
+        // the parameter / moment loads depend on nothing: first in the queue
+        float pv = 0.f, mv = 0.f, vv = 0.f;
+        if (adam_on) {
+            const int64_t ci = mine ? idx : 0;
+            pv = g_ld(ad.p + ci); mv = g_ld(ad.m + ci); vv = g_ld(ad.v + ci);
+        }
+        // the segment table goes to LDS once per block: no dependent global reads before the partials
+        __shared__ Seg sseg[MAXSEG];
+        __shared__ float s_ss[MAXSEG], s_bc2s[MAXSEG];
+        const int nseg = min(r.n_segs, MAXSEG);
+        {
+            const int nw = nseg * (int)(sizeof(Seg) / 4);
+            const int32_t* src = reinterpret_cast<const int32_t*>(r.segs);
+            int32_t* dst = reinterpret_cast<int32_t*>(sseg);
+            for (int k = tid; k < nw; k += NTR) dst[k] = g_ldi(src + k);
+        }
+        if (tid <= r.E) s_exec[tid] = g_ldi(r.exec_flags + tid);
+        float* my_steps = ad.steps + (size_t)blockIdx.x * (adam_on ? ad.n_seg : 0);
+        float t0 = 0.f;
+        int host_skip = 0;
+        if (adam_on && tid < nseg) {
+            t0 = g_ld(my_steps + tid);
+            host_skip = ad.seg_skip ? g_ldi(ad.seg_skip + tid) : 0;
+        }
+        __syncthreads();
+        if (adam_on) {
+            if (tid < nseg) {
+                const bool skip = host_skip || !s_exec[sseg[tid].gate];
+                const unsigned t = (unsigned)t0 + 1u;
+                const double bc1 = 1.0 - ipow(ad.b1, t);
+                const double bc2 = 1.0 - ipow(ad.b2, t);
+                s_ss[tid] = skip ? -1.f : (float)(ad.lr / bc1);
+                s_bc2s[tid] = (float)sqrt(bc2);
+                if (!skip) g_st(my_steps + tid, t0 + 1.f);
+            }
+            __syncthreads();
+        }
+        if (!mine) return;
+        int lo = 0, hi = nseg - 1;
+        while (lo < hi) {                                   // last segment with start <= idx
+            const int mid = (lo + hi + 1) >> 1;
+            if (sseg[mid].start <= idx) lo = mid; else hi = mid - 1;
+        }
+        const Seg sg = sseg[lo];
+        const int local = (int)(idx - sg.start);
+        const int m = local / sg.kdiv, n = local - m * sg.kdiv;
+        const float* src = r.slabs + sg.slab_base + (int64_t)(sg.row_off + m) * sg.ntot + n + sg.coff;
+        float sum = 0.f;
+        int k = 0;
+        for (; k + 16 <= sg.n_partials; k += 16) {          // 16 independent loads in flight, fixed order
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = g_ld(src + (int64_t)(k + j) * sg.pstride);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sum += v[j];
+        }
+        for (; k + 4 <= sg.n_partials; k += 4) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = g_ld(src + (int64_t)(k + j) * sg.pstride);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += v[j];
+        }
+        for (; k < sg.n_partials; ++k) sum += g_ld(src + (int64_t)k * sg.pstride);
+        g_st(sg.dst + local, sum);
+        if (adam_on) {
+            const float ss = s_ss[lo];
+            if (ss >= 0.f) {
+                adam_elem(pv, sum, mv, vv, (float)(1.0 - ad.b1), (float)ad.b2, (float)(1.0 - ad.b2), ad.eps, ad.wd, ss,
+                          s_bc2s[lo], ad.maximize);
+                g_st(ad.p + idx, pv); g_st(ad.m + idx, mv); g_st(ad.v + idx, vv);
+            }
+        }
+        return;
+    }
+    // stats block: 8 threads per quantity (loss cells, state change, 5 counters per cell) sum
+    // disjoint tile chunks with independent loads, then a fixed-order 8-way sum
+    const int R = r.R, D = r.D, E = r.E, S = r.S;
+    const int RD = R * D;
+    float* st = r.stats;
+    const float Bg = (float)batch_global;
+    if ((int)threadIdx.x < R) s_exec[threadIdx.x] = g_ldi(r.exec_flags + threadIdx.x);
+    __syncthreads();
+    __shared__ float spart[NTR / 8][8];
+    const int nq = RD + E + 5 * RD;
+    for (int qb = 0; qb < nq; qb += NTR / 8) {
+        const int qd = qb + (threadIdx.x >> 3), ch = threadIdx.x & 7;
+        float fs = 0.f;
+        if (qd < nq) {
+            const int per = (n_tiles + 7) >> 3;
+            const int t0 = ch * per, t1 = min(n_tiles, t0 + per);
+            if (qd < RD) {
+                if (s_exec[qd / D]) {
+#pragma unroll 8
+                    for (int t = t0; t < t1; ++t) fs += g_ld(r.lossp + (int64_t)t * RD + qd);
+                }
+            } else if (qd < RD + E) {
+                const int e = qd - RD;
+                if (s_exec[e + 1]) {
+#pragma unroll 8
+                    for (int t = t0; t < t1; ++t) fs += g_ld(r.scp + (int64_t)t * E + e);
+                }
+            } else {
+                const int c = qd - RD - E;
+                const int k = c / RD, cell = c - k * RD;
+                if (s_exec[cell / D]) {
+                    const int32_t* src = r.cnt + (int64_t)cell * 5 + k;
+                    int v = 0;
+#pragma unroll 8
+                    for (int t = t0; t < t1; ++t) v += g_ldi(src + (int64_t)t * RD * 5);
+                    fs = (float)v;                          // exact: per-chunk counts are far below 2^24
+                }
+            }
+        }
+        spart[threadIdx.x >> 3][ch] = fs;
+        __syncthreads();
+        if (qd < nq && ch == 0) {
+            const float* sp = spart[threadIdx.x >> 3];
+            const float tot = (((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7])));
+            st[qd] = qd < RD ? tot / Bg : (qd < RD + E ? tot / (Bg * (float)S) : tot);
+        }
+        __syncthreads();
+    }
+    for (int q = threadIdx.x; q < R; q += NTR) st[RD + E + 5 * RD + q] = s_exec[q] ? (float)batch : 0.f;
+    if (nan_flags && threadIdx.x < MMN_MAX_ENCODERS) nan_flags[threadIdx.x] = 0;
+    if (accumulate) {
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x < NT) epoch_accumulate_block(r, alpha, beta);
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_epoch_accumulate(const DevPlan* __restrict__ P, float alpha, float beta) {
+    epoch_accumulate_block(*P, alpha, beta);
+}
+
+}  // namespace
+
+// ================================================================================================
+// host side: plan + C ABI
+// ================================================================================================
+struct mmn_plan {
+    mmn_model m;
+    DevPlan host;            // host copy of the device plan
+    DevPlan* dev;            // device address (start of workspace)
+    int max_batch;
+    size_t lds_bytes[3];     // by RT
+    size_t par_lds_fwd, par_lds_bwd;
+    int par_ok;
+    ParArgs pa;              // kernel-argument descriptor of the 8-wave fast tier
+    WgArgs wg;               // kernel-argument descriptor of k_wgrad
+    RdArgs rd;               // kernel-argument descriptor of k_reduce
+    std::vector<Seg> segs;   // host copy of the gradient segments (fused-Adam layout check)
+    const void* adam_ok_seg_start;   // seg_start array already verified against `segs`
+    const void* adam_ok_grads;
+    size_t f8_lds_fwd, f8_lds_bwd, fb8_lds_bytes;
+    int f8_ok, fb8_ok;
+    int grad_blocks;
+    int rt_override;
+};
 
 static thread_local int g_last_hip = 0;
 #define HIP_TRY(expr)                                   \
@@ -3472,9 +3531,9 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
         }
     };
     auto add_seg = [&](float* dst, int count, int64_t base, int64_t pstride, int nparts, int kdiv, int ntot,
-                       int coff, int row_off) {
+                       int coff, int row_off, int gate) {
         if (!dst) return;
-        L.segs.push_back(Seg{dst, gstart, base, pstride, count, nparts, kdiv, ntot, coff, row_off});
+        L.segs.push_back(Seg{dst, gstart, base, pstride, count, nparts, kdiv, ntot, coff, row_off, gate, 0});
         gstart += count;
     };
     // init state: column sums of dS0
@@ -3486,7 +3545,7 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
         const int id = (int)L.tasks.size();
         L.tasks.push_back(t);
         add_items(id, S, 2, 0, true, ks);
-        add_seg(m.g_init_state, S, slab, t.pstride, ks, 1, 1, 0, 0);
+        add_seg(m.g_init_state, S, slab, t.pstride, ks, 1, 1, 0, 0, 0);
         slab += (int64_t)ks * t.pstride;
     }
     for (int e = 0; e < E; ++e) {
@@ -3512,8 +3571,8 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
             const int kst = ks;
             add_items(id, t.M, 0, t.k0, true, kst);
             if (last) add_items(id, t.M, 1, t.k1, false, kst);
-            add_seg(lin.gw, lin.out_dim * lin.in_dim, slab, t.pstride, kst, lin.in_dim, t.ntot, 0, 0);
-            add_seg(lin.gb, lin.out_dim, slab, t.pstride, kst, 1, t.ntot, lin.in_dim, 0);
+            add_seg(lin.gw, lin.out_dim * lin.in_dim, slab, t.pstride, kst, lin.in_dim, t.ntot, 0, 0, e + 1);
+            add_seg(lin.gb, lin.out_dim, slab, t.pstride, kst, 1, t.ntot, lin.in_dim, 0, e + 1);
             slab += (int64_t)kst * t.pstride;
         }
     }
@@ -3532,8 +3591,8 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
             add_items(id, t.M, 0, S, true, ks);
         }
         for (int d = 0; d < D; ++d) {
-            add_seg(m.dec[d].gw, 2 * S, base, pstride, R * ks, S, S + 1, 0, 2 * d);
-            add_seg(m.dec[d].gb, 2, base, pstride, R * ks, 1, S + 1, S, 2 * d);
+            add_seg(m.dec[d].gw, 2 * S, base, pstride, R * ks, S, S + 1, 0, 2 * d, 0);
+            add_seg(m.dec[d].gb, 2, base, pstride, R * ks, 1, S + 1, S, 2 * d, 0);
         }
         slab += (int64_t)R * ks * pstride;
     }
@@ -3716,6 +3775,10 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     for (PackTask& t : L.ptasks) t.dst = h.pack + reinterpret_cast<intptr_t>(t.dst);   // offset -> address
     pl->dev = reinterpret_cast<DevPlan*>(ws + L.off_plan);
     pl->wg = WgArgs{h.recs, h.dpre, h.dS, h.dz, h.states, h.hid, m->init_state, h.slabs, h.stamps, h.maxB, h.S};
+    pl->rd = RdArgs{h.segs, h.slabs, h.lossp, h.scp, h.cnt, h.exec_flags, h.stats, h.epoch, L.n_grad_elems,
+                    (int32_t)L.segs.size(), h.R, h.D, h.E, h.S, 0};
+    pl->segs = L.segs;
+    pl->adam_ok_seg_start = nullptr; pl->adam_ok_grads = nullptr;
     pl->grad_blocks = (int)((L.n_grad_elems + NTR - 1) / NTR);
     {
         int maxF = 1;
@@ -3959,13 +4022,51 @@ int mmn_wgrad(mmn_plan* p, const mmn_batch* b, void* stream) {
     return MMN_OK;
 }
 
+static AdamArgs adam_args(const mmn_adam* d) {
+    AdamArgs a{};
+    if (!d) return a;
+    a.p = d->params; a.g = d->grads; a.m = d->exp_avg; a.v = d->exp_avg_sq;
+    a.steps = d->steps; a.seg_start = d->seg_start; a.seg_skip = d->seg_skip;
+    a.n = (int)d->n; a.n_seg = d->n_seg;
+    a.lr = d->lr; a.b1 = d->beta1; a.b2 = d->beta2; a.eps = (float)d->eps; a.wd = (float)d->weight_decay;
+    a.maximize = d->maximize;
+    return a;
+}
+
+static int check_adam(const mmn_adam* d) {
+    if (!d || !d->params || !d->grads || !d->exp_avg || !d->exp_avg_sq || !d->steps || !d->seg_start) return MMN_ERR_ARG;
+    if (d->n < 1 || d->n > 0x7fffffff - 4 * ADAM_NT || d->n_seg < 1 || d->n_seg > ADAM_MAX_SEG) return MMN_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(d->params) | reinterpret_cast<uintptr_t>(d->grads) |
+         reinterpret_cast<uintptr_t>(d->exp_avg) | reinterpret_cast<uintptr_t>(d->exp_avg_sq)) & 15)
+        return MMN_ERR_ARG;
+    return MMN_OK;
+}
+
+// The fused reduce+Adam needs the optimizer's flat layout to BE the plan's gradient layout: same
+// tensors, same order, gradients at the plan's addresses.  Checked once per (seg_start, grads) pair
+// (one small synchronous device read: do the first fused step outside stream capture).
+static int adam_fusable(mmn_plan* p, const mmn_adam* d) {
+    int rc = check_adam(d);
+    if (rc != MMN_OK) return rc;
+    if (p->adam_ok_seg_start == d->seg_start && p->adam_ok_grads == d->grads) return MMN_OK;
+    if (d->n != p->host.n_grad_elems || d->n_seg != (int)p->segs.size() || p->segs.size() > (size_t)MAXSEG) return MMN_ERR_UNSUPPORTED;
+    std::vector<int32_t> st(d->n_seg + 1);
+    HIP_TRY(hipMemcpy(st.data(), d->seg_start, sizeof(int32_t) * st.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < d->n_seg; ++i) {
+        if ((int64_t)st[i] != p->segs[i].start || p->segs[i].dst != d->grads + st[i]) return MMN_ERR_UNSUPPORTED;
+    }
+    if ((int64_t)st[d->n_seg] != d->n) return MMN_ERR_UNSUPPORTED;
+    p->adam_ok_seg_start = d->seg_start; p->adam_ok_grads = d->grads;
+    return MMN_OK;
+}
+
 static int launch_reduce(mmn_plan* p, const mmn_batch* b, int want_grads, int accumulate, float alpha, float beta,
-                         void* stream) {
+                         void* stream, const mmn_adam* adam = nullptr) {
     const int rt = rt_for(p, b);
     const int tiles = (b->batch + 16 * rt - 1) / (16 * rt);
-    hipLaunchKernelGGL(k_reduce, dim3(p->grad_blocks + 1), dim3(NTR), 0, static_cast<hipStream_t>(stream), p->dev, b->batch,
-                       b->batch_global, tiles, p->grad_blocks, want_grads, accumulate, alpha, beta,
-                       const_cast<int32_t*>(b->nan_flags));
+    hipLaunchKernelGGL(k_reduce, dim3(p->grad_blocks + 1), dim3(NTR), 0, static_cast<hipStream_t>(stream), p->rd,
+                       adam_args(adam), adam ? 1 : 0, b->batch, b->batch_global, tiles, p->grad_blocks, want_grads, accumulate,
+                       alpha, beta, const_cast<int32_t*>(b->nan_flags));
     HIP_TRY(hipGetLastError());
     return MMN_OK;
 }
@@ -3993,6 +4094,24 @@ int mmn_train_step(mmn_plan* p, const mmn_batch* b, float err_penalty, float sc_
     return launch_reduce(p, b, 1, accumulate_epoch, err_penalty, sc_pen_x001, stream);
 }
 
+int mmn_train_step_adam(mmn_plan* p, const mmn_batch* b, float err_penalty, float sc_pen_x001, int accumulate_epoch,
+                        const mmn_adam* adam, void* stream) {
+    int rc = check_batch(p, b);
+    if (rc != MMN_OK) return rc;
+    if ((rc = adam_fusable(p, adam)) != MMN_OK) return rc;
+    if ((rc = mmn_prepare(p, b, 1, stream)) != MMN_OK) return rc;
+    if ((rc = mmn_chain_fwd_bwd(p, b, err_penalty, sc_pen_x001, stream)) != MMN_OK) return rc;
+    if ((rc = mmn_wgrad(p, b, stream)) != MMN_OK) return rc;
+    return launch_reduce(p, b, 1, accumulate_epoch, err_penalty, sc_pen_x001, stream, adam);
+}
+
+int mmn_reduce_adam(mmn_plan* p, const mmn_batch* b, const mmn_adam* adam, void* stream) {
+    int rc = check_batch(p, b);
+    if (rc != MMN_OK) return rc;
+    if ((rc = adam_fusable(p, adam)) != MMN_OK) return rc;
+    return launch_reduce(p, b, 1, 0, 0.f, 0.f, stream, adam);
+}
+
 int mmn_eval_step(mmn_plan* p, const mmn_batch* b, int accumulate_epoch, void* stream) {
     int rc = mmn_prepare(p, b, 0, stream);
     if (rc != MMN_OK) return rc;
@@ -4006,20 +4125,9 @@ int mmn_adam_blocks(int64_t n) {
 }
 
 int mmn_adam_step(const mmn_adam* d, void* stream) {
-    if (!d || !d->params || !d->grads || !d->exp_avg || !d->exp_avg_sq || !d->steps || !d->seg_start)
-        return MMN_ERR_ARG;
-    if (d->n < 1 || d->n > 0x7fffffff - 4 * ADAM_NT || d->n_seg < 1 || d->n_seg > ADAM_MAX_SEG) return MMN_ERR_ARG;
-    if ((reinterpret_cast<uintptr_t>(d->params) | reinterpret_cast<uintptr_t>(d->grads) |
-         reinterpret_cast<uintptr_t>(d->exp_avg) | reinterpret_cast<uintptr_t>(d->exp_avg_sq)) & 15)
-        return MMN_ERR_ARG;
-    AdamArgs a;
-    a.p = d->params; a.g = d->grads; a.m = d->exp_avg; a.v = d->exp_avg_sq;
-    a.steps = d->steps; a.seg_start = d->seg_start; a.seg_skip = d->seg_skip;
-    a.n = (int)d->n; a.n_seg = d->n_seg;
-    a.lr = d->lr; a.b1 = d->beta1; a.b2 = d->beta2; a.eps = (float)d->eps; a.wd = (float)d->weight_decay;
-    a.maximize = d->maximize;
-    const int blocks = mmn_adam_blocks(d->n);
-    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(ADAM_NT), 0, static_cast<hipStream_t>(stream), a);
+    const int rc = check_adam(d);
+    if (rc != MMN_OK) return rc;
+    hipLaunchKernelGGL(k_adam, dim3(mmn_adam_blocks(d->n)), dim3(ADAM_NT), 0, static_cast<hipStream_t>(stream), adam_args(d));
     HIP_TRY(hipGetLastError());
     return MMN_OK;
 }

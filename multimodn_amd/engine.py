@@ -209,13 +209,31 @@ class HipChainEngine:
             b.seq_enc[t] = e
         return b
 
-    def local_step(self, b: hip.Batch, err_penalty: float, sc_penalty_x001: float, accumulate: bool = False) -> None:
+    def local_step(self, b: hip.Batch, err_penalty: float, sc_penalty_x001: float, accumulate: bool = False,
+                   optimizer=None) -> bool:
         """prepare (NaN scan when the batch carries device flags, weight transposes) + fwd + bwd +
         wgrad + reduce: afterwards reduce_buf = [grads | stats] holds this rank's sums (already
         divided by batch_global).  accumulate=True also folds the loss combination / epoch
-        accumulation into the last launch (single-GPU)."""
+        accumulation into the last launch (single-GPU).
+
+        optimizer: a multimodn_amd.optim.Adam over exactly this model's parameters; its step is
+        then fused behind the gradient sum in the last launch (single GPU only: with data parallel
+        the all-reduce has to come first).  Returns True if the optimizer step was applied by this
+        call (the optimizer's next .step() is then a no-op), False if the caller still has to step."""
+        if optimizer is not None:
+            d = optimizer.fused_descriptor(self)
+            if d is not None:
+                rc = self.lib.mmn_train_step_adam(self._plan, C.byref(b), err_penalty, sc_penalty_x001,
+                                                  1 if accumulate else 0, C.byref(d), self._stream())
+                if rc == 0:
+                    optimizer.mark_fused_step()
+                    return True
+                if rc != hip.ERR_UNSUPPORTED:
+                    hip.check(rc, "mmn_train_step_adam")
+                optimizer.fusion_refused(self)
         hip.check(self.lib.mmn_train_step(self._plan, C.byref(b), err_penalty, sc_penalty_x001,
                                           1 if accumulate else 0, self._stream()), "mmn_train_step")
+        return False
 
     def eval_step(self, b: hip.Batch, accumulate: bool = False) -> None:
         hip.check(self.lib.mmn_eval_step(self._plan, C.byref(b), 1 if accumulate else 0, self._stream()), "mmn_eval_step")

@@ -127,7 +127,8 @@ class MultiModN(nn.Module):
             executed[e] = True
         return xs, y, exec_pairs, executed
 
-    def _run_step(self, eng, data, target, encoder_sequence, train: bool, batch_global: Optional[int] = None):
+    def _run_step(self, eng, data, target, encoder_sequence, train: bool, batch_global: Optional[int] = None,
+                  optimizer=None):
         pairs = self.get_encoder_iterable(encoder_sequence, self.shuffle_mode, train=train)
         xs, y, exec_pairs, executed = self._ingest(data, target, pairs)
         B = int(y.shape[0])
@@ -135,7 +136,10 @@ class MultiModN(nn.Module):
                            device_nan_flags=executed is None)
         dp = self._dp_group is not None
         if train:
-            eng.local_step(b, float(self.err_penalty), float(self.state_change_penalty), accumulate=not dp)
+            # single GPU + multimodn_amd.optim.Adam: optimizer.step() rides in the last launch
+            fuse = optimizer if (not dp and hasattr(optimizer, "fused_descriptor")) else None
+            eng.local_step(b, float(self.err_penalty), float(self.state_change_penalty), accumulate=not dp,
+                           optimizer=fuse)
         else:
             eng.eval_step(b, accumulate=not dp)
         if dp:
@@ -170,7 +174,7 @@ class MultiModN(nn.Module):
             else:
                 eng.ensure(int(target.shape[0]))
             optimizer.zero_grad()
-            executed, keep = self._run_step(eng, data, target, encoder_sequence, train=True)
+            executed, keep = self._run_step(eng, data, target, encoder_sequence, train=True, optimizer=optimizer)
             eng.assign_grads(executed)          # what loss.backward() leaves behind (multimodn.py:203)
             optimizer.step()
             if log_interval and batch_idx % log_interval == log_interval - 1:

@@ -145,6 +145,47 @@ class Adam(Optimizer):
         d.maximize = 1 if group["maximize"] else 0
         return d
 
+    # ------------------------------------------------------------------ fusion with the engine's last launch
+    def fused_descriptor(self, engine) -> Optional["hip.AdamDesc"]:
+        """The mmn_adam struct for engine.local_step(..., optimizer=self), or None when this
+        optimizer cannot be fused with that engine (several groups / runs, other parameters,
+        a refusal by the library earlier).  The library re-checks the layout itself."""
+        if len(self.param_groups) != 1 or getattr(self, "_no_fuse_sig", None) == engine._sig:
+            return None
+        group = self.param_groups[0]
+        params = group["params"]
+        if len(params) != len(engine.params) or any(a is not b for a, b in zip(params, engine.params)):
+            return None
+        if self._lib is None:
+            self._lib = hip.load()
+        if not hasattr(self, "_last_grads"):
+            self._last_grads = {}
+        for p, g in zip(engine.params, engine.grad_views):     # the gradients WILL live there
+            self._last_grads[id(p)] = g
+        runs = self._runs[0]
+        if runs is None or not self._runs_valid(runs) or runs[0].g_ptr != engine.flat_grads.data_ptr():
+            saved = [p.grad for p in params]
+            for p, g in zip(params, engine.grad_views):
+                p.grad = g
+            try:
+                runs = self._runs[0] = self._build_runs(0, group)
+            finally:
+                for p, g in zip(params, saved):
+                    p.grad = g
+        if len(runs) != 1:
+            return None
+        r = runs[0]
+        if any(r.skip_host):                                  # the kernel derives skips from the executed rows
+            r.seg_skip.zero_()
+            r.skip_host = tuple([0] * len(r.params))
+        return self.descriptor(r, group)
+
+    def mark_fused_step(self) -> None:
+        self._fused_pending = True
+
+    def fusion_refused(self, engine) -> None:
+        self._no_fuse_sig = engine._sig
+
     # ------------------------------------------------------------------ step
     @torch.no_grad()
     def step(self, closure=None):
@@ -152,6 +193,9 @@ class Adam(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if getattr(self, "_fused_pending", False):           # engine.local_step(..., optimizer=self) already stepped
+            self._fused_pending = False
+            return loss
         if self._lib is None:
             self._lib = hip.load()
         if not hasattr(self, "_last_grads"):

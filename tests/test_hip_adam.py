@@ -121,3 +121,73 @@ def test_graph_replay_advances_steps():
     assert float(opt.state[ps[0]]["step"]) == 5.0
     for p, rp in zip(ps, ref_ps):
         assert rel_err(p.detach().cpu().numpy(), rp.detach().cpu().numpy()) < 1e-5
+
+
+def _c3_like_model(mm, seed=0, B=192):
+    from oracle import multimodn_oracle as O
+    from helpers import build_torch_model
+    spec = O.ModelSpec(64, [O.EncoderSpec(16, (16,), O.ACT_RELU), O.EncoderSpec(32, (32, 16), O.ACT_RELU),
+                            O.EncoderSpec(8, (), O.ACT_RELU)], 2, 1.0, 0.4)
+    params = O.init_params(spec, seed)
+    batches = O.synthetic_batches(spec, 3 * B, B, seed=5)
+    return spec, params, batches, build_torch_model(spec, params, "cuda", mm)
+
+
+@pytest.mark.parametrize("nan_policy", ["host", "device"])
+def test_fused_step_equals_separate_step_and_skips_like_torch(nan_policy):
+    """optimizer.step() fused into the last launch of the training step: bit-identical parameters
+    to train step + k_adam, and an encoder skipped on a NaN batch keeps parameters, moments and
+    step count untouched (torch leaves grad None parameters alone), under both NaN policies."""
+    import multimodn_amd as mm
+    spec, params, batches, model_f = _c3_like_model(mm)
+    _, _, _, model_s = _c3_like_model(mm)
+    model_f.nan_policy = model_s.nan_policy = nan_policy
+    opt_f = mm.optim.Adam(list(model_f.parameters()), 2e-3)
+    opt_s = mm.optim.Adam(list(model_s.parameters()), 2e-3)
+    opt_s.fused_descriptor = lambda engine: None           # force the separate k_adam launch
+    crit = torch.nn.CrossEntropyLoss()
+
+    def loader(nan_at=None):
+        out = []
+        for i, (xs, y) in enumerate(batches):
+            xs = [x.copy() for x in xs]
+            if nan_at is not None and i == nan_at:
+                xs[1][3, 2] = np.nan                       # encoder 1 is skipped for this whole batch
+            out.append(([torch.from_numpy(x) for x in xs], torch.from_numpy(y)))
+        return out
+
+    model_f.train_epoch(loader(), opt_f, crit)
+    model_s.train_epoch(loader(), opt_s, crit)
+    before = {n: p.detach().clone() for n, p in model_f.named_parameters()}
+    steps_before = {n: float(opt_f.state[p]["step"]) for n, p in model_f.named_parameters()}
+    model_f.train_epoch(loader(nan_at=0)[:1], opt_f, crit)
+    model_s.train_epoch(loader(nan_at=0)[:1], opt_s, crit)
+    torch.cuda.synchronize()
+    for (n, pf), (_, ps) in zip(model_f.named_parameters(), model_s.named_parameters()):
+        skipped = n.startswith("encoders.1.")
+        # (device policy + a separate optimizer sees ZERO gradients for the skipped encoder, not
+        # None, so only the fused path can leave it untouched there)
+        if not (skipped and nan_policy == "device"):
+            assert torch.equal(pf, ps), n
+            assert float(opt_f.state[pf]["step"]) == float(opt_s.state[ps]["step"])
+        assert float(opt_f.state[pf]["step"]) == steps_before[n] + (0 if skipped else 1), n
+        assert torch.equal(pf, before[n]) == skipped, n
+
+
+def test_fused_path_is_taken_and_matches_torch_adam():
+    import multimodn_amd as mm
+    spec, params, batches, model = _c3_like_model(mm, seed=3)
+    _, _, _, ref = _c3_like_model(mm, seed=3)
+    opt = mm.optim.Adam(list(model.parameters()), 1e-3)
+    topt = torch.optim.Adam(list(ref.parameters()), 1e-3)
+    crit = torch.nn.CrossEntropyLoss()
+    loader = [([torch.from_numpy(x) for x in xs], torch.from_numpy(y)) for xs, y in batches]
+    taken = []
+    orig = opt.mark_fused_step
+    opt.mark_fused_step = lambda: (taken.append(1), orig())[1]
+    for _ in range(2):
+        model.train_epoch(loader, opt, crit)
+        ref.train_epoch(loader, topt, crit)
+    assert len(taken) == 2 * len(loader)
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.detach().cpu().numpy(), q.detach().cpu().numpy()) < 1e-5, n

@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--resident-batches", type=int, default=8)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay also for N>1")
+    ap.add_argument("--graph-steps", type=int, default=8, help="consecutive steps captured into one hipGraph")
     ap.add_argument("--optimizer", choices=("hip", "torch"), default="hip",
                     help="hip: multimodn_amd.optim.Adam (one k_adam launch); torch: torch.optim.Adam(fused, capturable)")
     ap.add_argument("--no-fused-adam", action="store_true", help="keep optimizer.step() a separate k_adam launch")
@@ -147,43 +148,61 @@ def main():
     eng.epoch_reset()
     use_graph = (not args.no_graph) and (world == 1 or args.graph)
     graphs = None
+    group = 1
     for i in range(3):                                        # eager warm-up (also initialises Adam state)
         step(i)
     torch.cuda.synchronize()
     if use_graph:
+        # One hipGraph holds `group` consecutive steps (each step = its own batch: prepare, fused
+        # forward+backward chain, wgrad, reduce(+Adam)); replaying it costs one host submission for
+        # `group` steps, which keeps the host ahead of a ~85 us step.
+        group = max(1, min(args.graph_steps, len(batches)))
+        while len(batches) % group:
+            group -= 1
         try:
             graphs = []
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for i in range(len(batches)):
+                for i0 in range(0, len(batches), group):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=side):
-                        step(i)
+                        for i in range(i0, i0 + group):
+                            step(i)
                     graphs.append(g)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
         except Exception as exc:                              # pragma: no cover - depends on the box
             print(f"[bench] hipGraph capture failed ({exc!r}); running eagerly", file=sys.stderr)
             graphs = None
+    if graphs is None:
+        group = 1
 
-    def run(i):
-        if graphs is not None:
-            graphs[i % len(graphs)].replay()
-        else:
-            step(i)
+    def run_range(i0, n):
+        """Steps i0 .. i0+n-1, in order."""
+        if graphs is None:
+            for i in range(i0, i0 + n):
+                step(i)
+            return
+        i = i0
+        while i < i0 + n:
+            if i % group == 0 and i + group <= i0 + n:
+                graphs[(i // group) % len(graphs)].replay()
+                i += group
+            else:                                             # ragged head / tail: eager single steps
+                step(i)
+                i += 1
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        run(i)
+    run_range(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        run(i)
+    start = -(-args.warmup // group) * group              # timed steps start on a graph boundary
+    run_range(start, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -265,7 +284,7 @@ def main():
                    "optimizer": ("multimodn_amd.optim.Adam fused into k_reduce" if fuse_opt is not None else
                                  "multimodn_amd.optim.Adam (k_adam)") if args.optimizer == "hip" else "torch.optim.Adam(fused, capturable)",
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                   "launch": "hipGraph replay" if graphs is not None else "eager",
+                   "launch": f"hipGraph replay ({group} steps per graph)" if graphs is not None else "eager",
                    "samples_per_sec_per_gpu": value / world},
         "roofline": roofline,
     }

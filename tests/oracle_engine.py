@@ -88,10 +88,11 @@ class OracleEngine:
                                    for n, p in zip(self.names, self.params)])
             self.flat_grads.copy_(torch.from_numpy(flat))
 
-    def local_step(self, b, alpha, beta, accumulate=False):
+    def local_step(self, b, alpha, beta, accumulate=False, optimizer=None):
         self._run(b, True)
         if accumulate:
             self.accumulate(alpha, beta)
+        return False                     # never applies the optimizer step itself
 
     def eval_step(self, b, accumulate=False):
         spec = self.spec

@@ -1759,12 +1759,19 @@ __host__ __device__ inline Par8Lds par8_lds(int R, int E, int ldS, int ldH, int 
 }
 
 // NS k-steps of ONE column tile
+// (tile, T, t_begin are wave-uniform: each fragment address is a scalar base plus the lane's 16 bytes,
+// so a request costs two scalar ops and one vector-memory instruction)
 template <int NS>
 __device__ __forceinline__ void issue_t(f32x4 (&bq)[NS], const float* pk, int T, int ntiles, int tile, int t_begin) {
     const int lane = threadIdx.x & 63;
-    const float* p0 = pk + ((int64_t)min(tile, ntiles - 1) * T * 64 + lane) * 4;
+    const int tl = __builtin_amdgcn_readfirstlane(min(tile, ntiles - 1));
+    const int Tu = __builtin_amdgcn_readfirstlane(T), tb = __builtin_amdgcn_readfirstlane(t_begin);
+    const float* p0 = pk + (int64_t)tl * Tu * 256;
 #pragma unroll
-    for (int j = 0; j < NS; ++j) bq[j] = g_ld4(p0 + min(t_begin + j, T - 1) * 256);
+    for (int j = 0; j < NS; ++j) {
+        const float* pt = p0 + min(tb + j, Tu - 1) * 256;    // scalar
+        bq[j] = g_ld4(pt + lane * 4);
+    }
 }
 // acc += A[16 x 16*(t_end-t_begin)] x fragment registers; A image row stride lda, step t reads a + 16 (t - t_base)
 template <int NS>
@@ -2420,16 +2427,6 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
     float init_v[2];                                       // state row 0 = init state (state.py:29-32)
 #pragma unroll
     for (int k = 0; k < 2; ++k) init_v[k] = g_ld(a.init + min(lane + 64 * k, S - 1));
-    {
-        const PB BU = make_pb(pkU, S, S, HL);
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            const int nn[2] = {16 * (4 * half + 2 * pr), 16 * (4 * half + 2 * pr + 1)};
-            issue_b<4>(uq[pr], BU, nn, BU.T0);             // tiles past S re-read the last tile
-            ub[pr][0] = g_ld(pe.bias[Lh] + min(nn[0] + i, S - 1));
-            ub[pr][1] = g_ld(pe.bias[Lh] + min(nn[1] + i, S - 1));
-        }
-    }
     // targets / decoder biases of this thread's (row r, decoder d, batch row) triple, first pass
     int y_pre = 0;
     float bd0_pre = 0.f, bd1_pre = 0.f;
@@ -2468,8 +2465,6 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
         const ParEnc& p2 = a.enc[X.e(ok ? k : 0)];
         issue_t<8>(w, a.pack + (ok ? p2.pkf[p2.Lh] : 0), ok ? T0 + ((p2.HL + 15) >> 4) : 1, ok ? ntS : 1, wave, 0);
     };
-    issue_fwd(wsA, 0);
-    issue_fwd(wsB, 1);
     {                                                      // x -> the pair's LDS image
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -2483,6 +2478,20 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
             if (lane + 64 * k < S) lds_st(St + r * ldS + lane + 64 * k, init_v[k]);
     __syncthreads();
     STAMP8();
+    // second batch of requests (u_e operand, first two chain steps): they stream in underneath the
+    // hidden layers instead of queueing in front of the x tile
+    {
+        const PB BU = make_pb(pkU, S, S, HL);
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int nn[2] = {16 * (4 * half + 2 * pr), 16 * (4 * half + 2 * pr + 1)};
+            issue_b<4>(uq[pr], BU, nn, BU.T0);             // tiles past S re-read the last tile
+            ub[pr][0] = g_ld(pe.bias[Lh] + min(nn[0] + i, S - 1));
+            ub[pr][1] = g_ld(pe.bias[Lh] + min(nn[1] + i, S - 1));
+        }
+    }
+    issue_fwd(wsA, 0);
+    issue_fwd(wsB, 1);
 
     // ---- phase A: u_e = W_x h_e + b of this pair's encoder
     if (Lmax >= 1) {                                       // hidden layer 0 (mlp_encoder.py:75-76), tile = half
@@ -2562,29 +2571,38 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
     //      tile, so the epilogue is the LDS write of the new state tile alone; the state-change sums
     //      and the global copies of the tiles (for k_wgrad) happen off this critical path.
     int cur = 0;
-    auto store_state = [&](int e) {                         // each wave stores two rows of state tile e+1
-        const clp sN = St + (e + 1) * TB * ldS;
-        for (int r = wave; r < nrows; r += 8)
-            for (int c = lane * 4; c < S; c += 256) {
-                if (((S & 3) == 0)) g_st4(a.states + ((int64_t)e * a.maxB + row0 + r) * S + c, lds_ld4(sN + r * ldS + c));
-                else for (int kk = 0; kk < 4 && c + kk < S; ++kk) g_st(a.states + ((int64_t)e * a.maxB + row0 + r) * S + c + kk, lds_ld(sN + r * ldS + c + kk));
-            }
+    float scl[4] = {0.f, 0.f, 0.f, 0.f};                    // per-lane state-change partial of executed step k
+    // a [16 x S] LDS tile -> global rows: wave w stores rows 2w, 2w+1, 32 lanes x 16 bytes per row
+    // (the 8-wave tier has S <= 128, S % 4 == 0)
+    auto store_tile = [&](float* gbase, clp tile_lds) {
+        const int r = 2 * wave + (lane >> 5), c = (lane & 31) * 4;
+        if (r < nrows && c < S) g_st4(gbase + (int64_t)(row0 + r) * S + c, lds_ld4(tile_lds + r * ldS + c));
     };
+    auto store_state = [&](int e) { store_tile(a.states + (int64_t)e * a.maxB * S, St + (e + 1) * TB * ldS); };
     auto chain_step = [&](f32x4 (&wc)[8], int k) {
         const int e = X.e(k);
         const clp sC = St + cur * TB * ldS;
         const lp sN = St + (e + 1) * TB * ldS;
         const clp U = Ut + e * TB * ldS;
         const int col = 16 * wave + i, colc = min(col, S - 1);
-        f32x4 acc;
+        f32x4 acc, old;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc[kk] = lds_ld(U + (4 * q + kk) * ldS + colc);
+        for (int kk = 0; kk < 4; ++kk) {
+            acc[kk] = lds_ld(U + (4 * q + kk) * ldS + colc);
+            old[kk] = lds_ld(sC + (4 * q + kk) * ldS + colc);   // this lane's elements of the state being left
+        }
         if (wave < ntS) consume_t<8>(acc, sC, ldS, 0, wc, 0, T0);
         issue_fwd(wc, k + 2);
         if (k > 0) store_state(X.e(k - 1));                 // the previous tile, underneath the MFMAs
         if (wave < ntS && col < S) {
+            float sc = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) lds_st(sN + (4 * q + kk) * ldS + col, acc[kk]);
+            for (int kk = 0; kk < 4; ++kk) {
+                lds_st(sN + (4 * q + kk) * ldS + col, acc[kk]);
+                const float dlt = acc[kk] - old[kk];
+                sc += (4 * q + kk < nrows) ? dlt * dlt : 0.f;     // multimodn.py:174, this lane's share
+            }
+            scl[k] = sc;
         }
         __syncthreads();
         STAMP8();
@@ -2612,32 +2630,17 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
             for (int k = 0; k < 4; ++k) lds_st(sZ + (wave * TB + q * 4 + k) * 16 + i, z[k]);
         }
     }
-    // sum over the tile of (s_r - s_prev(r))^2, fixed order: lane -> (row = lane / 4, 4 column
-    // groups), then a butterfly; rows are dealt to the waves that have no decoder row (or to all
-    // waves when R == 8)
+    // state-change partials: four independent butterflies per wave, then one LDS cell per (step, wave)
     {
-        const int nidle = R < 8 ? 8 - R : 8, first = R < 8 ? R : 0;
-        if (wave >= first) {
-            for (int r = 1 + (wave - first); r < R; r += nidle) {
-                if (!X.row(r)) continue;
-                const clp sr = St + r * TB * ldS, sp = St + X.prev_row(r) * TB * ldS;
-                const int row = lane >> 2;
-                float sc = 0.f;
-                if (row < nrows) {
-                    for (int c = (lane & 3) * 4; c < S; c += 16) {
+        float t4[4];
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            if (c + kk < S) {
-                                const float dlt = lds_ld(sr + row * ldS + c + kk) - lds_ld(sp + row * ldS + c + kk);
-                                sc += dlt * dlt;
-                            }
-                        }
-                    }
-                }
-                sc = wave_sum(sc);
-                if (lane == 0) g_st(a.scp + (int64_t)tile * E + (r - 1), sc);
-            }
+        for (int k = 0; k < 4; ++k) t4[k] = scl[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t4[k] += __shfl_xor(t4[k], off);
         }
+        if (lane < 4) lds_st(sRed + 8 * lane + wave, lane == 0 ? t4[0] : (lane == 1 ? t4[1] : (lane == 2 ? t4[2] : t4[3])));
     }
     if (X.n >= 1) store_state(X.e(X.n - 1));                // the last state tile
     // ---- backward requests: the Wdec^T fragment of this wave's column tile (one k-step: 2D <= 16),
@@ -2649,19 +2652,21 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
         const ParEnc& p2 = a.enc[X.e(ok ? X.n - 1 - j : 0)];
         issue_t<8>(w, a.pack + (ok ? p2.pkb[p2.Lh] : 0), ok ? T0 : 1, ok ? ntS : 1, wave, 0);
     };
+    // (requests are spread over the phases that follow: a burst of 35 KB per wave would sit in
+    //  front of the vector-memory pipe for ~2 us)
     f32x4 wdzq[1];
     issue_t<1>(wdzq, a.pack + a.pkd, 1, ntS, wave, 0);
     issue_bwd(wcA, 0);
-    issue_bwd(wcB, 1);
     const bool actC = act && Lh >= 1;                       // E <= 4: one encoder per wave pair
     f32x4 hqC[2][8], h1qC[2];
-    {
-        const bool okh = Lh >= 1, ok1 = Lh >= 2;
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-            issue_t<8>(hqC[k], a.pack + (okh ? pe.pkh : 0), okh ? T0 : 1, okh ? (HL + 15) >> 4 : 1, half + 2 * k, 0);
+    auto issue_dh = [&](int k) {                            // dh fragments of this pair's encoder, column tile half + 2k
+        const bool okh = Lh >= 1;
+        issue_t<8>(hqC[k], a.pack + (okh ? pe.pkh : 0), okh ? T0 : 1, okh ? (HL + 15) >> 4 : 1, half + 2 * k, 0);
+    };
+    auto issue_dh1 = [&]() {
+        const bool ok1 = Lh >= 2;
         issue_t<2>(h1qC, a.pack + (ok1 ? pe.pkb[1] : 0), ok1 ? (pe.out[1] + 15) >> 4 : 1, ok1 ? (pe.in[1] + 15) >> 4 : 1, half, 0);
-    }
+    };
     __syncthreads();
     STAMP8();
     const int total = R * D * TB;
@@ -2715,6 +2720,11 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
     }
     for (int e = threadIdx.x; e < E; e += NT8)              // encoders that did not run: zero state change
         if (!X.row(e + 1)) g_st(a.scp + (int64_t)tile * E + e, 0.f);
+    if ((int)threadIdx.x < X.n) {                           // executed step k: fixed-order sum over the 8 waves
+        float sm = 0.f;
+        for (int w8 = 0; w8 < 8; ++w8) sm += lds_ld(sRed + 8 * threadIdx.x + w8);
+        g_st(a.scp + (int64_t)tile * E + X.e(threadIdx.x), sm);
+    }
     __syncthreads();                                        // dz tiles complete; u_e tiles dead
     STAMP8();
 
@@ -2746,17 +2756,12 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
             }
         }
     }
+    issue_bwd(wcB, 1);
     __syncthreads();
     STAMP8();
     // ---- phase B': G_out(prev row) += G_out(e) W_s; the accumulator starts from the target tile.
     //      G_out(e) is final when its step starts: its rows go out as dS[e] underneath the MFMAs.
-    auto store_row = [&](int r, int idx) {
-        for (int rr = wave; rr < nrows; rr += 8)
-            for (int c = lane * 4; c < S; c += 256) {
-                if ((S & 3) == 0) g_st4(a.dS + ((int64_t)idx * a.maxB + row0 + rr) * S + c, lds_ld4(DG + (r * TB + rr) * ldS + c));
-                else for (int k = 0; k < 4 && c + k < S; ++k) g_st(a.dS + ((int64_t)idx * a.maxB + row0 + rr) * S + c + k, lds_ld(DG + (r * TB + rr) * ldS + c + k));
-            }
-    };
+    auto store_row = [&](int r, int idx) { store_tile(a.dS + (int64_t)idx * a.maxB * S, DG + r * TB * ldS); };
     {
         auto chain_step = [&](f32x4 (&wc)[8], int j) {
             const int e = X.e(X.n - 1 - j);
@@ -2769,6 +2774,8 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
             for (int k = 0; k < 4; ++k) acc[k] = lds_ld(Gx + (4 * q + k) * ldS + colc);
             if (wave < ntS) consume_t<8>(acc, Go, ldS, 0, wc, 0, T0);
             issue_bwd(wc, j + 2);
+            if (j == 0) issue_dh(0);                        // the hidden-layer backward operands ride along
+            if (j == 1) issue_dh(1);
             store_row(e + 1, e);
             if (wave < ntS && col < S) {
 #pragma unroll
@@ -2788,6 +2795,9 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
             }
         }
     }
+    if (X.n < 1) issue_dh(0);
+    if (X.n < 2) issue_dh(1);
+    issue_dh1();
     store_row(0, E);                                        // dS0 (final since the last barrier)
     STAMP8();
     // ---- phase C': hidden-layer backward of this pair's encoder; h_0 / h_1 are still in the pair's

@@ -20,6 +20,11 @@ torch.cuda.synchronize()
 ptr = eng.lib.mmn_debug_buffer(eng._plan, 3, 0)
 off = ptr - eng.workspace.data_ptr()
 st = eng.workspace[off:off + 8 * 250].view(torch.int64).cpu().numpy()
+f = st[150:166].copy()
+if f[0] > 0:
+    for wv, o in ((0, 0), (5, 8)):
+        print(f"phase C, wave {wv}: z/sums {(f[o+1]-f[o])/100:.2f}  store_state {(f[o+2]-f[o+1])/100:.2f}  "
+              f"issue {(f[o+3]-f[o+2])/100:.2f}  barrier wait {(f[o+4]-f[o+3])/100:.2f}")
 w = st[100:112].copy()
 st = st[:100]
 st = st[st > 0]

@@ -5,8 +5,9 @@ Workload (N=1): BASELINE.json configs[2], the configuration the metric is quoted
 synthetic MIMIC-shaped tabular data, 4 modalities x 64 features, 3 binary tasks, state_dim 128,
 encoder hidden (32, 32) relu, batch 4096 per GPU, Adam lr 1e-3, err_penalty 1, state_change 0.3.
 A "step" = one full training step of one mini-batch whose inputs are already resident in HBM:
-NaN scan + forward chain + backward chain + weight grads + reduction [+ one RCCL all-reduce of
-grads+stats when N>1] + loss/epoch accumulation + torch.optim.Adam(fused) step.
+NaN scan + forward and reverse chain (one fused kernel) + weight grads + reduction with the Adam
+step fused in [N>1: reduction, ONE RCCL all-reduce of grads+stats, loss/epoch accumulation, then
+Adam as its own launch].
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...

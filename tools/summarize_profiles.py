@@ -1,0 +1,36 @@
+"""Turn the rocprofv3 --pmc counter CSVs of tools/collect_profiles.sh into <tag>_pmc_traffic.json:
+per kernel, FETCH_SIZE / WRITE_SIZE per dispatch (KB) and HBM bytes per launch with the gfx950
+correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE counts half of a wide coalesced
+read): hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024."""
+import csv, glob, json, os, re, sys
+from collections import defaultdict
+
+out, tag = sys.argv[1], sys.argv[2]
+res = defaultdict(dict)
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob(os.path.join(out, f"pmc_{counter}", "**", "*counter_collection.csv"), recursive=True)
+    acc, cnt = defaultdict(float), defaultdict(int)
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            m = re.search(r"(k_[a-z0-9_]+)", row["Kernel_Name"])
+            if not m:
+                continue
+            acc[m.group(1)] += float(row["Counter_Value"])
+            cnt[m.group(1)] += 1
+    for k in acc:
+        res[k][f"{counter}_KB_per_launch"] = round(acc[k] / cnt[k], 1)
+        res[k]["launches"] = cnt[k]
+for k, v in res.items():
+    if "FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v:
+        v["hbm_bytes_per_launch"] = int((2 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024)
+doc = {
+    "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 20 --warmup 5 "
+               "--no-cpu-baseline --no-graph   (tools/collect_profiles.sh)",
+    "units": "rocprofv3 FETCH_SIZE / WRITE_SIZE are KB per dispatch; on gfx950 FETCH_SIZE counts half of a wide "
+             "coalesced read (MI355X_MICROARCH.md, HBM section), so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
+    "kernels": dict(res),
+}
+json.dump(doc, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(doc["kernels"], indent=1))

@@ -2410,14 +2410,25 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
     {
         const float* xg = b.x[slotA] + (int64_t)row0 * b.ldx[slotA];
         const int64_t ldx = b.ldx[slotA];
+        // 16-byte loads when every row of the slot is 16-byte aligned (wave-uniform), else four
+        // 4-byte loads from clamped addresses; columns >= F are zeroed either way (a row's padding
+        // may hold anything)
+        const bool xvec = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(b.x[slotA]) & 15) == 0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                      // this half's 8 rows of the x tile
             const int idx = lane + 64 * k;
             const int row = 8 * half + idx / f4, c = (idx % f4) << 2;
             const bool ok = idx < 8 * f4 && row < nrows && c < F;
-            const f32x4 v = g_ld4(xg + (ok ? (int64_t)row * ldx + c : 0));
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            xr[k] = ok ? v : z;
+            const float* px = xg + (ok ? (int64_t)row * ldx + c : 0);
+            f32x4 v;
+            if (xvec) {
+                v = g_ld4(px);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = g_ld(px + ((ok && c + j < F) ? j : 0));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xr[k][j] = (ok && c + j < F) ? v[j] : 0.f;
         }
         issue_t<8>(h0q, a.pack + pe.pkf[l0], (pe.in[l0] + 15) >> 4, (pe.out[l0] + 15) >> 4, half, 0);
         hb0 = g_ld(pe.bias[l0] + min(16 * half + i, pe.out[l0] - 1));
@@ -3812,11 +3823,13 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
         memset(&a, 0, sizeof(a));
         bool ok = pl->par_ok && h.E <= 8 && h.D <= MMN_MAX_DECODERS && h.S <= 128 && (h.S % 4) == 0;
         bool aligned16 = (h.S % 16) == 0;
+        bool f_al = true;
         for (int e = 0; e < h.E && ok; ++e) {
             const mmn_encoder& enc = m->enc[e];
             const int Lh = enc.n_layers - 1;
             ParEnc& pe = a.enc[e];
-            ok = ok && Lh <= 2 && enc.n_features <= 128 && (enc.n_features % 4) == 0;
+            ok = ok && Lh <= 2 && enc.n_features <= 128;
+            f_al = f_al && (enc.n_features % 4) == 0;       // k_fwd8 / k_bwd8 read x with 16-byte loads only
             if (!ok) break;
             pe.F = enc.n_features; pe.Lh = Lh; pe.akind = enc.activation;
             pe.HL = enc.layer[Lh].in_dim - h.S;
@@ -3846,7 +3859,7 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
         ok = ok && pl->f8_lds_fwd <= 160 * 1024 && pl->f8_lds_bwd <= 160 * 1024;
         const char* fe = getenv("MMN_FAST8");
         if (fe && atoi(fe) == 0) ok = false;
-        pl->f8_ok = ok ? 1 : 0;
+        pl->f8_ok = (ok && f_al) ? 1 : 0;
         pl->fb8_lds_bytes = sizeof(float) * (size_t)fb8_lds(h.R, h.ldS, h.ldH, h.ldX).total;
         {
             const char* fb = getenv("MMN_FUSED");
@@ -3930,6 +3943,9 @@ static bool use_fast8(const mmn_plan* p, const mmn_batch* b) {
     return true;
 }
 
+// the fused kernel reads x rows of any alignment
+static bool use_fb8(const mmn_plan* p, const mmn_batch* b) { return p->fb8_ok && b->n_seq >= 1; }
+
 static int rt_for(const mmn_plan* p, const mmn_batch* b) {
     if (p->par_ok) return 1;                 // the parallel-phase kernels use 16-row tiles
     int rt = choose_rt(p, b->batch);
@@ -3939,7 +3955,7 @@ static int rt_for(const mmn_plan* p, const mmn_batch* b) {
 
 const char* mmn_chain_kernel_name(mmn_plan* p, const mmn_batch* b, int backward) {
     if (!p || !b) return "";
-    if (backward == 2) return (use_fast8(p, b) && p->fb8_ok && b->n_seq >= 1) ? "k_fb8" : "";
+    if (backward == 2) return use_fb8(p, b) ? "k_fb8" : "";
     if (use_fast8(p, b)) return backward ? "k_bwd8" : "k_fwd8";
     if (p->par_ok) return backward ? "k_chain_bwd_par" : "k_chain_fwd_par";
     return backward ? "k_chain_bwd" : "k_chain_fwd";
@@ -4009,7 +4025,7 @@ int mmn_chain_bwd(mmn_plan* p, const mmn_batch* b, float sc_pen_x001, void* stre
 int mmn_chain_fwd_bwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float sc_pen_x001, void* stream) {
     int rc = check_batch(p, b);
     if (rc != MMN_OK) return rc;
-    if (use_fast8(p, b) && p->fb8_ok && b->n_seq >= 1) {   // one launch for both chains
+    if (use_fb8(p, b)) {                                   // one launch for both chains
         const int tiles = (b->batch + 15) / 16;
         const float cL = err_penalty / ((float)p->m.n_decoders * (float)(p->m.n_encoders + 1) * (float)b->batch_global);
         mmn_batch bb = *b;

@@ -193,7 +193,9 @@ int mmn_epoch_accumulate(mmn_plan* p, float err_penalty, float state_change_pena
 int mmn_train_step(mmn_plan* p, const mmn_batch* b, float err_penalty, float state_change_penalty_x001,
                    int accumulate_epoch, void* stream);
 
-/* Forward-only step for test()/predict() (multimodn.py:255-419): fwd + reduce (+ accumulate). */
+/* Forward-only step for test()/predict()/get_states() (multimodn.py:255-492): fwd + reduce
+ * (+ accumulate).  Leaves the state rows and the decoder outputs of every grid row in the workspace
+ * (mmn_debug_buffer kinds 0 and 1). */
 int mmn_eval_step(mmn_plan* p, const mmn_batch* b, int accumulate_epoch, void* stream);
 
 /* optimizer.step() (multimodn.py:204) for torch.optim.Adam as the reference pipelines build it
@@ -245,9 +247,15 @@ size_t mmn_epoch_doubles(const mmn_model* m);
 int mmn_epoch_reset(mmn_plan* p, void* stream);
 int mmn_epoch_read(mmn_plan* p, double* out_host, void* stream);
 
-/* Debug/parity access to intermediate buffers of the last step (device pointers into the
- * workspace): kind 0 = state row r [max_batch? no: batch rows x S] (r>=1), 1 = dz row r [B, 2D],
- * 2 = dS for encoder r [B,S] (r = n_encoders -> dS0). Returns NULL if out of range. */
+/* Device pointers (into the workspace) to what the last step left behind; the forward-only
+ * consumers test() / predict() / get_states() (multimodn.py:255-492) read them, parity tests too.
+ *   kind 0, index r in 1..E : state row r, [batch x S] (state after encoder r-1), written by every step
+ *   kind 1, index r in 0..E : [batch x 2D]: after mmn_eval_step the decoder OUTPUTS sigmoid(z) of
+ *                             grid row r (decoder d at columns 2d, 2d+1); after a training step dz
+ *   kind 2, index e         : dS of encoder e [batch x S] (e = n_encoders -> dS0), training only
+ *   kind 3                  : diagnostic timestamps (MMN_STAMPS=1)
+ *   kind 4                  : int32[E+1] "state row exists" flags of the last step (row 0 always 1)
+ * Rows of encoders that did not run hold stale data.  Returns NULL if out of range. */
 const float* mmn_debug_buffer(mmn_plan* p, int kind, int index);
 
 #ifdef __cplusplus

@@ -608,6 +608,9 @@ __device__ __forceinline__ void decode_state(const DecodeCtx& c, clp sS, int gri
             dzv.x = c.cL * g0 * o0 * (1.0f - o0);
             dzv.y = c.cL * g1 * o1 * (1.0f - o1);
             g_st2(p.dz + ((int64_t)grid_row * p.maxB + grow) * (2 * D) + 2 * d, dzv);
+        } else {                                    // forward-only: the decoder OUTPUTS take dz's place (test()/predict())
+            f32x2 ov; ov.x = o0; ov.y = o1;
+            g_st2(p.dz + ((int64_t)grid_row * p.maxB + grow) * (2 * D) + 2 * d, ov);
         }
     }
 #pragma unroll
@@ -986,7 +989,7 @@ __global__ __launch_bounds__(NT) void k_chain_fwd(const DevPlan* __restrict__ P,
         __syncthreads();
         if (threadIdx.x == 0)
             g_st(p.scp + (int64_t)tile * E + e, ((lds_ld(sRed) + lds_ld(sRed + 1)) + lds_ld(sRed + 2)) + lds_ld(sRed + 3));
-        if (want_grads) store_rows(p.states + ((int64_t)e * p.maxB + row0) * S, sN, ldS, nrows, S);
+        store_rows(p.states + ((int64_t)e * p.maxB + row0) * S, sN, ldS, nrows, S);   // also forward-only: get_states()
         cur ^= 1;
         STAMP();
         decode_state<RT>(dc, sS[cur], e + 1);
@@ -1476,7 +1479,7 @@ __global__ __launch_bounds__(NT) void k_chain_fwd_par(const DevPlan* __restrict_
         if (lane == 0) lds_st(sRed + 64 + 4 * e + wave, scacc);
         __syncthreads();
         STAMP();   // B3: barrier
-        if (want_grads) store_rows(p.states + ((int64_t)e * p.maxB + row0) * S, sN, ldS, nrows, S);
+        store_rows(p.states + ((int64_t)e * p.maxB + row0) * S, sN, ldS, nrows, S);   // also forward-only: get_states()
         STAMP();   // B4: state tile stored
         cur = e + 1;
     };
@@ -1541,6 +1544,9 @@ __global__ __launch_bounds__(NT) void k_chain_fwd_par(const DevPlan* __restrict_
                 dzv.x = cL * g0 * o0 * (1.0f - o0);
                 dzv.y = cL * g1 * o1 * (1.0f - o1);
                 g_st2(p.dz + ((int64_t)r * p.maxB + grow) * (2 * D) + 2 * d, dzv);
+            } else {                                // forward-only: the decoder OUTPUTS take dz's place
+                f32x2 ov; ov.x = o0; ov.y = o1;
+                g_st2(p.dz + ((int64_t)r * p.maxB + grow) * (2 * D) + 2 * d, ov);
             }
         }
 #pragma unroll
@@ -2012,8 +2018,8 @@ __global__ __launch_bounds__(NT8) void k_fwd8(const ParArgs a, const mmn_batch b
         scacc = wave_sum(scacc);
         if (lane == 0) lds_st(sRed + 8 * e + wave, scacc);
         __syncthreads();
-        if (want_grads) {                                   // each wave stores two rows of the new state tile
-            for (int r = wave; r < nrows; r += 8)
+        {                                                   // each wave stores two rows of the new state tile
+            for (int r = wave; r < nrows; r += 8)               // (also forward-only: get_states())
                 for (int c = lane * 4; c < S; c += 256) {
                     if (((S & 3) == 0)) g_st4(a.states + ((int64_t)e * a.maxB + row0 + r) * S + c, lds_ld4(sN + r * ldS + c));
                     else for (int k = 0; k < 4 && c + k < S; ++k) g_st(a.states + ((int64_t)e * a.maxB + row0 + r) * S + c + k, lds_ld(sN + r * ldS + c + k));
@@ -2072,6 +2078,9 @@ __global__ __launch_bounds__(NT8) void k_fwd8(const ParArgs a, const mmn_batch b
                 dzv.x = cL * g0 * o0 * (1.0f - o0);
                 dzv.y = cL * g1 * o1 * (1.0f - o1);
                 g_st2(a.dz + ((int64_t)r * a.maxB + grow) * (2 * D) + 2 * d, dzv);
+            } else {                                // forward-only: the decoder OUTPUTS take dz's place
+                f32x2 ov; ov.x = o0; ov.y = o1;
+                g_st2(a.dz + ((int64_t)r * a.maxB + grow) * (2 * D) + 2 * d, ov);
             }
         }
 #pragma unroll
@@ -4180,6 +4189,7 @@ const float* mmn_debug_buffer(mmn_plan* p, int kind, int index) {
         case 1: return (index >= 0 && index < h.R) ? h.dz + (int64_t)index * h.maxB * 2 * h.D : nullptr;
         case 2: return (index >= 0 && index <= h.E) ? h.dS + (int64_t)index * h.maxB * h.S : nullptr;
         case 3: return reinterpret_cast<const float*>(h.stamps);
+        case 4: return reinterpret_cast<const float*>(h.exec_flags);
         default: return nullptr;
     }
 }

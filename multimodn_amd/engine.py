@@ -267,6 +267,20 @@ class HipChainEngine:
         """Last step's stats block (synchronises)."""
         return split_stats(self.stats.detach().cpu().numpy(), self.E, self.D)
 
+    # ------------------------------------------------------------------ what a forward-only step leaves behind
+    def state_rows(self, e: int, batch: int) -> torch.Tensor:
+        """[batch, S] view of the state after encoder e of the last step (any step kind)."""
+        return self.debug_tensor(0, e + 1, self.max_batch, self.S)[:batch]
+
+    def decoder_outputs(self, row: int, batch: int) -> torch.Tensor:
+        """[batch, 2D] view: sigmoid outputs of every decoder on grid row `row` of the last
+        eval_step (decoder d at columns 2d, 2d+1).  After a TRAINING step this buffer holds dz."""
+        return self.debug_tensor(1, row, self.max_batch, 2 * self.D)[:batch]
+
+    def executed_rows(self) -> List[bool]:
+        """Which state rows the last step produced (synchronises; the device NaN policy needs it)."""
+        return [bool(v) for v in self.debug_tensor(4, 0, 1, self.E + 1).view(torch.int32).flatten().tolist()]
+
     def debug_tensor(self, kind: int, index: int, rows: int, cols: int) -> torch.Tensor:
         ptr = self.lib.mmn_debug_buffer(self._plan, kind, index)
         if not ptr:

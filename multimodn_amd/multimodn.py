@@ -24,6 +24,7 @@ from .decoders import MultiModDecoder
 from .encoders import MultiModEncoder
 from .engine import HipChainEngine, check_criterion
 from .history import MultiModNHistory
+from .metrics import get_performance_metrics
 from .state import InitState, TrainableInitState
 
 
@@ -224,9 +225,10 @@ class MultiModN(nn.Module):
             log_results: bool = False,
             logger: Optional[Callable] = None,
     ):
-        """Forward-only epoch (multimodn.py:255-409) on the same HIP forward kernel.  The
-        torchmetrics-based per-decoder report (multimodn.py:410-419) is outside this round's
-        scope (SURVEY.md section 8f #2): returns None."""
+        """Forward-only epoch (multimodn.py:255-419) on the HIP forward kernels.  Appends the
+        `tag` arrays to `history` and returns, per decoder, the reference's 15-value report
+        (get_performance_metrics, multimodn.py:22-49) on the decoder fed with the state after the
+        last encoder, computed natively (multimodn_amd/metrics.py) instead of via torchmetrics."""
         check_criterion(criterion)
         if log_results and not logger:
             logger = print
@@ -234,6 +236,8 @@ class MultiModN(nn.Module):
         n_batches = len(test_loader)
         eng = None
         keep = None
+        outputs_epoch: List[Tensor] = []
+        targets_epoch: List[Tensor] = []
         for batch in test_loader:
             data, target, encoder_sequence = (list(batch) + [None])[:3]
             if eng is None:
@@ -241,7 +245,13 @@ class MultiModN(nn.Module):
                 eng.epoch_reset()
             else:
                 eng.ensure(int(target.shape[0]))
-            _, keep = self._run_step(eng, data, target, encoder_sequence, train=False)
+            executed, keep = self._run_step(eng, data, target, encoder_sequence, train=False)
+            if executed is None:                               # device NaN policy: ask the GPU which rows exist
+                executed = eng.executed_rows()[1:]
+            last = len(self.encoders) - 1
+            targets_epoch.append(keep[1].detach().to("cpu"))
+            if executed[last]:                                  # multimodn.py:354-357: only the LAST encoder's row
+                outputs_epoch.append(eng.decoder_outputs(last + 1, int(keep[1].shape[0])).clone())
         if eng is None:
             return None
         arrays = self._epoch_arrays(eng, n_batches)
@@ -254,12 +264,64 @@ class MultiModN(nn.Module):
         if history is not None:
             for name in ("loss", "accuracy", "sensitivity", "specificity", "balanced_accuracy"):
                 getattr(history, name).setdefault(tag, []).append(arrays[name])
-        return None
+        # per-decoder report on the state after the last encoder (multimodn.py:410-419)
+        results: List = [[]] * len(self.decoders)
+        if outputs_epoch:
+            out = torch.cat(outputs_epoch, dim=0).to("cpu")            # [N, 2D]
+            tgt = torch.cat(targets_epoch, dim=0)
+            for d in range(len(self.decoders)):
+                o = out[:, 2 * d:2 * d + 2]
+                o = torch.div(o, torch.sum(o, dim=1).reshape(-1, 1))   # class probabilities sum to 1 (:415)
+                _, pred = torch.max(o, dim=1)
+                results[d] = get_performance_metrics(tgt[:, d], pred, o[:, 1])
+        return results
 
     def predict(self, x: List[Tensor], encoder_sequence: Optional[np.ndarray] = None) -> np.ndarray:
-        raise NotImplementedError("predict() (multimodn.py:422-458) is scheduled after the training "
-                                  "hot path (SURVEY.md section 8f #2)")
+        """Predicted class of every decoder on every state: ndarray [(E+1), D, N] (multimodn.py:422-458).
+        As in the reference there is NO NaN skip on this path, and rows of encoders that are not in
+        the sequence stay 0."""
+        self.eval()
+        n_samples = int(x[0].shape[0])
+        full = np.zeros((len(self.encoders) + 1, len(self.decoders), n_samples))
+        if n_samples == 0:
+            return full
+        seq = None if encoder_sequence is None else np.asarray(encoder_sequence)
+        pairs = self.get_encoder_iterable(seq, self.shuffle_mode, train=False)
+        eng = self._get_engine(n_samples)
+        xs = [t.to(self.device, dtype=torch.float32).contiguous() for t in x]
+        y = torch.zeros((n_samples, len(self.decoders)), dtype=torch.int64, device=self.device)
+        b = eng.make_batch(xs, y, pairs, batch_global=n_samples, device_nan_flags=False)
+        eng.eval_step(b, accumulate=False)
+        D = len(self.decoders)
+        for row in [0] + [e + 1 for _, e in pairs]:
+            o = eng.decoder_outputs(row, n_samples)
+            pred = (o[:, 1::2] > o[:, 0::2])                    # torch.max: first index wins ties
+            full[row] = pred.to(torch.float64).t().cpu().numpy().reshape(D, n_samples)
+        del xs, y
+        return full
 
     def get_states(self, data_loader: DataLoader) -> List[Tensor]:
-        raise NotImplementedError("get_states() (multimodn.py:460-492) is scheduled after the training "
-                                  "hot path (SURVEY.md section 8f #2)")
+        """The state after the last executed encoder, one [S] tensor per sample (multimodn.py:460-492)."""
+        self.eval()
+        batch_states: List[Tensor] = []
+        for batch in data_loader:
+            data, _, encoder_sequence = (list(batch) + [None])[:3]
+            n = int(data[0].shape[0])
+            eng = self._get_engine(n)
+            dummy = torch.zeros((n, len(self.decoders)), dtype=torch.int64)
+            pairs = self.get_encoder_iterable(encoder_sequence, self.shuffle_mode, train=False)
+            xs, y, exec_pairs, executed = self._ingest(data, dummy, pairs)
+            b = eng.make_batch(xs, y, exec_pairs, batch_global=n, device_nan_flags=executed is None)
+            eng.eval_step(b, accumulate=False)
+            if executed is None:
+                executed = eng.executed_rows()[1:]
+            last = None
+            for _, e in pairs:
+                if executed[e]:
+                    last = e
+            if last is None:
+                batch_states.append(self.init_state(n).detach().to(self.device))
+            else:
+                batch_states.append(eng.state_rows(last, n).clone())
+            del xs, y
+        return list(torch.cat(batch_states, dim=0)) if batch_states else []

@@ -401,6 +401,129 @@ def train_epoch(params: Dict[str, np.ndarray], spec: ModelSpec, batches, optimiz
     return aggregate_epoch(spec.E, spec.D, results, sizes)
 
 
+# ------------------------------------------------------------------------------------------------
+# forward-only entry points: test() / predict() / get_states() (multimodn.py:255-492)
+# ------------------------------------------------------------------------------------------------
+def decoder_outputs(params: Dict[str, np.ndarray], spec: ModelSpec, state: np.ndarray, dtype=np.float32) -> np.ndarray:
+    """sigmoid(Linear(state)) of every decoder (decoders.py:19-20): [B, D, 2]."""
+    dt = np.dtype(dtype)
+    s = np.asarray(state, dt)
+    out = np.zeros((s.shape[0], spec.D, 2), dt)
+    for d in range(spec.D):
+        z = s @ np.asarray(params[f"decoders.{d}.fc.weight"], dt).T + np.asarray(params[f"decoders.{d}.fc.bias"], dt)
+        out[:, d, :] = 1.0 / (1.0 + np.exp(-z))
+    return out
+
+
+def test_epoch(params, spec: ModelSpec, batches, dtype=np.float32):
+    """multimodn.py:255-419 without the optimiser: returns (EpochResult with the 'test' History
+    arrays, outputs) where outputs[d] = (y_true [N], y_pred [N], y_prob [N]) for the decoder on the
+    state after the LAST encoder (enc_idx == E-1, :354-357), probabilities renormalised to sum to 1
+    (:415), prediction = argmax of the renormalised pair (first index wins ties)."""
+    eval_spec = ModelSpec(spec.state_size, spec.encoders, spec.D, 1.0, 0.0)
+    results, sizes = [], []
+    outs, tgts = [], []
+    for batch in batches:
+        xs, y, seq = (list(batch) + [None])[:3]
+        r = forward_backward(params, eval_spec, xs, y, seq, dtype=dtype, want_grads=False, keep_states=True)
+        results.append(r)
+        sizes.append(np.asarray(y).shape[0])
+        tgts.append(np.asarray(y))
+        if r.executed[spec.E - 1]:
+            outs.append(decoder_outputs(params, spec, r.states[spec.E], dtype))
+    ep = aggregate_epoch(spec.E, spec.D, results, sizes)
+    outputs = []
+    if outs:
+        o = np.concatenate(outs, axis=0)
+        t = np.concatenate(tgts, axis=0)
+        for d in range(spec.D):
+            p = o[:, d, :] / o[:, d, :].sum(axis=1, keepdims=True)
+            pred = (p[:, 1] > p[:, 0]).astype(np.int64)
+            outputs.append((t[:, d].astype(np.int64), pred, p[:, 1]))
+    return ep, outputs
+
+
+def predict(params, spec: ModelSpec, xs, encoder_sequence=None, dtype=np.float32) -> np.ndarray:
+    """multimodn.py:422-458: argmax class of every decoder on every state, [(E+1), D, N] float64;
+    rows of encoders outside the sequence stay 0; NO NaN skip on this path."""
+    N = np.asarray(xs[0]).shape[0]
+    dummy_y = np.zeros((N, spec.D), np.int64)
+    r = forward_backward(params, spec, xs, dummy_y, encoder_sequence, dtype=dtype, want_grads=False,
+                         keep_states=True, present_override=[True] * len(encoder_iterable(spec.E, encoder_sequence)))
+    full = np.zeros((spec.E + 1, spec.D, N))
+    for row, st in r.states.items():
+        o = decoder_outputs(params, spec, st, dtype)
+        full[row] = (o[:, :, 1] > o[:, :, 0]).T.astype(np.float64)
+    return full
+
+
+def get_states(params, spec: ModelSpec, batches, dtype=np.float32) -> np.ndarray:
+    """multimodn.py:460-492: the state after the last EXECUTED encoder of every sample, [N, S]."""
+    out = []
+    for batch in batches:
+        xs, y, seq = (list(batch) + [None])[:3]
+        N = np.asarray(xs[0]).shape[0]
+        r = forward_backward(params, spec, xs, np.zeros((N, spec.D), np.int64), seq, dtype=dtype,
+                             want_grads=False, keep_states=True)
+        last = 0
+        for _, e in encoder_iterable(spec.E, seq):
+            if r.executed[e]:
+                last = e + 1
+        out.append(r.states[last])
+    return np.concatenate(out, axis=0)
+
+
+def performance_metrics(y_true: np.ndarray, y_pred: np.ndarray, y_prob: np.ndarray) -> Dict[str, object]:
+    """get_performance_metrics (multimodn.py:22-49) with the torchmetrics binary metrics restated
+    (torchmetrics is a third-party dependency of the reference, unpinned in requirements-cpu.txt and
+    absent from this image; algorithms as published for torchmetrics >= 1.0, thresholds=None):
+      * f1       : F1Score(task="binary") on the PROBABILITIES -> thresholded at 0.5 (prob > 0.5),
+                   2tp / (2tp + fp + fn), 0 when the denominator is 0
+      * auc      : AUROC(task="binary") = trapezoidal area under the exact ROC curve below
+      * accuracy : Accuracy(task="binary") on the predicted labels
+      * sensitivity / specificity from ConfusionMatrix(y_pred, y_true) (0 when undefined, :38-45)
+      * fpr, tpr, thr_roc : ROC(task="binary"): samples sorted by descending score, one point per
+                   DISTINCT score (cumulative fp / tp), a leading (0, 0) point with threshold 1.0,
+                   then divided by the totals
+      * precision, recall, thr_pr : PrecisionRecallCurve(task="binary"): the same distinct-score
+                   points, precision = tp/(tp+fp), recall = tp/tp_total, reversed so that recall
+                   decreases, with a final (precision 1, recall 0) point; thresholds ascending."""
+    y_true = np.asarray(y_true).astype(np.int64)
+    y_pred = np.asarray(y_pred).astype(np.int64)
+    y_prob = np.asarray(y_prob, np.float32)
+    tp = int(((y_pred == 1) & (y_true == 1)).sum()); tn = int(((y_pred == 0) & (y_true == 0)).sum())
+    fp = int(((y_pred == 1) & (y_true == 0)).sum()); fn = int(((y_pred == 0) & (y_true == 1)).sum())
+    sens = tp / (tp + fn) if (tp + fn) != 0 else 0
+    spec_ = tn / (tn + fp) if (tn + fp) != 0 else 0
+    hard = (y_prob > 0.5).astype(np.int64)
+    tp5 = int(((hard == 1) & (y_true == 1)).sum()); fp5 = int(((hard == 1) & (y_true == 0)).sum())
+    fn5 = int(((hard == 0) & (y_true == 1)).sum())
+    f1 = 2 * tp5 / (2 * tp5 + fp5 + fn5) if (2 * tp5 + fp5 + fn5) != 0 else 0.0
+    order = np.argsort(-y_prob, kind="stable")
+    ps, ts = y_prob[order], y_true[order]
+    distinct = np.nonzero(np.diff(ps))[0]
+    idx = np.concatenate([distinct, [len(ps) - 1]]) if len(ps) else np.array([], np.int64)
+    tps = np.cumsum(ts)[idx].astype(np.float64)
+    fps = (1 + idx - tps).astype(np.float64)
+    thr = ps[idx]
+    tps0 = np.concatenate([[0.0], tps]); fps0 = np.concatenate([[0.0], fps])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        fpr = fps0 / fps0[-1] if fps0[-1] > 0 else np.zeros_like(fps0)
+        tpr = tps0 / tps0[-1] if tps0[-1] > 0 else np.zeros_like(tps0)
+        precision = tps / (tps + fps)
+        recall = tps / tps[-1] if len(tps) and tps[-1] > 0 else np.zeros_like(tps)
+    auc = float(np.trapezoid(tpr, fpr))
+    return {"f1": f1, "auc": auc, "accuracy": (tp + tn) / max(len(y_true), 1), "sensitivity": sens,
+            "specificity": spec_, "fpr": fpr, "tpr": tpr,
+            "precision": np.concatenate([precision[::-1], [1.0]]), "recall": np.concatenate([recall[::-1], [0.0]]),
+            "tn": tn, "fp": fp, "fn": fn, "tp": tp,
+            "thr_roc": np.concatenate([[1.0], thr]), "thr_pr": thr[::-1].copy()}
+
+
+PERFORMANCE_METRICS = ["f1", "auc", "accuracy", "sensitivity", "specificity", "fpr", "tpr", "precision", "recall",
+                       "tn", "fp", "fn", "tp", "thr_roc", "thr_pr"]       # multimodn.py:18-19 (tuple order of :47-49)
+
+
 def per_sample_step(params, spec: ModelSpec, xs, y, sequences, dtype=np.float32) -> StepResult:
     """Build-defined extension for per-sample missingness / per-sample encoder order (SURVEY 9.6,
     BASELINE config 5): the reference only defines this at batch size 1 (multimodn.py:518-523 raises

@@ -57,9 +57,16 @@ def install_shims():
         def __call__(self, *a, **k):
             return torch.tensor(float("nan"))
 
+    class _Inert3(_Inert):                         # the curve metrics return (x, y, thresholds)
+        def __call__(self, *a, **k):
+            nan = torch.tensor(float("nan"))
+            return nan, nan, nan
+
     tm.ConfusionMatrix = ConfusionMatrix
-    for n in ("F1Score", "ROC", "PrecisionRecallCurve", "Accuracy", "AUROC"):
+    for n in ("F1Score", "Accuracy", "AUROC"):
         setattr(tm, n, type(n, (_Inert,), {}))
+    for n in ("ROC", "PrecisionRecallCurve"):
+        setattr(tm, n, type(n, (_Inert3,), {}))
     sys.modules["torchmetrics"] = tm
 
     import torch._utils
@@ -184,8 +191,21 @@ def run_reference(name, cfg, seed=0):
             model.train_epoch(loader, opt, crit, hist)
     finally:
         torch.Tensor.backward = orig_backward
+    # forward-only entry points on the TRAINED model (multimodn.py:255-492): History arrays of
+    # test(), predict() on the first batch, get_states() over the loader.  (test()'s per-decoder
+    # report goes through torchmetrics, which is stubbed here: not recorded.)
+    ev = {}
+    test_hist = MultiModNHistory([f"t{d}" for d in range(D)])
+    model.test(loader, torch.nn.CrossEntropyLoss(), test_hist, tag="test")
+    for k in ("loss", "accuracy", "sensitivity", "specificity", "balanced_accuracy"):
+        ev[f"test_{k}"] = np.asarray(getattr(test_hist, k)["test"][0])
+    b0 = loader[0]
+    if not any(bool(torch.isnan(t).any()) for t in b0[0]):
+        seq0 = b0[2] if len(b0) > 2 else None      # (a Tensor: get_encoder_iterable calls .numpy(), multimodn.py:518)
+        ev["predict"] = model.predict(b0[0], seq0)
+    ev["states"] = torch.stack(model.get_states(loader)).numpy()
     return dict(init=init, batches=batches_np, crit_calls=crit.calls, grads=opt.grads,
-                params=opt.params, losses=losses, hist=hist)
+                params=opt.params, losses=losses, hist=hist, eval=ev)
 
 
 def spec_of(cfg):
@@ -238,11 +258,13 @@ def main():
                     out[f"step{s}/param/{n}"] = p
         for n, p in ref["params"][-1].items():
             out[f"final/{n}"] = p
+        for k, v in ref["eval"].items():
+            out[f"eval/{k}"] = v
 
         # ---- verify the oracle (fp32 and fp64) against what the reference just produced
         params = {n: v.copy() for n, v in ref["init"].items()}
         opt = O.Adam(cfg["lr"])
-        w = dict(loss=0.0, grad=0.0, param=0.0, hist=0.0, crit=0.0)
+        w = dict(loss=0.0, grad=0.0, param=0.0, hist=0.0, crit=0.0, eval=0.0)
         ci = 0
         ep_results = []
         for ep in range(cfg["epochs"]):
@@ -275,11 +297,21 @@ def main():
             assert np.array_equal(er.specificity, h.specificity["train"][ep]), name
             assert np.array_equal(er.balanced_accuracy, h.balanced_accuracy["train"][ep]), name
         assert ci == len(ref["crit_calls"])
+        # ---- forward-only entry points: oracle on the reference's TRAINED weights vs the reference
+        fin = {n: p.copy() for n, p in ref["params"][-1].items()}
+        ev = ref["eval"]
+        tep, _ = O.test_epoch(fin, spec, ref["batches"])
+        w["eval"] = max(rel(tep.loss, ev["test_loss"]), rel(O.get_states(fin, spec, ref["batches"]), ev["states"]))
+        assert np.array_equal(tep.accuracy, ev["test_accuracy"]), name
+        assert np.array_equal(tep.sensitivity, ev["test_sensitivity"]) and np.array_equal(tep.specificity, ev["test_specificity"]), name
+        if "predict" in ev:
+            b0 = ref["batches"][0]
+            assert np.array_equal(O.predict(fin, spec, b0[0], b0[2] if len(b0) > 2 else None), ev["predict"]), name
         worst[name] = w
         print(f"{name:14s} steps={n_steps:3d} oracle-vs-reference rel err: " +
               " ".join(f"{k}={v:.2e}" for k, v in w.items()))
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
-    bad = {n: w for n, w in worst.items() if w["loss"] > 2e-6 or w["crit"] > 2e-6}
+    bad = {n: w for n, w in worst.items() if w["loss"] > 2e-6 or w["crit"] > 2e-6 or w["eval"] > 2e-6}
     assert not bad, bad
 
 

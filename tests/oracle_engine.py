@@ -69,7 +69,8 @@ class OracleEngine:
         if not b.pairs:
             xs, seq, override = [], np.zeros((len(b.y), 0), np.int64), []
         r = O.forward_backward(params, spec, xs, b.y, seq, batch_global=b.batch_global,
-                               present_override=override, want_grads=want_grads)
+                               present_override=override, want_grads=want_grads, keep_states=True)
+        self._last = (params, r)
         R, D, E = self.E + 1, self.D, self.E
         st = np.zeros(self.n_stats, np.float32)
         RD = R * D
@@ -103,6 +104,18 @@ class OracleEngine:
             self.spec = spec
         if accumulate:
             self.accumulate(1.0, 0.0)
+
+    # what a step leaves behind (HipChainEngine.state_rows / decoder_outputs / executed_rows)
+    def state_rows(self, e, batch):
+        return torch.from_numpy(np.ascontiguousarray(self._last[1].states[e + 1][:batch]))
+
+    def decoder_outputs(self, row, batch):
+        params, r = self._last
+        o = O.decoder_outputs(params, self.spec, r.states[row][:batch])
+        return torch.from_numpy(np.ascontiguousarray(o.reshape(o.shape[0], -1)))
+
+    def executed_rows(self):
+        return [True] + [bool(v) for v in self._last[1].executed]
 
     def accumulate(self, alpha, beta):
         """numpy twin of k_epoch_accumulate."""

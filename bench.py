@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--graph-steps", type=int, default=8, help="consecutive steps captured into one hipGraph")
     ap.add_argument("--optimizer", choices=("hip", "torch"), default="hip",
                     help="hip: multimodn_amd.optim.Adam (one k_adam launch); torch: torch.optim.Adam(fused, capturable)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="testing aid: take the data-parallel code path (process group, all-reduce, separate Adam) "
+                         "even with one rank")
     ap.add_argument("--no-fused-adam", action="store_true", help="keep optimizer.step() a separate k_adam launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -150,8 +153,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    dp = world > 1 or args.force_dist
+    if dp:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:                  # --force-dist without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
 
     wl = WORKLOADS[args.workload]
@@ -160,7 +166,7 @@ def main():
     params = O.init_params(spec, 0)                           # same weights on every rank
     model = build_torch_model(spec, params, dev, mm)
     model.nan_policy = "device"
-    if world > 1:
+    if dp:
         model.enable_data_parallel()
     eng = model._get_engine(B)
     if args.optimizer == "hip":
@@ -180,20 +186,20 @@ def main():
     batches = [eng.make_batch(xs, y, pairs, batch_global=B * world, device_nan_flags=True) for xs, y in resident]
     alpha, beta = float(model.err_penalty), float(model.state_change_penalty)
 
-    fuse_opt = opt if (world == 1 and args.optimizer == "hip" and not args.no_fused_adam) else None
+    fuse_opt = opt if (not dp and args.optimizer == "hip" and not args.no_fused_adam) else None
 
     def step(i):
         b = batches[i % len(batches)]
         # single GPU: Adam rides in the last launch (k_reduce) of the step; N > 1: all-reduce first
-        eng.local_step(b, alpha, beta, accumulate=(world == 1), optimizer=fuse_opt)
-        if world > 1:
+        eng.local_step(b, alpha, beta, accumulate=not dp, optimizer=fuse_opt)
+        if dp:
             dist.all_reduce(eng.reduce_buf)                  # ONE collective per step: grads + stats
             eng.accumulate(alpha, beta)
         opt.step()                                           # no-op when the step was fused
 
     eng.assign_grads(None)
     eng.epoch_reset()
-    use_graph = (not args.no_graph) and (world == 1 or args.graph)
+    use_graph = (not args.no_graph) and (not dp or args.graph)
     graphs = None
     group = 1
     for i in range(3):                                        # eager warm-up (also initialises Adam state)
@@ -342,7 +348,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

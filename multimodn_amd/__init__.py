@@ -5,14 +5,14 @@ from .state import InitState, TrainableInitState, StaticInitState
 from .encoders import MultiModEncoder, MLPEncoder, SLPEncoder, LinearEncoder, LogisticEncoder
 from .decoders import MultiModDecoder, ClassDecoder, LogisticDecoder
 from .history import MultiModNHistory
-from .datasets import MultiModDataset, PartitionDataset, FeatureWiseDataset, JointDatasets
+from .datasets import MultiModDataset, PartitionDataset, FeatureWiseDataset, JointDatasets, DeviceResidentLoader
 from .multimodn import MultiModN
 from .engine import HipChainEngine, UnsupportedModelError
-from . import optim
+from . import optim, metrics
 
 __all__ = [
     "InitState", "TrainableInitState", "StaticInitState", "MultiModEncoder", "MLPEncoder", "SLPEncoder",
     "LinearEncoder", "LogisticEncoder", "MultiModDecoder", "ClassDecoder", "LogisticDecoder",
     "MultiModNHistory", "MultiModDataset", "PartitionDataset", "FeatureWiseDataset", "JointDatasets",
-    "MultiModN", "HipChainEngine", "UnsupportedModelError", "optim",
+    "MultiModN", "HipChainEngine", "UnsupportedModelError", "optim", "DeviceResidentLoader", "metrics",
 ]

@@ -70,3 +70,77 @@ class JointDatasets(MultiModDataset):
 
     def __getitem__(self, idx: int) -> Tuple[List[Tensor], np.ndarray]:
         return [torch.cat(d[idx][0]) for d in self.datasets], self.datasets[0][idx][1]
+
+
+class DeviceResidentLoader:
+    """Data feed for the HIP path: the whole partitioned dataset lives in
+    HBM (288 GB per MI355X) and every batch is a set of device VIEWS in the batch format
+    train_epoch unpacks (multimodn.py:119): `(List[[B, F_k] f32], [B, D] i64 [, [B, E] i64])`.
+    No per-sample `Tensor(...)` construction, no collate, no host-to-device copy per step; with
+    `MultiModN.nan_policy = "device"` a training epoch then runs without a single host sync.
+
+    Drop-in where a pipeline builds `DataLoader(dataset, batch_size, shuffle=...)`
+    (pipelines/titanic/titanic_mlp_pipeline.py:57-60): same iteration protocol and `len()`.
+    `shuffle=True` draws a fresh device permutation per epoch and gathers each batch on the device.
+    """
+
+    def __init__(self, dataset, batch_size: int, shuffle: bool = False, drop_last: bool = False,
+                 device: Optional[torch.device] = None, generator: Optional[Generator] = None):
+        self.device = torch.device(device) if device is not None else torch.device("cuda")
+        self.batch_size = int(batch_size)
+        self.shuffle, self.drop_last, self.generator = shuffle, drop_last, generator
+        data, targets, seq = self._materialise(dataset)
+        self.data = [d.to(self.device, dtype=torch.float32).contiguous() for d in data]
+        self.targets = targets.to(self.device, dtype=torch.int64).contiguous()
+        if self.targets.dim() == 1:
+            self.targets = self.targets.view(-1, 1)
+        self.sequence = None if seq is None else seq.to(self.device, dtype=torch.int64).contiguous()
+        self.n = int(self.targets.shape[0])
+
+    @staticmethod
+    def _materialise(dataset):
+        """One pass over the dataset's items (or a ready (data, targets[, sequence]) tuple)."""
+        if isinstance(dataset, (tuple, list)) and len(dataset) in (2, 3) and isinstance(dataset[0], (list, tuple)) \
+                and all(isinstance(t, Tensor) for t in dataset[0]):
+            seq = dataset[2] if len(dataset) == 3 else None
+            return list(dataset[0]), torch.as_tensor(np.asarray(dataset[1]) if not isinstance(dataset[1], Tensor) else dataset[1]), \
+                (None if seq is None else torch.as_tensor(np.asarray(seq) if not isinstance(seq, Tensor) else seq))
+        if isinstance(dataset, PartitionDataset):                      # columns are already contiguous arrays
+            return [torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) for x in dataset.X], \
+                torch.from_numpy(np.asarray(dataset.y)), None
+        cols, ys, seqs = None, [], []
+        for i in range(len(dataset)):
+            item = dataset[i]
+            d, y, sq = (list(item) + [None])[:3]
+            if cols is None:
+                cols = [[] for _ in d]
+            for k, t in enumerate(d):
+                cols[k].append(torch.as_tensor(t, dtype=torch.float32).reshape(1, -1))
+            ys.append(np.asarray(y).reshape(1, -1))
+            if sq is not None:
+                seqs.append(np.asarray(sq).reshape(1, -1))
+        if cols is None:
+            raise ValueError("empty dataset")
+        return [torch.cat(c, dim=0) for c in cols], torch.from_numpy(np.concatenate(ys, 0)), \
+            (torch.from_numpy(np.concatenate(seqs, 0)) if seqs else None)
+
+    def __len__(self) -> int:
+        return self.n // self.batch_size if self.drop_last else -(-self.n // self.batch_size)
+
+    def __iter__(self):
+        perm = None
+        if self.shuffle:
+            g = self.generator
+            perm = (torch.randperm(self.n, generator=g) if g is not None else torch.randperm(self.n)).to(self.device)
+        for i in range(len(self)):
+            lo, hi = i * self.batch_size, min(self.n, (i + 1) * self.batch_size)
+            if perm is None:
+                item = [[d[lo:hi] for d in self.data], self.targets[lo:hi]]
+                if self.sequence is not None:
+                    item.append(self.sequence[lo:hi])
+            else:
+                idx = perm[lo:hi]
+                item = [[d.index_select(0, idx) for d in self.data], self.targets.index_select(0, idx)]
+                if self.sequence is not None:
+                    item.append(self.sequence.index_select(0, idx))
+            yield tuple(item)

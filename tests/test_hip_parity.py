@@ -297,3 +297,36 @@ def test_no_silent_fallback_off_gpu(lib):
     loader = [([torch.zeros(4, 4)], torch.zeros(4, 1, dtype=torch.int64))]
     with pytest.raises(lib.hip.MmnError):
         model.train_epoch(loader, torch.optim.Adam(model.parameters()), torch.nn.CrossEntropyLoss())
+
+
+def test_device_resident_loader_equals_host_batches(lib):
+    """DeviceResidentLoader (data feed in HBM): same batches, same History and weights
+    as a host-side list of the same batches; a PartitionDataset goes in without a per-sample loop."""
+    g = Golden("c2_split")
+    batches = g.batches()
+    X = np.concatenate([np.concatenate(b[0], axis=1) for b in batches], axis=0)
+    y = np.concatenate([b[1] for b in batches], axis=0)
+    ds = lib.PartitionDataset(X, y, [x.shape[1] for x in batches[0][0]])
+    B = batches[0][1].shape[0]
+    dev_loader = lib.DeviceResidentLoader(ds, B, device="cuda")
+    assert len(dev_loader) == len(batches)
+    first = next(iter(dev_loader))
+    assert first[0][0].is_cuda and first[1].dtype == torch.int64 and tuple(first[1].shape) == batches[0][1].shape
+    host_loader = [([torch.from_numpy(x) for x in b[0]], torch.from_numpy(b[1])) for b in batches]
+    out = []
+    for loader, policy in ((host_loader, "host"), (dev_loader, "device"), (dev_loader, "host")):
+        model = build_torch_model(g.spec, g.init_params(), "cuda", lib)
+        model.nan_policy = policy
+        opt = lib.optim.Adam(list(model.parameters()), g.cfg["lr"])
+        hist = lib.MultiModNHistory(["a", "b"])
+        for _ in range(2):
+            model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+        out.append((np.stack(hist.loss["train"]), {n: p.detach().cpu().numpy() for n, p in model.named_parameters()}))
+    for loss, params in out[1:]:
+        assert np.array_equal(loss, out[0][0])
+        for n in params:
+            assert np.array_equal(params[n], out[0][1][n]), n
+    # shuffled epochs: a permutation of the rows, reproducible from the generator
+    sh = lib.DeviceResidentLoader(ds, B, shuffle=True, device="cuda", generator=torch.Generator().manual_seed(5))
+    rows = torch.cat([b[1] for b in sh], dim=0).cpu().numpy()
+    assert rows.shape == y.reshape(len(y), -1).shape and rows.sum() == y.sum()

@@ -41,6 +41,10 @@ WORKLOADS = {
     "c3": dict(S=128, F=[64] * 4, H=(32, 32), D=3, B=4096, lr=1e-3, pen=(1.0, 0.3),
                text="MIMIC-shaped tabular: 4 modalities x 64 features, hidden (32,32) relu, 3 binary tasks, "
                     "state_dim 128, batch 4096 per GPU, Adam lr 1e-3, penalties 1.0/0.3"),
+    "c5": dict(S=128, F=[64] * 4, H=(32, 32), D=3, B=4096, lr=1e-3, pen=(1.0, 0.3), per_sample=True,
+               text="BASELINE configs[4]: the MIMIC-shaped model with per-sample missing modalities (30 % missing not at "
+                    "random, NaN rows) and a random encoder order per sample, batch 4096 per GPU; a step includes the "
+                    "on-device regrouping of the rows into tiles of one executed sequence (eager launches)"),
     "c2": dict(S=64, F=[3, 2], H=(5, 5), D=2, B=512, lr=1e-2, pen=(0.7, 0.3),
                text="Titanic-shaped, 2 encoders (features split 3+2), hidden (5,5) relu, 2 binary tasks, state_dim 64, "
                     "batch 512, Adam lr 1e-2, penalties 0.7/0.3 (latency-bound)"),
@@ -183,13 +187,39 @@ def main():
     for xs, y in host:
         resident.append(([torch.from_numpy(x).to(dev) for x in xs], torch.from_numpy(y).to(dev)))
     pairs = [(i, i) for i in range(spec.E)]
-    batches = [eng.make_batch(xs, y, pairs, batch_global=B * world, device_nan_flags=True) for xs, y in resident]
+    per_sample = bool(wl.get("per_sample"))
+    seqs = None
+    if per_sample:
+        # modality e is missing (NaN row) with probability 0.45 if y_0 = 1 else 0.15
+        # (mean 0.3); every sample carries its own random permutation of the encoders
+        rng = np.random.default_rng(1 + rank)
+        seqs = []
+        for xs, y in resident:
+            p_miss = torch.where(y[:, :1] == 1, 0.45, 0.15).cpu().numpy()
+            miss = torch.from_numpy(rng.random((B, spec.E)) < p_miss).to(dev)
+            for e in range(spec.E):
+                xs[e][miss[:, e]] = float("nan")
+            seqs.append(torch.from_numpy(np.stack([rng.permutation(spec.E) for _ in range(B)]).astype(np.int64)).to(dev))
+        args.no_graph = True                                 # the regrouping uses torch ops that size-sync
+        batches, _keep_ps = [], []
+        for (xs, y), sq in zip(resident, seqs):              # (only for the per-kernel timing section below)
+            bb, kk = eng.per_sample_batch(xs, y, sq)
+            bb.batch_global = B * world
+            batches.append(bb); _keep_ps.append(kk)
+    else:
+        batches = [eng.make_batch(xs, y, pairs, batch_global=B * world, device_nan_flags=True) for xs, y in resident]
     alpha, beta = float(model.err_penalty), float(model.state_change_penalty)
 
     fuse_opt = opt if (not dp and args.optimizer == "hip" and not args.no_fused_adam) else None
 
     def step(i):
-        b = batches[i % len(batches)]
+        if per_sample:                                       # regroup THIS batch's rows, then the usual step
+            xs, y = resident[i % len(resident)]
+            b, keep = eng.per_sample_batch(xs, y, seqs[i % len(seqs)])
+            b.batch_global = B * world
+            step.keep = keep
+        else:
+            b = batches[i % len(batches)]
         # single GPU: Adam rides in the last launch (k_reduce) of the step; N > 1: all-reduce first
         eng.local_step(b, alpha, beta, accumulate=not dp, optimizer=fuse_opt)
         if dp:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MMN_VERSION 100            /* 0.1.0 */
+#define MMN_VERSION 101            /* 0.1.1: mmn_batch grew tile_rows / tile_seq */
 #define MMN_MAX_ENCODERS 16
 #define MMN_MAX_DECODERS 8
 #define MMN_MAX_LAYERS 8           /* hidden layers + the state-update Linear */
@@ -113,6 +113,20 @@ typedef struct mmn_batch {
     int32_t reserved;
     int32_t seq_data[MMN_MAX_ENCODERS];
     int32_t seq_enc[MMN_MAX_ENCODERS];
+    /* Per-sample mode (BASELINE.json configs[4]: per-sample missing modalities and per-sample
+     * encoder order; a build-defined extension - the reference defines it only at batch size 1,
+     * multimodn.py:168,518-523 - whose result is the mean over the samples of the reference's
+     * batch-size-1 result).  Both NULL = ordinary batch.  Otherwise the caller has grouped the rows
+     * into 16-row tiles of ONE executed sequence each: tile t covers rows [16 t, 16 t + tile_rows[t])
+     * (tile_rows[t] in 0..16, the remaining rows of the tile are padding) and runs the encoders
+     * packed in tile_seq[t], 4 bits per step (encoder id + 1, first step in the low bits, 0 ends the
+     * list; a missing modality is simply absent from the list).  Then: batch = 16 * number of tiles,
+     * batch_global = the true number of samples, data slot k holds encoder k's features
+     * (seq_data[t] = seq_enc[t] = t, n_seq = n_encoders), every feature value is finite (missing
+     * entries zeroed), nan_flags = NULL.  Training steps only, fused-kernel shapes only
+     * (MMN_ERR_UNSUPPORTED otherwise). */
+    const int32_t* tile_rows;
+    const int32_t* tile_seq;
 } mmn_batch;
 
 /* Per-step statistics block, fp32, written by mmn_reduce (local sums, ready for an all-reduce)

@@ -108,6 +108,7 @@ struct WgArgs {
     const float* dpre; const float* dS; const float* dz; const float* states; const float* hid; const float* init;
     float* slabs;
     long long* stamps;
+    const float* sin;                   // per-sample mode: In operand of the state-update weights
     int32_t maxB, S;
 };
 
@@ -140,6 +141,7 @@ struct DevPlan {
     int64_t pkh_off[MMN_MAX_ENCODERS];                   // state update, dh part (columns of h), -1 if no hidden layer
     int64_t pkd_off;                                     // backward decoder operand Wdec^T [S x 2D]
     float* states; float* hid; float* dpre; float* dz; float* dS;
+    float* sin;               // per-sample mode: state that fed encoder e, [E][maxB][S]
     float* pack;              // fragment-ordered weights, rewritten by k_prepare every step
     float* lossp; float* scp; int32_t* cnt;   // cnt[tile][R*D][5]: per-tile integer counter partials
     int32_t* exec_flags;      // [R]   1 if state row r was produced this step
@@ -1741,6 +1743,7 @@ struct ParArgs {
     const float* init; const float* pack;
     int64_t pkd;
     float* states; float* hid; float* dpre; float* dz; float* dS;
+    float* sin;                         // per-sample mode: the state that fed encoder e, [E][maxB][S]
     float* lossp; float* scp; int32_t* cnt; int32_t* exec_flags; int32_t* prev_row;
     long long* stamps;
     const float* dec_w[MMN_MAX_DECODERS]; const float* dec_b[MMN_MAX_DECODERS];
@@ -2375,6 +2378,27 @@ __device__ __forceinline__ ExecInfo exec_info(const mmn_batch& b, unsigned pm) {
     return x;
 }
 
+// per-sample mode: the tile's executed sequence comes packed (4 bits per step: encoder id + 1,
+// first step in the low bits, 0 terminates) instead of from the batch-wide sequence + NaN mask
+__device__ __forceinline__ ExecInfo exec_from_code(unsigned code) {
+    ExecInfo x;
+    x.rowmask = 1u; x.n = 0; x.enc = 0ull; x.slot = 0ull; x.prev = 0ull; x.next = 0ull;
+    int prev = 0;
+    for (int j = 0; j < 8; ++j) {
+        const int v = (int)((code >> (4 * j)) & 15u);
+        if (!v) break;
+        const int e = v - 1;
+        x.rowmask |= 2u << e;
+        x.prev |= (unsigned long long)prev << (4 * (e + 1));
+        x.next |= (unsigned long long)(e + 1) << (4 * prev);
+        x.enc |= (unsigned long long)e << (4 * x.n);
+        x.slot |= (unsigned long long)e << (4 * x.n);
+        ++x.n;
+        prev = e + 1;
+    }
+    return x;
+}
+
 __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b, float cL, float cS) {
     constexpr int TB = 16;
     extern __shared__ __attribute__((aligned(16))) float smem_generic[];
@@ -2384,7 +2408,37 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
     const Fb8Lds L = fb8_lds(R, ldS, ldH, ldX);
     const lp sDzA = smem + L.sDzA;
     const int tile = blockIdx.x, row0 = tile * TB;
-    const int nrows = min(TB, b.batch - row0);
+    // per-sample mode (mmn_batch.tile_seq): rows come grouped into tiles of one executed sequence
+    const bool tiled = b.tile_seq != nullptr;
+    const int nrows = tiled ? g_ldi(b.tile_rows + tile) : min(TB, b.batch - row0);
+    const unsigned tcode = tiled ? (unsigned)g_ldi(b.tile_seq + tile) : 0u;
+    if (tiled && nrows == 0) {                             // padding tile (wave-uniform): its partials are zeros
+        const int RDt = a.R * a.D;
+        for (int c = threadIdx.x; c < RDt; c += NT8) {
+            g_st(a.lossp + (int64_t)tile * RDt + c, 0.f);
+            for (int k = 0; k < 5; ++k) g_sti(a.cnt + ((int64_t)tile * RDt + c) * 5 + k, 0);
+        }
+        for (int e = threadIdx.x; e < a.E; e += NT8) g_st(a.scp + (int64_t)tile * a.E + e, 0.f);
+        // ... and its 16 rows of every k_wgrad A operand (dS, dz, dpre) are zeros: an earlier step may
+        // have left real data at these positions
+        const int Sx = a.S, D2 = 2 * a.D;
+        for (int idx = threadIdx.x; idx < (a.E + 1) * TB * Sx; idx += NT8) {
+            const int e = idx / (TB * Sx), rem = idx - e * TB * Sx;
+            g_st(a.dS + ((int64_t)e * a.maxB + row0) * Sx + rem, 0.f);
+        }
+        for (int idx = threadIdx.x; idx < a.R * TB * D2; idx += NT8) {
+            const int r = idx / (TB * D2), rem = idx - r * TB * D2;
+            g_st(a.dz + ((int64_t)r * a.maxB + row0) * D2 + rem, 0.f);
+        }
+        for (int e = 0; e < a.E; ++e)
+            for (int l = 0; l < a.enc[e].Lh; ++l) {
+                const int N = a.enc[e].out[l];
+                for (int idx = threadIdx.x; idx < TB * N; idx += NT8) g_st(a.dpre + a.enc[e].hid[l] + (int64_t)row0 * N + idx, 0.f);
+            }
+        return;
+    }
+    const int nst = tiled ? TB : nrows;                    // rows that go to HBM: per-sample mode also writes the
+                                                           // (zero) padding rows, k_wgrad walks them
     const int lane = threadIdx.x & 63, wave = wave_id();
     const int i = lane & 15, q = lane >> 4;
     const int g = wave >> 1, half = wave & 1;
@@ -2469,11 +2523,15 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
     } else {                                               // dz tiles: unwritten entries must read as zero
         for (int idx = threadIdx.x; idx < R * 16 * LDZ; idx += NT8) lds_st(sDzA + idx, 0.f);
     }
-    const ExecInfo X = exec_info(b, pm);                   // waits for the mask only
-    const bool act = inA && slot_present(pm, slotA);
+    const ExecInfo X = tiled ? exec_from_code(tcode) : exec_info(b, pm);   // waits for the mask only
+    const bool act = inA && (tiled ? X.row(eA + 1) : slot_present(pm, slotA));
     int Lmax = 0;                                          // barrier counts must be uniform over the workgroup
     for (int k = 0; k < X.n; ++k) Lmax = max(Lmax, a.enc[X.e(k)].Lh);
-    if (tile == 0 && threadIdx.x == 0) {                   // which state rows exist this step (k_wgrad / k_reduce)
+    if (tile == 0 && threadIdx.x == 0 && tiled) {          // per-sample: every row may exist somewhere in the batch
+        for (int r = 0; r < R; ++r) g_sti(a.exec_flags + r, 1);
+        for (int e = 0; e < E; ++e) g_sti(a.prev_row + e, 0);
+    }
+    if (tile == 0 && threadIdx.x == 0 && !tiled) {         // which state rows exist this step (k_wgrad / k_reduce)
         for (int r = 0; r < R; ++r) g_sti(a.exec_flags + r, X.row(r) ? 1 : 0);
         for (int k = 0; k < X.n; ++k) g_sti(a.prev_row + X.e(k), X.prev_row(X.e(k) + 1));
     }
@@ -2596,7 +2654,7 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
     // (the 8-wave tier has S <= 128, S % 4 == 0)
     auto store_tile = [&](float* gbase, clp tile_lds) {
         const int r = 2 * wave + (lane >> 5), c = (lane & 31) * 4;
-        if (r < nrows && c < S) g_st4(gbase + (int64_t)(row0 + r) * S + c, lds_ld4(tile_lds + r * ldS + c));
+        if (r < nst && c < S) g_st4(gbase + (int64_t)(row0 + r) * S + c, lds_ld4(tile_lds + r * ldS + c));
     };
     auto store_state = [&](int e) { store_tile(a.states + (int64_t)e * a.maxB * S, St + (e + 1) * TB * ldS); };
     auto chain_step = [&](f32x4 (&wc)[8], int k) {
@@ -2614,6 +2672,7 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
         if (wave < ntS) consume_t<8>(acc, sC, ldS, 0, wc, 0, T0);
         issue_fwd(wc, k + 2);
         if (k > 0) store_state(X.e(k - 1));                 // the previous tile, underneath the MFMAs
+        if (tiled) store_tile(a.sin + (int64_t)e * a.maxB * S, sC);   // per-sample: what fed encoder e (k_wgrad's In)
         if (wave < ntS && col < S) {
             float sc = 0.f;
 #pragma unroll
@@ -2721,6 +2780,9 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
             g_st2(a.dz + ((int64_t)r * a.maxB + grow) * (2 * D) + 2 * d, dzv);
             lds_st(sDzA + (r * TB + row) * LDZ + 2 * d, dzv.x);
             lds_st(sDzA + (r * TB + row) * LDZ + 2 * d + 1, dzv.y);
+        } else if (tiled && valid) {                // per-sample: k_wgrad walks every row, dead entries must be 0
+            f32x2 zz; zz.x = 0.f; zz.y = 0.f;
+            g_st2(a.dz + ((int64_t)r * a.maxB + row0 + row) * (2 * D) + 2 * d, zz);
         }
 #pragma unroll
         for (int off = TB / 2; off >= 1; off >>= 1) lossv += __shfl_xor(lossv, off);
@@ -2848,7 +2910,7 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
         STAMP8();
         if (actC) {
             const int N = pe.out[Lh - 1];
-            const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
+            const int r0 = 8 * half, nr = max(0, min(8, nst - r0));
             wave_store_tile(a.dpre + pe.hid[Lh - 1] + (int64_t)(row0 + r0) * N, sHg[Lh - 1] + r0 * ldH, ldH, nr, N);
         }
         if (Lmax >= 2) {
@@ -2869,8 +2931,24 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
             STAMP8();
             if (actC && Lh >= 2) {
                 const int N = pe.out[0];
-                const int r0 = 8 * half, nr = max(0, min(8, nrows - r0));
+                const int r0 = 8 * half, nr = max(0, min(8, nst - r0));
                 wave_store_tile(a.dpre + pe.hid[0] + (int64_t)(row0 + r0) * N, sHg[0] + r0 * ldH, ldH, nr, N);
+            }
+        }
+    }
+    if (tiled) {
+        // encoders this tile did not execute: their rows of dS / sin / dpre must read as zero in
+        // k_wgrad (pair g owns encoder g, as in phase A)
+        if (inA && !X.row(eA + 1)) {
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const int r = 8 * half + (lane >> 3);                       // 8 rows per half, 8 lanes per row
+            for (int c = (lane & 7) * 4; c < S; c += 32) {
+                g_st4(a.dS + ((int64_t)eA * a.maxB + row0 + r) * S + c, z4);
+                g_st4(a.sin + ((int64_t)eA * a.maxB + row0 + r) * S + c, z4);
+            }
+            for (int l = 0; l < Lh; ++l) {
+                const int N = pe.out[l];
+                for (int c = (lane & 7); c < N; c += 8) g_st(a.dpre + pe.hid[l] + (int64_t)(row0 + r) * N + c, 0.f);
             }
         }
     }
@@ -3051,7 +3129,8 @@ __global__ __launch_bounds__(NT) void k_wgrad(const WgArgs w, const mmn_batch b)
     const WRec it = w.recs[blockIdx.x];
     const int rows_per_split = round_up((b.batch + it.nks - 1) / it.nks, 16);
     int rb = it.ks * rows_per_split, re = min(b.batch, rb + rows_per_split);
-    if (!row_executed(b, pm, it.gate) || rb >= re) { rb = 0; re = 0; }   // writes zeros
+    const bool tiled = b.tile_seq != nullptr;              // per-sample mode: dead rows are zero in A, no gating
+    if ((!tiled && !row_executed(b, pm, it.gate)) || rb >= re) { rb = 0; re = 0; }   // writes zeros
     const float* Ap = (it.a_kind == A_DPRE ? w.dpre : (it.a_kind == A_DS ? w.dS : w.dz)) + it.a_off;
     SrcRef in{nullptr, 0};
     switch (it.in_kind) {
@@ -3065,6 +3144,7 @@ __global__ __launch_bounds__(NT) void k_wgrad(const WgArgs w, const mmn_batch b)
         case IN_STATE_ROW: in.p = w.states + it.in_off; in.ld = it.ldi; break;
         case IN_INIT: in.p = w.init; in.ld = 0; break;
         case IN_PREV_STATE: {
+            if (tiled) { in.p = w.sin + (int64_t)it.in_enc * w.maxB * w.S; in.ld = w.S; break; }
             const int r = prev_row_of(b, pm, it.in_enc);
             if (r == 0) { in.p = w.init; in.ld = 0; }
             else { in.p = w.states + (int64_t)(r - 1) * w.maxB * w.S; in.ld = w.S; }
@@ -3250,7 +3330,8 @@ struct RdArgs {
 // A tensor whose encoder did not run this step has no gradient: it is left untouched.
 __global__ __launch_bounds__(NTR) void k_reduce(const RdArgs r, const AdamArgs ad, int adam_on, int batch, int batch_global,
                                                 int n_tiles, int grad_blocks, int want_grads, int accumulate,
-                                                float alpha, float beta, int32_t* nan_flags) {
+                                                float alpha, float beta, int32_t* nan_flags,
+                                                const int32_t* tile_rows, const int32_t* tile_seq) {
     __shared__ int s_exec[MMN_MAX_ENCODERS + 1];
     if ((int)blockIdx.x < grad_blocks) {
         if (!want_grads) return;
@@ -3380,7 +3461,23 @@ __global__ __launch_bounds__(NTR) void k_reduce(const RdArgs r, const AdamArgs a
         }
         __syncthreads();
     }
-    for (int q = threadIdx.x; q < R; q += NTR) st[RD + E + 5 * RD + q] = s_exec[q] ? (float)batch : 0.f;
+    if (tile_seq == nullptr) {
+        for (int q = threadIdx.x; q < R; q += NTR) st[RD + E + 5 * RD + q] = s_exec[q] ? (float)batch : 0.f;
+    } else {                                               // per-sample: samples that own grid row q
+        const int q = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        if (q < R) {
+            int cntq = 0;
+            for (int t = ln; t < n_tiles; t += 64) {
+                const int nr = g_ldi(tile_rows + t);
+                bool has = q == 0;
+                const unsigned code = (unsigned)g_ldi(tile_seq + t);
+                for (int j = 0; j < 8; ++j) has |= (int)((code >> (4 * j)) & 15u) == q && q > 0;
+                cntq += has ? nr : 0;
+            }
+            const float tot = wave_sum((float)cntq);       // exact: counts are far below 2^24
+            if (ln == 0) st[RD + E + 5 * RD + q] = tot;
+        }
+    }
     if (nan_flags && threadIdx.x < MMN_MAX_ENCODERS) nan_flags[threadIdx.x] = 0;
     if (accumulate) {
         __threadfence_block();
@@ -3450,7 +3547,7 @@ static int validate_model(const mmn_model* m) {
 namespace {
 struct Layout {
     size_t off_plan, off_states, off_hid, off_dpre, off_dz, off_dS, off_pack, off_lossp, off_scp, off_cnt,
-        off_flags, off_slabs, off_epoch, off_stamps, off_tasks, off_items, off_segs, off_ptasks, off_recs, total;
+        off_flags, off_slabs, off_epoch, off_stamps, off_tasks, off_items, off_segs, off_ptasks, off_recs, off_sin, total;
     int64_t hid_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
     int64_t pkf_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
     int64_t pkb_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
@@ -3695,6 +3792,7 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     L.off_segs = take(sizeof(Seg) * L.segs.size());
     L.off_ptasks = take(sizeof(PackTask) * L.ptasks.size());
     L.off_recs = take(sizeof(WRec) * L.items.size());
+    L.off_sin = take(sizeof(float) * (size_t)E * maxB * S);
     L.total = o;
 }
 
@@ -3798,13 +3896,14 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     h.segs = reinterpret_cast<Seg*>(ws + L.off_segs);
     h.ptasks = reinterpret_cast<PackTask*>(ws + L.off_ptasks);
     h.recs = reinterpret_cast<WRec*>(ws + L.off_recs);
+    h.sin = reinterpret_cast<float*>(ws + L.off_sin);
     h.n_tasks = (int)L.tasks.size(); h.n_items = (int)L.items.size(); h.n_segs = (int)L.segs.size();
     h.n_ptasks = (int)L.ptasks.size();
     h.n_grad_elems = L.n_grad_elems;
     h.n_pack_elems = L.pack_elems;
     for (PackTask& t : L.ptasks) t.dst = h.pack + reinterpret_cast<intptr_t>(t.dst);   // offset -> address
     pl->dev = reinterpret_cast<DevPlan*>(ws + L.off_plan);
-    pl->wg = WgArgs{h.recs, h.dpre, h.dS, h.dz, h.states, h.hid, m->init_state, h.slabs, h.stamps, h.maxB, h.S};
+    pl->wg = WgArgs{h.recs, h.dpre, h.dS, h.dz, h.states, h.hid, m->init_state, h.slabs, h.stamps, h.sin, h.maxB, h.S};
     pl->rd = RdArgs{h.segs, h.slabs, h.lossp, h.scp, h.cnt, h.exec_flags, h.stats, h.epoch, L.n_grad_elems,
                     (int32_t)L.segs.size(), h.R, h.D, h.E, h.S, 0};
     pl->segs = L.segs;
@@ -3859,7 +3958,7 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
         a.S = h.S; a.E = h.E; a.D = h.D; a.R = h.R; a.S16 = h.S16; a.ldS = h.ldS; a.ldH = h.ldH; a.ldX = h.ldX;
         a.maxB = h.maxB; a.needs_zero = aligned16 ? 0 : 1;
         a.init = m->init_state; a.pack = h.pack; a.pkd = L.pkd_off;
-        a.states = h.states; a.hid = h.hid; a.dpre = h.dpre; a.dz = h.dz; a.dS = h.dS;
+        a.states = h.states; a.hid = h.hid; a.dpre = h.dpre; a.dz = h.dz; a.dS = h.dS; a.sin = h.sin;
         a.lossp = h.lossp; a.scp = h.scp; a.cnt = h.cnt; a.exec_flags = h.exec_flags; a.prev_row = h.prev_row;
         a.stamps = h.stamps;
         for (int d = 0; d < h.D && d < MMN_MAX_DECODERS; ++d) { a.dec_w[d] = m->dec[d].w; a.dec_b[d] = m->dec[d].b; }
@@ -3893,6 +3992,9 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     if ((e = hipMemset(h.epoch, 0, sizeof(double) * mmn_epoch_doubles(m))) != hipSuccess) return fail(e);
     if ((e = hipMemset(h.exec_flags, 0, sizeof(int32_t) * (h.R + h.E + MMN_MAX_ENCODERS))) != hipSuccess) return fail(e);
     if ((e = hipMemset(h.pack, 0, sizeof(float) * (size_t)L.pack_floats)) != hipSuccess) return fail(e);
+    // activations / gradient operands start finite: per-sample mode multiplies rows nobody wrote by zero rows
+    if ((e = hipMemset(h.states, 0, L.off_pack - L.off_states)) != hipSuccess) return fail(e);
+    if ((e = hipMemset(h.sin, 0, sizeof(float) * (size_t)h.E * h.maxB * h.S)) != hipSuccess) return fail(e);
     const void* fns[4] = {reinterpret_cast<const void*>(k_chain_fwd<1>), reinterpret_cast<const void*>(k_chain_fwd<2>),
                           reinterpret_cast<const void*>(k_chain_bwd<1>), reinterpret_cast<const void*>(k_chain_bwd<2>)};
     for (int k = 0; k < 4; ++k) {
@@ -3928,7 +4030,10 @@ int32_t* mmn_nan_flags(mmn_plan* p) { return p ? p->host.nan_flags : nullptr; }
 
 static int check_batch(const mmn_plan* p, const mmn_batch* b) {
     if (!p || !b) return MMN_ERR_ARG;
-    if (b->batch < 1 || b->batch > p->max_batch || b->batch_global < b->batch || !b->y) return MMN_ERR_ARG;
+    // (per-sample mode pads every sequence group to whole tiles: there batch_global, the true sample
+    //  count, may be smaller than the padded batch)
+    if (b->batch < 1 || b->batch > p->max_batch || b->batch_global < 1 || !b->y) return MMN_ERR_ARG;
+    if (!b->tile_seq && b->batch_global < b->batch) return MMN_ERR_ARG;
     if (b->n_seq < 0 || b->n_seq > p->m.n_encoders) return MMN_ERR_SEQUENCE;
     unsigned seen_e = 0, seen_k = 0;
     for (int t = 0; t < b->n_seq; ++t) {
@@ -3938,6 +4043,13 @@ static int check_batch(const mmn_plan* p, const mmn_batch* b) {
         if ((seen_k >> k) & 1u) return MMN_ERR_SEQUENCE;
         seen_e |= 1u << e; seen_k |= 1u << k;
         if (!b->x[k] || b->ldx[k] < p->m.enc[e].n_features) return MMN_ERR_ARG;
+    }
+    if (b->tile_seq || b->tile_rows) {                     // per-sample mode
+        if (!b->tile_seq || !b->tile_rows || b->nan_flags) return MMN_ERR_ARG;
+        if ((b->batch & 15) != 0 || b->n_seq != p->m.n_encoders) return MMN_ERR_ARG;
+        for (int t = 0; t < b->n_seq; ++t)
+            if (b->seq_data[t] != t || b->seq_enc[t] != t) return MMN_ERR_SEQUENCE;   // slot k = encoder k
+        if (!p->fb8_ok) return MMN_ERR_UNSUPPORTED;        // only the fused kernel implements it
     }
     return MMN_OK;
 }
@@ -3998,6 +4110,7 @@ int mmn_chain_fwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float sc_p
     (void)sc_pen_x001;
     int rc = check_batch(p, b);
     if (rc != MMN_OK) return rc;
+    if (b->tile_seq) return MMN_ERR_UNSUPPORTED;           // per-sample mode exists in the fused kernel only
     const int rt = rt_for(p, b);
     const int tiles = (b->batch + 16 * rt - 1) / (16 * rt);
     const float cL = err_penalty / ((float)p->m.n_decoders * (float)(p->m.n_encoders + 1) * (float)b->batch_global);
@@ -4018,6 +4131,7 @@ static float sc_coeff(const mmn_plan* p, const mmn_batch* b, float beta) {
 int mmn_chain_bwd(mmn_plan* p, const mmn_batch* b, float sc_pen_x001, void* stream) {
     int rc = check_batch(p, b);
     if (rc != MMN_OK) return rc;
+    if (b->tile_seq) return MMN_ERR_UNSUPPORTED;
     const int rt = rt_for(p, b);
     const int tiles = (b->batch + 16 * rt - 1) / (16 * rt);
     mmn_batch bb = *b;
@@ -4101,7 +4215,7 @@ static int launch_reduce(mmn_plan* p, const mmn_batch* b, int want_grads, int ac
     const int tiles = (b->batch + 16 * rt - 1) / (16 * rt);
     hipLaunchKernelGGL(k_reduce, dim3(p->grad_blocks + 1), dim3(NTR), 0, static_cast<hipStream_t>(stream), p->rd,
                        adam_args(adam), adam ? 1 : 0, b->batch, b->batch_global, tiles, p->grad_blocks, want_grads, accumulate,
-                       alpha, beta, const_cast<int32_t*>(b->nan_flags));
+                       alpha, beta, const_cast<int32_t*>(b->nan_flags), b->tile_rows, b->tile_seq);
     HIP_TRY(hipGetLastError());
     return MMN_OK;
 }

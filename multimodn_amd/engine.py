@@ -235,6 +235,60 @@ class HipChainEngine:
                                           1 if accumulate else 0, self._stream()), "mmn_train_step")
         return False
 
+    # ------------------------------------------------------------------ per-sample mode (BASELINE configs[4])
+    def per_sample_batch(self, xs: Sequence[torch.Tensor], y: torch.Tensor, seq: Optional[torch.Tensor]):
+        """Group the rows of one mini-batch into 16-row tiles of identical EXECUTED sequence (the
+        ordered list of encoders whose modality is present for that sample) - what the fused kernel's
+        per-sample mode consumes (include/mmn_hip.h, mmn_batch.tile_rows / tile_seq).
+
+        xs[k]: [B, F] device features of data slot k (NaN anywhere in a row = that sample's modality is
+        missing); seq: None (slot k feeds encoder k) or [B, E] int64, sample b feeds slot k to encoder
+        seq[b, k].  Everything is torch ops on the device with fixed shapes: no host sync.  Returns
+        (hip.Batch, keep-alive tuple); the batch has 16 * n_tiles rows, batch_global = B."""
+        E, B, dev = self.E, int(y.shape[0]), self.device
+        if E > 7 or len(xs) != E:
+            raise UnsupportedModelError("per-sample mode needs one data slot per encoder and E <= 7")
+        feats = [int(enc.n_features) for enc in self.model.encoders]
+        if seq is not None and len(set(feats)) != 1:
+            raise UnsupportedModelError("per-sample encoder order needs modalities of equal width "
+                                        "(slot k must be able to feed any encoder)")
+        present = torch.stack([~torch.isnan(x).any(dim=1) for x in xs], dim=1)           # [B, E] slot present
+        enc_of = seq.to(dev, torch.int64) if seq is not None else torch.arange(E, device=dev).expand(B, E)
+        pi = present.to(torch.int64)
+        pos = torch.cumsum(pi, dim=1) - 1
+        code = (pi * ((enc_of + 1) << (4 * pos.clamp(min=0)))).sum(dim=1)                 # packed executed sequence
+        n_codes = 16 ** E
+        counts = torch.bincount(code, minlength=n_codes)
+        padded = (counts + 15) // 16 * 16
+        base = torch.cumsum(padded, 0) - padded
+        first = torch.cumsum(counts, 0) - counts
+        order = torch.argsort(code, stable=True)
+        scode = code[order]
+        where = base[scode] + (torch.arange(B, device=dev) - first[scode])                # padded position of each row
+        n_patterns = sum(int(np.prod(range(E - k + 1, E + 1))) for k in range(E + 1))     # ordered subsets of E encoders
+        bp = (B + 15) // 16 * 16 + 16 * min(n_patterns, B)
+        self.ensure(bp)
+        xs_p = []
+        for e in range(E):
+            src = torch.zeros((B, feats[e]), dtype=torch.float32, device=dev)
+            for k in range(E):                                                            # the slot that feeds encoder e
+                m = (present[:, k] & (enc_of[:, k] == e)).unsqueeze(1)
+                if xs[k].shape[1] == feats[e]:
+                    src = torch.where(m, torch.nan_to_num(xs[k]), src)
+            xp = torch.zeros((bp, feats[e]), dtype=torch.float32, device=dev)
+            xp.index_copy_(0, where, src[order])
+            xs_p.append(xp)
+        y_p = torch.zeros((bp, y.shape[1]), dtype=torch.int64, device=dev)
+        y_p.index_copy_(0, where, y[order])
+        tiles = bp // 16
+        tile_rows = torch.zeros(tiles, dtype=torch.int32, device=dev)
+        tile_rows.index_add_(0, where // 16, torch.ones(B, dtype=torch.int32, device=dev))
+        tile_seq = torch.zeros(tiles, dtype=torch.int32, device=dev)
+        tile_seq.index_copy_(0, where // 16, scode.to(torch.int32))
+        b = self.make_batch(xs_p, y_p, [(k, k) for k in range(E)], batch_global=B)
+        b.tile_rows, b.tile_seq = tile_rows.data_ptr(), tile_seq.data_ptr()
+        return b, (xs_p, y_p, tile_rows, tile_seq)
+
     def eval_step(self, b: hip.Batch, accumulate: bool = False) -> None:
         hip.check(self.lib.mmn_eval_step(self._plan, C.byref(b), 1 if accumulate else 0, self._stream()), "mmn_eval_step")
 

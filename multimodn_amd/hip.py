@@ -17,7 +17,7 @@ MAX_LAYERS = 8
 MAX_DIM = 256
 ADAM_MAX_SEG = 512
 ERR_UNSUPPORTED = -2
-VERSION = 100
+VERSION = 101
 
 ACT_IDENTITY, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -59,7 +59,8 @@ class Batch(C.Structure):
                 ("y", C.c_void_p), ("nan_flags", C.c_void_p),
                 ("batch", C.c_int32), ("batch_global", C.c_int32), ("n_seq", C.c_int32),
                 ("reserved", C.c_int32),
-                ("seq_data", C.c_int32 * MAX_ENCODERS), ("seq_enc", C.c_int32 * MAX_ENCODERS)]
+                ("seq_data", C.c_int32 * MAX_ENCODERS), ("seq_enc", C.c_int32 * MAX_ENCODERS),
+                ("tile_rows", C.c_void_p), ("tile_seq", C.c_void_p)]
 
 
 class AdamDesc(C.Structure):

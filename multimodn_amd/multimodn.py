@@ -117,6 +117,10 @@ class MultiModN(nn.Module):
         #: "host": decide NaN-skips on the host like the reference (exact grad=None semantics);
         #: "device": keep the decision on the GPU (no sync; skipped encoders get zero grads)
         self.nan_policy = "host"
+        #: build-defined extension (BASELINE.json configs[4]): every SAMPLE may miss modalities (NaN
+        #: rows) and carry its own encoder order; the batch result is the mean over the samples of the
+        #: reference's batch-size-1 result (the only case the reference defines, multimodn.py:168,518-523)
+        self.per_sample = False
 
     # nn.Module pickling: the engine holds raw device handles and is rebuilt on demand
     def __getstate__(self):
@@ -227,6 +231,37 @@ class MultiModN(nn.Module):
             eng.accumulate(float(self.err_penalty) if train else 1.0, float(self.state_change_penalty) if train else 0.0)
         return executed, (xs, y)
 
+    def _run_step_per_sample(self, eng, data, target, encoder_sequence, optimizer=None):
+        """One training step in per-sample mode: rows are regrouped on the device into tiles of one
+        executed sequence each (engine.per_sample_batch) and run by the fused kernel."""
+        if not isinstance(target, Tensor):
+            target = torch.as_tensor(np.asarray(target))
+        if target.dim() == 1:
+            target = target.view(-1, 1)
+        on_host = all(t.device.type == "cpu" for t in data) and target.device.type == "cpu"
+        if on_host and self.device.type == "cuda" and data:
+            if self._stager is None:
+                self._stager = _HostStager(self.device)
+            xs, y = self._stager.stage(data, target.to(torch.int64))
+        else:
+            xs = [t.to(self.device, dtype=torch.float32, non_blocking=True).contiguous() for t in data]
+            y = target.to(torch.int64).to(self.device, non_blocking=True).contiguous()
+        seq = None
+        if encoder_sequence is not None:
+            seq = encoder_sequence if isinstance(encoder_sequence, Tensor) else torch.as_tensor(np.asarray(encoder_sequence))
+            seq = seq.to(self.device, torch.int64)
+        B = int(y.shape[0])
+        dp = self._dp_group is not None
+        b, keep = eng.per_sample_batch(xs, y, seq)
+        b.batch_global = B * self._dp_world
+        fuse = optimizer if (not dp and hasattr(optimizer, "fused_descriptor")) else None
+        eng.local_step(b, float(self.err_penalty), float(self.state_change_penalty), accumulate=not dp, optimizer=fuse)
+        if dp:
+            import torch.distributed as dist
+            dist.all_reduce(eng.reduce_buf, group=self._dp_group)
+            eng.accumulate(float(self.err_penalty), float(self.state_change_penalty))
+        return None, (xs, y, keep)
+
     def train_epoch(
             self,
             train_loader: DataLoader,
@@ -253,7 +288,10 @@ class MultiModN(nn.Module):
             else:
                 eng.ensure(int(target.shape[0]))
             optimizer.zero_grad()
-            executed, keep = self._run_step(eng, data, target, encoder_sequence, train=True, optimizer=optimizer)
+            if self.per_sample:
+                executed, keep = self._run_step_per_sample(eng, data, target, encoder_sequence, optimizer)
+            else:
+                executed, keep = self._run_step(eng, data, target, encoder_sequence, train=True, optimizer=optimizer)
             eng.assign_grads(executed)          # what loss.backward() leaves behind (multimodn.py:203)
             optimizer.step()
             if log_interval and batch_idx % log_interval == log_interval - 1:

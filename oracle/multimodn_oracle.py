@@ -158,6 +158,7 @@ class StepResult:
     executed: np.ndarray            # [E] bool: encoder ran (no NaN skip) (multimodn.py:168-171)
     grads: Dict[str, Optional[np.ndarray]] = field(default_factory=dict)
     states: Dict[int, np.ndarray] = field(default_factory=dict)   # row -> [B,S] (row 0 = init)
+    row_counts: Optional[np.ndarray] = None   # per-sample mode only: samples that own each grid row, [(E+1)]
 
 
 def forward_backward(params: Dict[str, np.ndarray], spec: ModelSpec,
@@ -366,9 +367,14 @@ def aggregate_epoch(E: int, D: int, step_results: Sequence[StepResult],
     err = np.zeros((E + 1, D)); sc = np.zeros(E); ncor = np.zeros((E + 1, D))
     tp = np.zeros((E + 1, D), np.float32); tn = tp.copy(); fp = tp.copy(); fn = tp.copy()
     for r, bs in zip(step_results, batch_sizes):
-        n_samples[0] += bs
+        if r.row_counts is not None:                             # per-sample mode: rows += samples present
+            n_samples[:, 0] += r.row_counts
+            continue_counts = True
+        else:
+            continue_counts = False
+            n_samples[0] += bs
         for e in range(E):
-            if r.executed[e]:
+            if r.executed[e] and not continue_counts:
                 n_samples[e + 1] += bs
         err += r.err_loss.astype(np.float32)                     # f32 step values summed in f64
         sc += r.state_change.astype(np.float32)
@@ -534,10 +540,13 @@ def per_sample_step(params, spec: ModelSpec, xs, y, sequences, dtype=np.float32)
     E, D = spec.E, spec.D
     acc: Optional[StepResult] = None
     gsum: Dict[str, np.ndarray] = {}
+    counts = np.zeros(E + 1, np.int64)
+    counts[0] = B
     for b in range(B):
         xb = [np.asarray(x)[b:b + 1] for x in xs]
         sb = None if sequences is None else np.asarray(sequences)[b:b + 1]
         r = forward_backward(params, spec, xb, np.asarray(y)[b:b + 1], sb, batch_global=B, dtype=dtype)
+        counts[1:] += r.executed.astype(np.int64)
         for n, g in r.grads.items():
             if g is not None:
                 gsum[n] = g if n not in gsum else gsum[n] + g
@@ -550,6 +559,7 @@ def per_sample_step(params, spec: ModelSpec, xs, y, sequences, dtype=np.float32)
             acc.executed |= r.executed
             acc.loss += r.loss
     acc.grads = {n: gsum.get(n) for n in spec.param_names()}
+    acc.row_counts = counts
     return acc
 
 

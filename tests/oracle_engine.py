@@ -55,8 +55,22 @@ class OracleEngine:
         b.device_nan = device_nan_flags
         return b
 
+    def per_sample_batch(self, xs, y, seq):
+        b = _Batch()
+        b.xs = [x.numpy() for x in xs]
+        b.y = y.numpy()
+        b.seq = None if seq is None else seq.numpy()
+        b.batch_global = len(b.y)
+        b.per_sample = True
+        return b, None
+
     def _run(self, b, want_grads):
         params = {n: p.detach().numpy() for n, p in zip(self.names, self.params)}
+        if getattr(b, "per_sample", False):
+            r = O.per_sample_step(params, self.spec, b.xs, b.y, b.seq)
+            if b.batch_global != len(b.y):                      # data-parallel shard: divisors are global
+                raise NotImplementedError
+            return self._publish(r, want_grads, rows=r.row_counts.astype(np.float32))
         n_slots = max(k for k, _ in b.pairs) + 1 if b.pairs else 0
         seq = None
         xs = b.xs
@@ -71,6 +85,12 @@ class OracleEngine:
         r = O.forward_backward(params, spec, xs, b.y, seq, batch_global=b.batch_global,
                                present_override=override, want_grads=want_grads, keep_states=True)
         self._last = (params, r)
+        rows = np.zeros(self.E + 1, np.float32)
+        rows[0] = len(b.y)
+        rows[1:][r.executed] = len(b.y)
+        return self._publish(r, want_grads, rows)
+
+    def _publish(self, r, want_grads, rows):
         R, D, E = self.E + 1, self.D, self.E
         st = np.zeros(self.n_stats, np.float32)
         RD = R * D
@@ -78,9 +98,6 @@ class OracleEngine:
         st[RD:RD + E] = r.state_change
         for i, k in enumerate(("n_correct", "tp", "tn", "fp", "fn")):
             st[RD + E + i * RD:RD + E + (i + 1) * RD] = getattr(r, k).reshape(-1)
-        rows = np.zeros(R, np.float32)
-        rows[0] = len(b.y)
-        rows[1:][r.executed] = len(b.y)
         st[RD + E + 5 * RD:RD + E + 5 * RD + R] = rows
         self.stats.copy_(torch.from_numpy(st))
         if want_grads:

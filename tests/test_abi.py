@@ -43,7 +43,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(hip.Linear) == 40
     assert C.sizeof(hip.Encoder) == 16 + 40 * hip.MAX_LAYERS
     assert C.sizeof(hip.Model) == 32 + C.sizeof(hip.Encoder) * hip.MAX_ENCODERS + 32 * hip.MAX_DECODERS
-    assert C.sizeof(hip.Batch) == 8 * 16 + 4 * 16 + 16 + 16 + 64 + 64
+    assert C.sizeof(hip.Batch) == 8 * 16 + 4 * 16 + 16 + 16 + 64 + 64 + 16      # + tile_rows, tile_seq (ABI 101)
 
 
 def _model(S=128, F=64, H=(32, 32), E=4, D=3):

@@ -1,0 +1,140 @@
+"""Per-sample mode (BASELINE.json configs[4]): per-sample missing modalities (NaN rows)
+and per-sample encoder order.  The reference only defines this at batch size 1 (multimodn.py:168,
+518-523); the build-defined batch result is the mean over the samples of the reference's
+batch-size-1 result, restated in oracle.per_sample_step (which literally loops the pinned
+batch-size-1 oracle over the samples).  GPU tests compare the fused kernel's per-sample mode with it:
+1e-5 relative on loss cells / state change, exact integer counters and row counts, 2e-5 of max|g| on
+gradients."""
+import numpy as np
+import pytest
+import torch
+
+import multimodn_amd as mm
+from helpers import build_torch_model, rel_err
+from oracle import multimodn_oracle as O
+from oracle_engine import OracleEngine
+
+
+def c5_like(B, E=4, F=8, S=32, D=2, H=(8, 8), seed=0, p_missing=0.3, permute=True):
+    spec = O.ModelSpec(S, [O.EncoderSpec(F, H, O.ACT_RELU) for _ in range(E)], D, 1.0, 0.3)
+    rng = np.random.default_rng(seed)
+    xs, y = O.synthetic_batches(spec, B, B, seed=seed + 1)[0]
+    # missing-not-at-random: modality e is missing more often when y_0 = 1
+    pm = np.where(y[:, :1] == 1, 1.5 * p_missing, 0.5 * p_missing)
+    miss = rng.random((B, E)) < pm
+    xs = [x.copy() for x in xs]
+    for e in range(E):
+        xs[e][miss[:, e]] = np.nan
+    seq = np.stack([rng.permutation(E) for _ in range(B)]).astype(np.int64) if permute else None
+    return spec, xs, y, seq
+
+
+def check(stats, grads, ref, tol=1e-5, tolg=2e-5):
+    assert rel_err(stats["err_loss"], ref.err_loss) < tol
+    assert rel_err(stats["state_change"], ref.state_change) < tol
+    assert rel_err(stats["loss"], ref.loss) < tol
+    for k in ("n_correct", "tp", "tn", "fp", "fn"):
+        assert np.array_equal(stats[k].astype(np.int64), getattr(ref, k)), k
+    assert np.array_equal(stats["rows"].astype(np.int64), ref.row_counts)
+    for n, g in ref.grads.items():
+        got = grads[n]
+        if g is None:
+            assert np.abs(got).max() == 0.0, n
+        else:
+            assert rel_err(got.reshape(g.shape), g) < tolg, (n, rel_err(got.reshape(g.shape), g))
+
+
+def run_step(model, xs, y, seq):
+    model.per_sample = True
+    data = [torch.from_numpy(x) for x in xs]
+    eng = model._get_engine(len(y))
+    eng.epoch_reset()
+    _, keep = model._run_step_per_sample(eng, data, torch.from_numpy(y), None if seq is None else torch.from_numpy(seq))
+    eng.assign_grads(None)
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    stats = {k: np.array(v) for k, v in eng.step_values().items()}
+    grads = {n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
+    return stats, grads
+
+
+def test_per_sample_host_logic_on_checker_backend():
+    spec, xs, y, seq = c5_like(24, E=3, seed=3)
+    params = O.init_params(spec, 1)
+    model = build_torch_model(spec, params, "cpu", mm)
+    model._engine_factory = OracleEngine
+    stats, grads = run_step(model, xs, y, seq)
+    check(stats, grads, O.per_sample_step(params, spec, xs, y, seq), tol=1e-6, tolg=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,E,permute", [(1, 2, True), (37, 3, True), (200, 4, True), (130, 4, False), (16, 1, True)])
+def test_per_sample_step_matches_oracle(B, E, permute):
+    mm.hip.load()
+    spec, xs, y, seq = c5_like(B, E=E, seed=B)
+    if not permute:
+        seq = None
+    params = O.init_params(spec, 2)
+    model = build_torch_model(spec, params, "cuda", mm)
+    stats, grads = run_step(model, xs, y, seq)
+    check(stats, grads, O.per_sample_step(params, spec, xs, y, seq))
+
+
+@pytest.mark.gpu
+def test_per_sample_equals_batch_mode_when_nothing_varies():
+    """No missing modality, one common order: per-sample mode must reproduce the ordinary batch step."""
+    mm.hip.load()
+    spec, xs, y, _ = c5_like(100, E=4, seed=5, p_missing=0.0, permute=False)
+    params = O.init_params(spec, 4)
+    model = build_torch_model(spec, params, "cuda", mm)
+    stats, grads = run_step(model, xs, y, None)
+    ref = O.forward_backward(params, spec, xs, y)
+    assert rel_err(stats["err_loss"], ref.err_loss) < 1e-5 and rel_err(stats["loss"], ref.loss) < 1e-5
+    for n, g in ref.grads.items():
+        assert rel_err(grads[n].reshape(g.shape), g) < 2e-5, n
+
+
+@pytest.mark.gpu
+def test_per_sample_training_epochs_match_oracle():
+    """train_epoch in per-sample mode (fused Adam included) against the oracle loop: History and weights."""
+    mm.hip.load()
+    spec, xs, y, seq = c5_like(96, E=4, seed=11)
+    params = O.init_params(spec, 6)
+    model = build_torch_model(spec, params, "cuda", mm)
+    model.per_sample = True
+    opt = mm.optim.Adam(list(model.parameters()), 1e-2)
+    hist = mm.MultiModNHistory(["a", "b"])
+    loader = [([torch.from_numpy(x[s:s + 32]) for x in xs], torch.from_numpy(y[s:s + 32]), torch.from_numpy(seq[s:s + 32]))
+              for s in range(0, 96, 32)]
+    oparams = {n: v.copy() for n, v in params.items()}
+    oopt = O.Adam(1e-2)
+    for ep in range(2):
+        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+        results, sizes = [], []
+        for s in range(0, 96, 32):
+            r = O.per_sample_step(oparams, spec, [x[s:s + 32] for x in xs], y[s:s + 32], seq[s:s + 32])
+            oopt.step(oparams, {n: (g if g is not None else np.zeros_like(oparams[n])) for n, g in r.grads.items()})
+            results.append(r); sizes.append(32)
+        er = O.aggregate_epoch(spec.E, spec.D, results, sizes)
+        assert rel_err(hist.loss["train"][ep], er.loss) < 1e-5
+        assert rel_err(hist.state_change_loss[ep], er.state_change) < 1e-5
+        assert np.abs(hist.accuracy["train"][ep] - er.accuracy).max() <= 1.0 / 96 + 1e-12
+    for n, p in model.named_parameters():
+        assert rel_err(p.detach().cpu().numpy(), oparams[n]) < 1e-4, n
+
+
+@pytest.mark.gpu
+def test_c5_full_size_against_oracle():
+    """BASELINE configs[4] shape: 4 x 64 features, hidden (32,32), state 128, 3 tasks, batch 4096,
+    30 % missing-not-at-random, a random encoder order per sample."""
+    mm.hip.load()
+    spec, xs, y, seq = c5_like(4096, E=4, F=64, S=128, D=3, H=(32, 32), seed=1)
+    params = O.init_params(spec, 0)
+    model = build_torch_model(spec, params, "cuda", mm)
+    stats, grads = run_step(model, xs, y, seq)
+    ref = O.per_sample_step(params, spec, xs, y, seq)
+    ref64 = O.per_sample_step(params, spec, xs, y, seq, dtype=np.float64)
+    assert rel_err(stats["err_loss"], ref64.err_loss) < 1e-5 and rel_err(stats["state_change"], ref64.state_change) < 1e-5
+    assert np.array_equal(stats["rows"].astype(np.int64), ref.row_counts)
+    for n, g in ref64.grads.items():
+        assert rel_err(grads[n].reshape(g.shape), g) < 2e-5, (n, rel_err(grads[n].reshape(g.shape), g))

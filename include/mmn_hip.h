@@ -207,6 +207,20 @@ int mmn_epoch_accumulate(mmn_plan* p, float err_penalty, float state_change_pena
 int mmn_train_step(mmn_plan* p, const mmn_batch* b, float err_penalty, float state_change_penalty_x001,
                    int accumulate_epoch, void* stream);
 
+/* Per-sample mode helper: regroup the rows of an ordinary batch, ON THE DEVICE, into the tile layout
+ * mmn_batch.tile_rows / tile_seq describe (three launches, deterministic).
+ *   in  : x[k] = data slot k [batch x F] (NaN anywhere in a row = that sample's modality is missing),
+ *         y, batch = number of samples (<= 16384), batch_global; sequence fields are ignored
+ *   seq : device int64 [batch x n_encoders], sample b feeds data slot k to encoder seq[b][k]
+ *         (all modalities then need the same width), or NULL: slot k feeds encoder k
+ *   out : caller-allocated device buffers for rows = mmn_regroup_rows(batch, n_encoders) rows:
+ *         out->x[e] [rows x F_e] (row stride out->ldx[e]), out->y [rows x D], out->tile_rows and
+ *         out->tile_seq [rows / 16]; the call fills them (zeros where a modality is missing and in
+ *         padding rows) and completes every other field of *out, so that *out can go straight into
+ *         mmn_train_step.  The plan's max_batch must be >= rows.  E <= 4. */
+int mmn_regroup_rows(int batch, int n_encoders);
+int mmn_regroup(mmn_plan* p, const mmn_batch* in, const int64_t* seq, mmn_batch* out, void* stream);
+
 /* Forward-only step for test()/predict()/get_states() (multimodn.py:255-492): fwd + reduce
  * (+ accumulate).  Leaves the state rows and the decoder outputs of every grid row in the workspace
  * (mmn_debug_buffer kinds 0 and 1). */

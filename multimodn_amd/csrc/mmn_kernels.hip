@@ -3171,6 +3171,166 @@ __global__ __launch_bounds__(NT) void k_wgrad(const WgArgs w, const mmn_batch b)
 }
 
 // =====================================================================================
+// Per-sample mode: regrouping of the rows of a batch into tiles of one executed sequence
+// (mmn_regroup).  Three launches, deterministic (no atomics decide an order):
+//   k_ps_code   one wave per sample: which modalities are present (no NaN in the row), packed
+//               executed sequence
+//   k_ps_layout ONE workgroup: stable counting sort of the rows by sequence code (<= 65 distinct
+//               codes), groups padded to whole tiles -> source row of every position, per-tile
+//               row count and sequence
+//   k_ps_gather one wave per position: the sample's features (zeros where missing / padding),
+//               per ENCODER, and its targets
+// =====================================================================================
+constexpr int PS_MAX_ROWS = 16384;
+
+__global__ __launch_bounds__(NT) void k_ps_code(const mmn_batch b, const int64_t* __restrict__ seq, int E,
+                                                int32_t* __restrict__ codes, int32_t* __restrict__ pmask) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (NT / 64) + wave_id();
+    if (row >= b.batch) return;
+    unsigned present = 0;
+    for (int k = 0; k < E; ++k) {
+        const float* x = b.x[k] + (int64_t)row * b.ldx[k];
+        bool bad = false;
+        for (int c = lane; c < b.seq_data[k]; c += 64) { const float v = g_ld(x + c); bad |= (v != v); }   // seq_data[k] carries slot k's width here
+        if (!__any(bad)) present |= 1u << k;
+    }
+    if (lane == 0) {
+        unsigned code = 0; int n = 0;
+        for (int k = 0; k < E; ++k) {
+            if (!((present >> k) & 1u)) continue;
+            const int e = seq ? (int)seq[(int64_t)row * E + k] : k;
+            code |= (unsigned)((e & 15) + 1) << (4 * n);
+            ++n;
+        }
+        codes[row] = (int32_t)code;
+        pmask[row] = (int32_t)present;
+    }
+}
+
+constexpr int PS_MAXG = 96;                   // distinct executed sequences of E <= 4 encoders: 65
+
+// Stable counting sort by sequence code, one workgroup.  The codes of a batch take at most 65 distinct
+// values (ordered subsets of <= 4 encoders): (1) collect the distinct codes in an LDS hash set and
+// rank them (group id = rank of the code, so the layout does not depend on the hash order);
+// (2) per 64-row chunk, ballots give every row its rank inside (chunk, group) and the chunk's count
+// per group; (3) prefix over chunks and padded group bases; (4) scatter.
+__global__ __launch_bounds__(1024) void k_ps_layout(const int32_t* __restrict__ codes, int B, int rows_out,
+                                                    int32_t* __restrict__ src_of, int32_t* __restrict__ tile_rows,
+                                                    int32_t* __restrict__ tile_seq) {
+    extern __shared__ __attribute__((aligned(16))) unsigned ps_smem[];
+    const int n_chunks = (B + 63) >> 6;
+    int* cnt = reinterpret_cast<int*>(ps_smem);                 // [n_chunks][PS_MAXG] -> exclusive prefix over chunks
+    __shared__ int hkey[256];                                   // hash set of codes (-1 = empty)
+    __shared__ int gcode[PS_MAXG], gtot[PS_MAXG], gbase[PS_MAXG];
+    __shared__ int n_groups;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < rows_out; i += 1024) src_of[i] = -1;
+    for (int i = tid; i < rows_out / 16; i += 1024) { tile_rows[i] = 0; tile_seq[i] = 0; }
+    for (int i = tid; i < 256; i += 1024) hkey[i] = -1;
+    for (int i = tid; i < n_chunks * PS_MAXG; i += 1024) cnt[i] = 0;
+    if (tid == 0) n_groups = 0;
+    __syncthreads();
+    // (1) distinct codes
+    for (int i = tid; i < B; i += 1024) {
+        const int c = codes[i];
+        unsigned h = ((unsigned)c * 2654435761u) >> 24;
+        for (int probe = 0; probe < 256; ++probe) {
+            const int old = atomicCAS(&hkey[h], -1, c);
+            if (old == -1 || old == c) break;
+            h = (h + 1) & 255u;
+        }
+    }
+    __syncthreads();
+    if (tid < 256 && hkey[tid] != -1) {                        // compact, then rank
+        const int slot = atomicAdd(&n_groups, 1);
+        if (slot < PS_MAXG) gcode[slot] = hkey[tid];
+    }
+    __syncthreads();
+    const int G = min(n_groups, PS_MAXG);
+    __shared__ int sorted_code[PS_MAXG];
+    if (tid < G) {
+        const int mine = gcode[tid];
+        int rank = 0;
+        for (int j = 0; j < G; ++j) rank += gcode[j] < mine;
+        sorted_code[rank] = mine;
+    }
+    __syncthreads();
+    // (2) per chunk: group id of every row, rank inside (chunk, group), chunk counts
+    int my_gid[16], my_rank[16];
+    int nmine = 0;
+    for (int ch = wave; ch < n_chunks; ch += 16) {
+        const int row = ch * 64 + lane;
+        int gid = -1;
+        if (row < B) {
+            const int c = codes[row];
+            int lo = 0, hi = G - 1;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_code[mid] < c) lo = mid + 1; else hi = mid; }
+            gid = lo;
+        }
+        int rk = 0;
+        for (int g = 0; g < G; ++g) {
+            const unsigned long long m = __ballot(gid == g);
+            if (gid == g) rk = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) cnt[ch * PS_MAXG + g] = __popcll(m);
+        }
+        my_gid[nmine] = gid; my_rank[nmine] = rk; ++nmine;
+    }
+    __syncthreads();
+    // (3) exclusive prefix over the chunks per group, group totals, padded bases
+    if (tid < G) {
+        int run = 0;
+        for (int ch = 0; ch < n_chunks; ++ch) { const int v = cnt[ch * PS_MAXG + tid]; cnt[ch * PS_MAXG + tid] = run; run += v; }
+        gtot[tid] = run;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int g = 0; g < G; ++g) { gbase[g] = run; run += (gtot[g] + 15) / 16 * 16; }
+    }
+    __syncthreads();
+    // (4) scatter
+    nmine = 0;
+    for (int ch = wave; ch < n_chunks; ch += 16) {
+        const int row = ch * 64 + lane;
+        const int gid = my_gid[nmine], rk = my_rank[nmine]; ++nmine;
+        if (row < B && gid >= 0) {
+            const int pos = gbase[gid] + cnt[ch * PS_MAXG + gid] + rk;
+            if (pos < rows_out) src_of[pos] = row;
+        }
+    }
+    for (int g = wave; g < G; g += 16) {                        // tile tables straight from the group totals
+        const int ntile = (gtot[g] + 15) >> 4;
+        for (int t = lane; t < ntile; t += 64) {
+            const int tile = (gbase[g] >> 4) + t;
+            if (tile < rows_out / 16) { tile_rows[tile] = min(16, gtot[g] - 16 * t); tile_seq[tile] = sorted_code[g]; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_ps_gather(const mmn_batch b, const int64_t* __restrict__ seq, int E, int D,
+                                                  const int32_t* __restrict__ src_of, const int32_t* __restrict__ pmask,
+                                                  mmn_batch out, int rows_out) {
+    const int lane = threadIdx.x & 63;
+    const int pos = blockIdx.x * (NT / 64) + wave_id();
+    if (pos >= rows_out) return;
+    const int src = g_ldi(src_of + pos);
+    const unsigned pm = src >= 0 ? (unsigned)g_ldi(pmask + src) : 0u;
+    for (int e = 0; e < E; ++e) {
+        int slot = -1;                                                   // the present slot that feeds encoder e
+        if (src >= 0)
+            for (int k = 0; k < E; ++k)
+                if (((pm >> k) & 1u) && (seq ? (int)seq[(int64_t)src * E + k] : k) == e) slot = k;
+        float* dst = const_cast<float*>(out.x[e]) + (int64_t)pos * out.ldx[e];
+        const int F = out.seq_data[e];                                   // width of encoder e's features
+        const float* sx = slot >= 0 ? b.x[slot] + (int64_t)src * b.ldx[slot] : nullptr;
+        for (int c = lane; c < F; c += 64) g_st(dst + c, slot >= 0 ? g_ld(sx + c) : 0.f);
+    }
+    int64_t* yo = const_cast<int64_t*>(out.y) + (int64_t)pos * D;
+    for (int d = lane; d < D; d += 64) yo[d] = src >= 0 ? b.y[(int64_t)src * D + d] : 0;
+}
+
+// =====================================================================================
 // k_adam: optimizer.step() of the training loop (multimodn.py:204) for torch.optim.Adam as the
 // reference pipelines build it, over the FLAT parameter / gradient / moment buffers: one launch
 // for the whole model instead of a multi-tensor apply (one block per 64K-element chunk) plus a
@@ -3506,6 +3666,7 @@ struct mmn_plan {
     ParArgs pa;              // kernel-argument descriptor of the 8-wave fast tier
     WgArgs wg;               // kernel-argument descriptor of k_wgrad
     RdArgs rd;               // kernel-argument descriptor of k_reduce
+    int32_t* ps_scratch;     // per-sample regrouping scratch (3 x max_batch ints)
     std::vector<Seg> segs;   // host copy of the gradient segments (fused-Adam layout check)
     const void* adam_ok_seg_start;   // seg_start array already verified against `segs`
     const void* adam_ok_grads;
@@ -3547,7 +3708,7 @@ static int validate_model(const mmn_model* m) {
 namespace {
 struct Layout {
     size_t off_plan, off_states, off_hid, off_dpre, off_dz, off_dS, off_pack, off_lossp, off_scp, off_cnt,
-        off_flags, off_slabs, off_epoch, off_stamps, off_tasks, off_items, off_segs, off_ptasks, off_recs, off_sin, total;
+        off_flags, off_slabs, off_epoch, off_stamps, off_tasks, off_items, off_segs, off_ptasks, off_recs, off_sin, off_ps, total;
     int64_t hid_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
     int64_t pkf_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
     int64_t pkb_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
@@ -3793,6 +3954,7 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     L.off_ptasks = take(sizeof(PackTask) * L.ptasks.size());
     L.off_recs = take(sizeof(WRec) * L.items.size());
     L.off_sin = take(sizeof(float) * (size_t)E * maxB * S);
+    L.off_ps = take(sizeof(int32_t) * 3 * (size_t)maxB);      // per-sample regrouping scratch: codes, masks, source rows
     L.total = o;
 }
 
@@ -3907,6 +4069,7 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     pl->rd = RdArgs{h.segs, h.slabs, h.lossp, h.scp, h.cnt, h.exec_flags, h.stats, h.epoch, L.n_grad_elems,
                     (int32_t)L.segs.size(), h.R, h.D, h.E, h.S, 0};
     pl->segs = L.segs;
+    pl->ps_scratch = reinterpret_cast<int32_t*>(ws + L.off_ps);
     pl->adam_ok_seg_start = nullptr; pl->adam_ok_grads = nullptr;
     pl->grad_blocks = (int)((L.n_grad_elems + NTR - 1) / NTR);
     {
@@ -4003,6 +4166,8 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
             (e = hipFuncSetAttribute(fns[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)) != hipSuccess)
             return fail(e);
     }
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ps_layout), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(sizeof(int) * (PS_MAX_ROWS / 64) * PS_MAXG))) != hipSuccess) return fail(e);
     if (pl->fb8_ok &&
         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fb8), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)pl->fb8_lds_bytes)) != hipSuccess) return fail(e);
@@ -4259,6 +4424,48 @@ int mmn_reduce_adam(mmn_plan* p, const mmn_batch* b, const mmn_adam* adam, void*
     if (rc != MMN_OK) return rc;
     if ((rc = adam_fusable(p, adam)) != MMN_OK) return rc;
     return launch_reduce(p, b, 1, 0, 0.f, 0.f, stream, adam);
+}
+
+int mmn_regroup_rows(int batch, int n_encoders) {
+    if (batch < 1 || n_encoders < 1 || n_encoders > 4) return 0;
+    int patterns = 0;                                      // ordered subsets of the encoders = distinct executed sequences
+    for (int k = 0; k <= n_encoders; ++k) {
+        int perm = 1;
+        for (int j = 0; j < k; ++j) perm *= (n_encoders - j);
+        patterns += perm;
+    }
+    return (batch + 15) / 16 * 16 + 16 * (patterns < batch ? patterns : batch);
+}
+
+int mmn_regroup(mmn_plan* p, const mmn_batch* in, const int64_t* seq, mmn_batch* out, void* stream) {
+    if (!p || !in || !out || !in->y || !out->y || !out->tile_rows || !out->tile_seq) return MMN_ERR_ARG;
+    const int E = p->m.n_encoders, D = p->m.n_decoders, B = in->batch;
+    if (!p->fb8_ok || E > 4) return MMN_ERR_UNSUPPORTED;
+    if (B < 1 || B > PS_MAX_ROWS) return MMN_ERR_UNSUPPORTED;
+    const int rows = mmn_regroup_rows(B, E);
+    if (rows > p->max_batch) return MMN_ERR_ARG;
+    mmn_batch bi = *in, bo = *out;
+    for (int k = 0; k < E; ++k) {
+        if (!in->x[k] || !out->x[k]) return MMN_ERR_ARG;
+        // (the kernels take the widths through the otherwise unused seq_data slots of their by-value copies)
+        bi.seq_data[k] = p->m.enc[seq ? 0 : k].n_features;   // slot k's width (all equal when an order is given)
+        bo.seq_data[k] = p->m.enc[k].n_features;
+        if (seq && p->m.enc[k].n_features != p->m.enc[0].n_features) return MMN_ERR_UNSUPPORTED;
+        if (in->ldx[k] < bi.seq_data[k] || out->ldx[k] < bo.seq_data[k]) return MMN_ERR_ARG;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int32_t* codes = p->ps_scratch; int32_t* pmask = codes + p->max_batch; int32_t* src_of = pmask + p->max_batch;
+    hipLaunchKernelGGL(k_ps_code, dim3((B + NT / 64 - 1) / (NT / 64)), dim3(NT), 0, st, bi, seq, E, codes, pmask);
+    hipLaunchKernelGGL(k_ps_layout, dim3(1), dim3(1024), sizeof(int) * (size_t)((B + 63) / 64) * PS_MAXG, st, codes, B, rows, src_of,
+                       const_cast<int32_t*>(out->tile_rows), const_cast<int32_t*>(out->tile_seq));
+    hipLaunchKernelGGL(k_ps_gather, dim3((rows + NT / 64 - 1) / (NT / 64)), dim3(NT), 0, st, bi, seq, E, D, src_of, pmask, bo, rows);
+    HIP_TRY(hipGetLastError());
+    out->batch = rows;
+    out->batch_global = in->batch_global;
+    out->n_seq = E;
+    out->nan_flags = nullptr;
+    for (int k = 0; k < E; ++k) { out->seq_data[k] = k; out->seq_enc[k] = k; }
+    return MMN_OK;
 }
 
 int mmn_eval_step(mmn_plan* p, const mmn_batch* b, int accumulate_epoch, void* stream) {

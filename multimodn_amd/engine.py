@@ -83,6 +83,7 @@ class HipChainEngine:
                 raise UnsupportedModelError("parameters must be float32")
         self._flatten_params()
         self.n_params = self.flat_params.numel()
+        self._torch_regroup = False          # tests: force the torch-op regrouping of per-sample mode
         self._build(max_batch)
 
     # ------------------------------------------------------------------ buffers and plan
@@ -252,6 +253,21 @@ class HipChainEngine:
         if seq is not None and len(set(feats)) != 1:
             raise UnsupportedModelError("per-sample encoder order needs modalities of equal width "
                                         "(slot k must be able to feed any encoder)")
+        rows = int(self.lib.mmn_regroup_rows(B, E))
+        if rows > 0 and B <= 16384 and not self._torch_regroup:
+            # three HIP launches (k_ps_code / k_ps_layout / k_ps_gather) instead of ~40 torch ops
+            self.ensure(rows)
+            xs_p = [torch.empty((rows, f), dtype=torch.float32, device=dev) for f in feats]
+            y_p = torch.empty((rows, y.shape[1]), dtype=torch.int64, device=dev)
+            tile_rows = torch.empty(rows // 16, dtype=torch.int32, device=dev)
+            tile_seq = torch.empty(rows // 16, dtype=torch.int32, device=dev)
+            bin_ = self.make_batch(xs, y, [(k, k) for k in range(E)], batch_global=B)
+            bout = self.make_batch(xs_p, y_p, [(k, k) for k in range(E)], batch_global=B)
+            bout.tile_rows, bout.tile_seq = tile_rows.data_ptr(), tile_seq.data_ptr()
+            sq = None if seq is None else seq.to(dev, torch.int64).contiguous()
+            hip.check(self.lib.mmn_regroup(self._plan, C.byref(bin_), None if sq is None else sq.data_ptr(),
+                                           C.byref(bout), self._stream()), "mmn_regroup")
+            return bout, (xs_p, y_p, tile_rows, tile_seq, sq, xs, y)
         present = torch.stack([~torch.isnan(x).any(dim=1) for x in xs], dim=1)           # [B, E] slot present
         enc_of = seq.to(dev, torch.int64) if seq is not None else torch.arange(E, device=dev).expand(B, E)
         pi = present.to(torch.int64)

@@ -44,10 +44,11 @@ def check(stats, grads, ref, tol=1e-5, tolg=2e-5):
             assert rel_err(got.reshape(g.shape), g) < tolg, (n, rel_err(got.reshape(g.shape), g))
 
 
-def run_step(model, xs, y, seq):
+def run_step(model, xs, y, seq, torch_regroup=False):
     model.per_sample = True
     data = [torch.from_numpy(x) for x in xs]
     eng = model._get_engine(len(y))
+    eng._torch_regroup = torch_regroup      # regrouping by torch ops instead of mmn_regroup's three kernels
     eng.epoch_reset()
     _, keep = model._run_step_per_sample(eng, data, torch.from_numpy(y), None if seq is None else torch.from_numpy(seq))
     eng.assign_grads(None)
@@ -78,6 +79,24 @@ def test_per_sample_step_matches_oracle(B, E, permute):
     model = build_torch_model(spec, params, "cuda", mm)
     stats, grads = run_step(model, xs, y, seq)
     check(stats, grads, O.per_sample_step(params, spec, xs, y, seq))
+
+
+@pytest.mark.gpu
+def test_hip_regrouping_equals_torch_regrouping():
+    """mmn_regroup (k_ps_code / k_ps_layout / k_ps_gather) and the torch-op regrouping build the same
+    layout: bit-identical statistics and gradients."""
+    mm.hip.load()
+    for B, E, perm in ((333, 4, True), (64, 3, False), (4096, 4, True)):
+        spec, xs, y, seq = c5_like(B, E=E, seed=7 + B)
+        if not perm:
+            seq = None
+        params = O.init_params(spec, 2)
+        a = run_step(build_torch_model(spec, params, "cuda", mm), xs, y, seq, torch_regroup=False)
+        b = run_step(build_torch_model(spec, params, "cuda", mm), xs, y, seq, torch_regroup=True)
+        for k in a[0]:
+            assert np.array_equal(a[0][k], b[0][k]), k
+        for n in a[1]:
+            assert np.array_equal(a[1][n], b[1][n]), n
 
 
 @pytest.mark.gpu

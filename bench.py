@@ -21,17 +21,12 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
-sys.path.insert(0, os.path.join(REPO, "tests"))
 
 import numpy as np
 import torch
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix) = vector peak
 HBM_PEAK_GBS = 8000.0
-
-
-def c3_spec(O):
-    return O.ModelSpec(128, [O.EncoderSpec(64, (32, 32), O.ACT_RELU) for _ in range(4)], 3, 1.0, 0.3)
 
 
 # SURVEY.md section 8 shorthand.  c3 is the configuration the metric is quoted on (the default and
@@ -54,17 +49,39 @@ WORKLOADS = {
 }
 
 
-def workload_spec(O, name):
-    w = WORKLOADS[name]
+def oracle_spec(O, w):
+    """The workload as the CPU oracle describes it (cpu_baseline leg only)."""
     return O.ModelSpec(w["S"], [O.EncoderSpec(f, tuple(w["H"]), O.ACT_RELU) for f in w["F"]], w["D"], *w["pen"])
 
 
-def flops_per_sample(spec):
+def build_model(mm, w, device):
+    """The workload's model on the product surface: MLPEncoder / LogisticDecoder / MultiModN with
+    torch's default initialisation under a fixed seed (the same weights on every rank)."""
+    torch.manual_seed(0)
+    enc = [mm.MLPEncoder(w["S"], f, tuple(w["H"])) for f in w["F"]]
+    dec = [mm.LogisticDecoder(w["S"]) for _ in range(w["D"])]
+    return mm.MultiModN(w["S"], enc, dec, w["pen"][0], w["pen"][1], device=device)
+
+
+def synthetic_batches(w, n_rows, batch_size, seed):
+    """SURVEY 8d generator: standard-normal float32 features, learnable binary targets
+    y_d = 1[x . w_d + 0.5 eps > 0]; returns [(list of [B, F_k] arrays, [B, D] int64)]."""
+    rng = np.random.default_rng(seed)
+    Fs = w["F"]
+    X = rng.standard_normal((n_rows, sum(Fs))).astype(np.float32)
+    wt = rng.standard_normal((sum(Fs), w["D"])).astype(np.float32)
+    y = ((X @ wt + 0.5 * rng.standard_normal((n_rows, w["D"])).astype(np.float32)) > 0).astype(np.int64)
+    offs = np.cumsum([0] + list(Fs))
+    return [([X[s:s + batch_size, offs[k]:offs[k + 1]].copy() for k in range(len(Fs))], y[s:s + batch_size].copy())
+            for s in range(0, n_rows, batch_size)]
+
+
+def flops_per_sample_of(w):
     """Algorithmic FLOPs (MAC = 2) per sample of each launch (SURVEY.md section 8d formulas)."""
-    S, E, D = spec.state_size, spec.E, spec.D
+    S, E, D = w["S"], len(w["F"]), w["D"]
     fwd = bwd = wg = 0
-    for enc in spec.encoders:
-        dims = [enc.n_features] + list(enc.hidden)
+    for f in w["F"]:
+        dims = [f] + list(w["H"])
         hidden = sum(a * b for a, b in zip(dims, dims[1:]))
         last = (dims[-1] + S) * S
         fwd += hidden + last
@@ -145,8 +162,6 @@ def main():
     args = ap.parse_args()
 
     import multimodn_amd as mm
-    from helpers import build_torch_model
-    from oracle import multimodn_oracle as O      # cpu_baseline leg + synthetic generator only
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -165,10 +180,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
 
     wl = WORKLOADS[args.workload]
-    spec = workload_spec(O, args.workload)
+    n_enc = len(wl["F"])
     B = args.batch or wl["B"]
-    params = O.init_params(spec, 0)                           # same weights on every rank
-    model = build_torch_model(spec, params, dev, mm)
+    model = build_model(mm, wl, dev)
     model.nan_policy = "device"
     if dp:
         model.enable_data_parallel()
@@ -182,11 +196,11 @@ def main():
         opt = torch.optim.Adam(list(model.parameters()), wl["lr"], fused=True, capturable=True)
 
     # synthetic data resident in HBM (weak scaling: every rank its own B rows per step)
-    host = O.synthetic_batches(spec, B * args.resident_batches, B, seed=100 + rank, learnable=True)
+    host = synthetic_batches(wl, B * args.resident_batches, B, seed=100 + rank)
     resident = []
     for xs, y in host:
         resident.append(([torch.from_numpy(x).to(dev) for x in xs], torch.from_numpy(y).to(dev)))
-    pairs = [(i, i) for i in range(spec.E)]
+    pairs = [(i, i) for i in range(n_enc)]
     per_sample = bool(wl.get("per_sample"))
     seqs = None
     if per_sample:
@@ -196,10 +210,10 @@ def main():
         seqs = []
         for xs, y in resident:
             p_miss = torch.where(y[:, :1] == 1, 0.45, 0.15).cpu().numpy()
-            miss = torch.from_numpy(rng.random((B, spec.E)) < p_miss).to(dev)
-            for e in range(spec.E):
+            miss = torch.from_numpy(rng.random((B, n_enc)) < p_miss).to(dev)
+            for e in range(n_enc):
                 xs[e][miss[:, e]] = float("nan")
-            seqs.append(torch.from_numpy(np.stack([rng.permutation(spec.E) for _ in range(B)]).astype(np.int64)).to(dev))
+            seqs.append(torch.from_numpy(np.stack([rng.permutation(n_enc) for _ in range(B)]).astype(np.int64)).to(dev))
         args.no_graph = True                                 # the regrouping uses torch ops that size-sync
         batches, _keep_ps = [], []
         for (xs, y), sq in zip(resident, seqs):              # (only for the per-kernel timing section below)
@@ -335,7 +349,7 @@ def main():
             torch.cuda.synchronize()
             times.append(e0.elapsed_time(e1) * 1e3 / REP)
         avg_us[name] = float(np.median(times))
-    flp = flops_per_sample(spec)
+    flp = flops_per_sample_of(wl)
     if fused_name:
         fl = {fused_name: flp["k_chain_fwd"] + flp["k_chain_bwd"], "k_wgrad": flp["k_wgrad"]}
     else:
@@ -372,6 +386,8 @@ def main():
         "roofline": roofline,
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
+        from oracle import multimodn_oracle as O      # the CPU oracle: imported for this leg ONLY, never measured as `value`
+        spec = oracle_spec(O, wl)
         out["cpu_baseline"] = cpu_baseline(O, spec, B, args.cpu_budget)
         out["cpu_baseline"]["reference_style_step"] = cpu_faithful_step(O, spec, B)
     elif rank == 0:

@@ -2399,6 +2399,9 @@ __device__ __forceinline__ ExecInfo exec_from_code(unsigned code) {
     return x;
 }
 
+// TILED = per-sample mode (mmn_batch.tile_seq): a separate instantiation, so that the ordinary
+// batch path carries none of its branches
+template <bool TILED>
 __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b, float cL, float cS) {
     constexpr int TB = 16;
     extern __shared__ __attribute__((aligned(16))) float smem_generic[];
@@ -2409,7 +2412,7 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
     const lp sDzA = smem + L.sDzA;
     const int tile = blockIdx.x, row0 = tile * TB;
     // per-sample mode (mmn_batch.tile_seq): rows come grouped into tiles of one executed sequence
-    const bool tiled = b.tile_seq != nullptr;
+    constexpr bool tiled = TILED;
     const int nrows = tiled ? g_ldi(b.tile_rows + tile) : min(TB, b.batch - row0);
     const unsigned tcode = tiled ? (unsigned)g_ldi(b.tile_seq + tile) : 0u;
     if (tiled && nrows == 0) {                             // padding tile (wave-uniform): its partials are zeros
@@ -4169,8 +4172,10 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ps_layout), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(sizeof(int) * (PS_MAX_ROWS / 64) * PS_MAXG))) != hipSuccess) return fail(e);
     if (pl->fb8_ok &&
-        (e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fb8), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)pl->fb8_lds_bytes)) != hipSuccess) return fail(e);
+        ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fb8<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)pl->fb8_lds_bytes)) != hipSuccess ||
+         (e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fb8<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)pl->fb8_lds_bytes)) != hipSuccess)) return fail(e);
     if (pl->f8_ok) {
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd8), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)pl->f8_lds_fwd)) != hipSuccess) return fail(e);
@@ -4317,8 +4322,12 @@ int mmn_chain_fwd_bwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float 
         const int tiles = (b->batch + 15) / 16;
         const float cL = err_penalty / ((float)p->m.n_decoders * (float)(p->m.n_encoders + 1) * (float)b->batch_global);
         mmn_batch bb = *b;
-        hipLaunchKernelGGL(k_fb8, dim3(tiles), dim3(NT8), p->fb8_lds_bytes, static_cast<hipStream_t>(stream), p->pa, bb, cL,
-                           sc_coeff(p, b, sc_pen_x001));
+        if (b->tile_seq)
+            hipLaunchKernelGGL(k_fb8<true>, dim3(tiles), dim3(NT8), p->fb8_lds_bytes, static_cast<hipStream_t>(stream), p->pa, bb,
+                               cL, sc_coeff(p, b, sc_pen_x001));
+        else
+            hipLaunchKernelGGL(k_fb8<false>, dim3(tiles), dim3(NT8), p->fb8_lds_bytes, static_cast<hipStream_t>(stream), p->pa, bb,
+                               cL, sc_coeff(p, b, sc_pen_x001));
         HIP_TRY(hipGetLastError());
         return MMN_OK;
     }

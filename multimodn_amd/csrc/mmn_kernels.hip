@@ -3271,12 +3271,15 @@ __global__ __launch_bounds__(1024) void k_ps_layout(const int32_t* __restrict__ 
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_code[mid] < c) lo = mid + 1; else hi = mid; }
             gid = lo;
         }
-        int rk = 0;
-        for (int g = 0; g < G; ++g) {
-            const unsigned long long m = __ballot(gid == g);
-            if (gid == g) rk = __popcll(m & ((1ull << lane) - 1ull));
-            if (lane == 0) cnt[ch * PS_MAXG + g] = __popcll(m);
+        // lanes of this chunk with MY group id: AND of one ballot per id bit (7 ballots, not one per group)
+        unsigned long long same = __ballot(gid >= 0);
+#pragma unroll
+        for (int bit = 0; bit < 7; ++bit) {
+            const unsigned long long mb = __ballot((gid >> bit) & 1);
+            same &= ((gid >> bit) & 1) ? mb : ~mb;
         }
+        const int rk = __popcll(same & ((1ull << lane) - 1ull));
+        if (gid >= 0 && rk == 0) cnt[ch * PS_MAXG + gid] = __popcll(same);     // the group's first lane in the chunk
         my_gid[nmine] = gid; my_rank[nmine] = rk; ++nmine;
     }
     __syncthreads();

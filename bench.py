@@ -153,6 +153,10 @@ def main():
     ap.add_argument("--graph-steps", type=int, default=8, help="consecutive steps captured into one hipGraph")
     ap.add_argument("--optimizer", choices=("hip", "torch"), default="hip",
                     help="hip: multimodn_amd.optim.Adam (one k_adam launch); torch: torch.optim.Adam(fused, capturable)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default, what the driver's scaling run uses): every GPU gets the workload's batch; "
+                         "strong: the workload's batch is split over the GPUs (SURVEY 8e: the mode whose loss curve "
+                         "must equal the single-device one)")
     ap.add_argument("--force-dist", action="store_true",
                     help="testing aid: take the data-parallel code path (process group, all-reduce, separate Adam) "
                          "even with one rank")
@@ -182,6 +186,8 @@ def main():
     wl = WORKLOADS[args.workload]
     n_enc = len(wl["F"])
     B = args.batch or wl["B"]
+    if args.scaling == "strong":
+        B = max(1, B // max(world, 1))                       # rows per GPU; the global batch stays the workload's
     model = build_model(mm, wl, dev)
     model.nan_policy = "device"
     if dp:
@@ -375,9 +381,9 @@ def main():
     out = {
         "metric": "samples/sec/GPU (MIMIC 4-enc/3-dec, state_dim=128) + CPU-match Δloss",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": wl["text"] if B == wl["B"] else wl["text"] + f" [batch overridden: {B}]",
+        "config": {"workload": wl["text"] if B == wl["B"] else wl["text"] + f" [rows per GPU: {B}]",
                    "optimizer": ("multimodn_amd.optim.Adam fused into k_reduce" if fuse_opt is not None else
                                  "multimodn_amd.optim.Adam (k_adam)") if args.optimizer == "hip" else "torch.optim.Adam(fused, capturable)",
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",

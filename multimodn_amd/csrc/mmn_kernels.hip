@@ -3445,36 +3445,55 @@ __global__ __launch_bounds__(ADAM_NT) void k_adam(const AdamArgs a) {
 // k_reduce: slabs -> gradient tensors (one thread per element); last block: tile partials -> stats
 // (+ optional loss combination / epoch accumulation, + re-zeroing of the NaN flags)
 // ------------------------------------------------------------------------------------------------
+// Epoch accumulators (f64 sums of the f32 step values; tp/tn/fp/fn kept in fp32 like the reference's
+// torch.zeros tensors, multimodn.py:112-115,209-212).  Split in two so that k_reduce can request the
+// old sums at kernel start and only add + store once the step's stats exist: `st` may be an LDS copy.
+struct EpochPre { double v[8]; };
 template <class PlanLike>
-__device__ __forceinline__ void epoch_accumulate_block(const PlanLike& p, float alpha, float beta) {
+__device__ __forceinline__ EpochPre epoch_prefetch(const PlanLike& p) {
     const int R = p.R, D = p.D, E = p.E, RD = R * D;
-    float* st = p.stats;
+    const double* ep = p.epoch;
+    const int c = threadIdx.x;
+    EpochPre q;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q.v[k] = 0.0;
+    if (c < RD) {
+        q.v[0] = ep[c];
+        q.v[1] = ep[RD + E + c];
+        for (int k = 1; k < 5; ++k) q.v[1 + k] = ep[RD + E + k * RD + c];
+    }
+    if (c < E) q.v[6] = ep[RD + c];
+    if (c < R) q.v[7] = ep[RD + E + 5 * RD + c];
+    return q;
+}
+// needs blockDim.x >= max(R*D, 64); `st` holds the step's stats block (first RD + E + 5 RD + R entries)
+template <class PlanLike>
+__device__ __forceinline__ void epoch_apply(const PlanLike& p, const float* st, const EpochPre& q, float alpha, float beta) {
+    const int R = p.R, D = p.D, E = p.E, RD = R * D;
     double* ep = p.epoch;
-    const int lane = threadIdx.x & 63, wave = wave_id();
-    if (wave == 0) {                                       // fixed-order sums of grid and state change
+    const int c = threadIdx.x, lane = threadIdx.x & 63;
+    if (c < 64) {                                          // fixed-order sums of grid and state change
         float se = 0.f, ss = 0.f;
-        for (int c = lane; c < RD; c += 64) se += st[c];
+        for (int k = lane; k < RD; k += 64) se += st[k];
         for (int e = lane; e < E; e += 64) ss += st[RD + e];
         se = wave_sum(se); ss = wave_sum(ss);
         if (lane == 0) {
             const float ge = se / (float)(D * R);          // multimodn.py:194
             const float gs = ss / (float)E;                // multimodn.py:196
-            float* tail = st + RD + E + 5 * RD + R;
+            float* tail = p.stats + RD + E + 5 * RD + R;
             tail[0] = ge * alpha + gs * beta;              // multimodn.py:199-202
             tail[1] = ge; tail[2] = gs; tail[3] = 0.f;
             ep[RD + E + 5 * RD + R] += 1.0;                // n_steps
         }
     }
-    for (int c = threadIdx.x; c < RD; c += NT) {
-        ep[c] += (double)st[c];                                            // err_loss_epoch (f64 += f32)
-        ep[RD + E + c] += (double)st[RD + E + c];                          // n_correct
-        for (int k = 1; k < 5; ++k) {                                      // tp/tn/fp/fn kept in fp32
-            double* a = ep + RD + E + k * RD + c;
-            *a = (double)((float)*a + st[RD + E + k * RD + c]);
-        }
+    if (c < RD) {
+        ep[c] = q.v[0] + (double)st[c];                                    // err_loss_epoch (f64 += f32)
+        ep[RD + E + c] = q.v[1] + (double)st[RD + E + c];                  // n_correct
+        for (int k = 1; k < 5; ++k)                                        // tp/tn/fp/fn kept in fp32
+            ep[RD + E + k * RD + c] = (double)((float)q.v[1 + k] + st[RD + E + k * RD + c]);
     }
-    for (int e = threadIdx.x; e < E; e += NT) ep[RD + e] += (double)st[RD + e];
-    for (int r = threadIdx.x; r < R; r += NT) ep[RD + E + 5 * RD + r] += (double)st[RD + E + 5 * RD + r];
+    if (c < E) ep[RD + c] = q.v[6] + (double)st[RD + c];
+    if (c < R) ep[RD + E + 5 * RD + c] = q.v[7] + (double)st[RD + E + 5 * RD + c];
 }
 
 constexpr int NTR = 1024;     // k_reduce block size
@@ -3586,6 +3605,9 @@ __global__ __launch_bounds__(NTR) void k_reduce(const RdArgs r, const AdamArgs a
     float* st = r.stats;
     const float Bg = (float)batch_global;
     if ((int)threadIdx.x < R) s_exec[threadIdx.x] = g_ldi(r.exec_flags + threadIdx.x);
+    EpochPre epre;
+    if (accumulate) epre = epoch_prefetch(r);              // the old epoch sums travel while the partials are summed
+    __shared__ float s_st[MMN_MAX_ENCODERS * 0 + 1024];    // this step's stats, for the epoch accumulation below
     __syncthreads();
     __shared__ float spart[NTR / 8][8];
     const int nq = RD + E + 5 * RD;
@@ -3623,12 +3645,18 @@ __global__ __launch_bounds__(NTR) void k_reduce(const RdArgs r, const AdamArgs a
         if (qd < nq && ch == 0) {
             const float* sp = spart[threadIdx.x >> 3];
             const float tot = (((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + (sp[6] + sp[7])));
-            st[qd] = qd < RD ? tot / Bg : (qd < RD + E ? tot / (Bg * (float)S) : tot);
+            const float val = qd < RD ? tot / Bg : (qd < RD + E ? tot / (Bg * (float)S) : tot);
+            st[qd] = val;
+            if (qd < 1024) s_st[qd] = val;
         }
         __syncthreads();
     }
     if (tile_seq == nullptr) {
-        for (int q = threadIdx.x; q < R; q += NTR) st[RD + E + 5 * RD + q] = s_exec[q] ? (float)batch : 0.f;
+        for (int q = threadIdx.x; q < R; q += NTR) {
+            const float val = s_exec[q] ? (float)batch : 0.f;
+            st[RD + E + 5 * RD + q] = val;
+            if (RD + E + 5 * RD + q < 1024) s_st[RD + E + 5 * RD + q] = val;
+        }
     } else {                                               // per-sample: samples that own grid row q
         const int q = threadIdx.x >> 6, ln = threadIdx.x & 63;
         if (q < R) {
@@ -3641,19 +3669,23 @@ __global__ __launch_bounds__(NTR) void k_reduce(const RdArgs r, const AdamArgs a
                 cntq += has ? nr : 0;
             }
             const float tot = wave_sum((float)cntq);       // exact: counts are far below 2^24
-            if (ln == 0) st[RD + E + 5 * RD + q] = tot;
+            if (ln == 0) { st[RD + E + 5 * RD + q] = tot; if (RD + E + 5 * RD + q < 1024) s_st[RD + E + 5 * RD + q] = tot; }
         }
     }
     if (nan_flags && threadIdx.x < MMN_MAX_ENCODERS) nan_flags[threadIdx.x] = 0;
     if (accumulate) {
-        __threadfence_block();
         __syncthreads();
-        if (threadIdx.x < NT) epoch_accumulate_block(r, alpha, beta);
+        // (stats blocks larger than the LDS mirror - more than 16 encoders x 8 decoders would be needed -
+        //  fall back to reading the stats back from global memory)
+        const bool fits = RD + E + 5 * RD + R <= 1024;
+        if (!fits) __threadfence_block();
+        epoch_apply(r, fits ? s_st : st, epre, alpha, beta);
     }
 }
 
 __global__ __launch_bounds__(NT) void k_epoch_accumulate(const DevPlan* __restrict__ P, float alpha, float beta) {
-    epoch_accumulate_block(*P, alpha, beta);
+    const EpochPre q = epoch_prefetch(*P);
+    epoch_apply(*P, P->stats, q, alpha, beta);
 }
 
 }  // namespace

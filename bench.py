@@ -244,7 +244,10 @@ def main():
         eng.local_step(b, alpha, beta, accumulate=not dp, optimizer=fuse_opt)
         if dp:
             dist.all_reduce(eng.reduce_buf)                  # ONE collective per step: grads + stats
-            eng.accumulate(alpha, beta)
+            if args.optimizer == "hip":
+                eng.accumulate_and_step(alpha, beta, opt)    # epoch accumulation + Adam: one launch
+            else:
+                eng.accumulate(alpha, beta)
         opt.step()                                           # no-op when the step was fused
 
     eng.assign_grads(None)

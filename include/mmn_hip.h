@@ -253,6 +253,10 @@ typedef struct mmn_adam {
 } mmn_adam;
 int mmn_adam_blocks(int64_t n);      /* rows of `steps`; 0 if n is out of range */
 int mmn_adam_step(const mmn_adam* d, void* stream);
+/* Data-parallel tail in one launch, after the all-reduce of [grads | stats]: mmn_adam_step plus
+ * mmn_epoch_accumulate. */
+int mmn_adam_step_accumulate(mmn_plan* p, const mmn_adam* d, float err_penalty, float state_change_penalty_x001,
+                             void* stream);
 
 /* mmn_train_step with optimizer.step() fused behind the gradient sum (single GPU: no all-reduce in
  * between): the last launch forms each gradient element and immediately applies Adam to that

@@ -3381,7 +3381,7 @@ __device__ __forceinline__ double ipow(double b, unsigned t) {
     return r;
 }
 
-__global__ __launch_bounds__(ADAM_NT) void k_adam(const AdamArgs a) {
+__device__ __forceinline__ void adam_block(const AdamArgs& a) {
     __shared__ int s_start[ADAM_MAX_SEG + 1];
     __shared__ float s_ss[ADAM_MAX_SEG], s_bc2s[ADAM_MAX_SEG];
     const int tid = threadIdx.x;
@@ -3440,6 +3440,8 @@ __global__ __launch_bounds__(ADAM_NT) void k_adam(const AdamArgs a) {
         }
     }
 }
+
+__global__ __launch_bounds__(ADAM_NT) void k_adam(const AdamArgs a) { adam_block(a); }
 
 // ------------------------------------------------------------------------------------------------
 // k_reduce: slabs -> gradient tensors (one thread per element); last block: tile partials -> stats
@@ -3684,6 +3686,15 @@ __global__ __launch_bounds__(NTR) void k_reduce(const RdArgs r, const AdamArgs a
 }
 
 __global__ __launch_bounds__(NT) void k_epoch_accumulate(const DevPlan* __restrict__ P, float alpha, float beta) {
+    const EpochPre q = epoch_prefetch(*P);
+    epoch_apply(*P, P->stats, q, alpha, beta);
+}
+
+// Data-parallel tail in ONE launch (after the all-reduce of [grads | stats]): workgroups
+// [0, adam_blocks) are k_adam, the last one is k_epoch_accumulate.
+__global__ __launch_bounds__(ADAM_NT) void k_adam_accumulate(const AdamArgs a, int adam_blocks, const DevPlan* __restrict__ P,
+                                                             float alpha, float beta) {
+    if ((int)blockIdx.x < adam_blocks) { adam_block(a); return; }
     const EpochPre q = epoch_prefetch(*P);
     epoch_apply(*P, P->stats, q, alpha, beta);
 }
@@ -4522,6 +4533,17 @@ int mmn_eval_step(mmn_plan* p, const mmn_batch* b, int accumulate_epoch, void* s
 int mmn_adam_blocks(int64_t n) {
     if (n < 1 || n > 0x7fffffff - 4 * ADAM_NT) return 0;
     return (int)((n + 4 * ADAM_NT - 1) / (4 * ADAM_NT));
+}
+
+int mmn_adam_step_accumulate(mmn_plan* p, const mmn_adam* d, float err_penalty, float sc_pen_x001, void* stream) {
+    if (!p) return MMN_ERR_ARG;
+    const int rc = check_adam(d);
+    if (rc != MMN_OK) return rc;
+    const int blocks = mmn_adam_blocks(d->n);
+    hipLaunchKernelGGL(k_adam_accumulate, dim3(blocks + 1), dim3(ADAM_NT), 0, static_cast<hipStream_t>(stream), adam_args(d),
+                       blocks, p->dev, err_penalty, sc_pen_x001);
+    HIP_TRY(hipGetLastError());
+    return MMN_OK;
 }
 
 int mmn_adam_step(const mmn_adam* d, void* stream) {

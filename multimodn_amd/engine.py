@@ -308,6 +308,19 @@ class HipChainEngine:
     def eval_step(self, b: hip.Batch, accumulate: bool = False) -> None:
         hip.check(self.lib.mmn_eval_step(self._plan, C.byref(b), 1 if accumulate else 0, self._stream()), "mmn_eval_step")
 
+    def accumulate_and_step(self, err_penalty: float, sc_penalty_x001: float, optimizer) -> bool:
+        """Data-parallel tail after the all-reduce: epoch accumulation + the optimizer's Adam step in ONE
+        launch when `optimizer` is a multimodn_amd.optim.Adam over this model (returns True: its next
+        .step() is a no-op); otherwise only the accumulation (returns False)."""
+        d = optimizer.fused_descriptor(self) if hasattr(optimizer, "fused_descriptor") else None
+        if d is None:
+            self.accumulate(err_penalty, sc_penalty_x001)
+            return False
+        hip.check(self.lib.mmn_adam_step_accumulate(self._plan, C.byref(d), err_penalty, sc_penalty_x001, self._stream()),
+                  "mmn_adam_step_accumulate")
+        optimizer.mark_fused_step()
+        return True
+
     def accumulate(self, err_penalty: float, sc_penalty_x001: float) -> None:
         hip.check(self.lib.mmn_epoch_accumulate(self._plan, err_penalty, sc_penalty_x001, self._stream()),
                   "mmn_epoch_accumulate")

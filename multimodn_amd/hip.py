@@ -30,7 +30,7 @@ ABI_SYMBOLS = (
     "mmn_workspace_bytes", "mmn_plan_create", "mmn_plan_destroy", "mmn_nan_flags", "mmn_prepare",
     "mmn_nan_scan", "mmn_chain_kernel_name", "mmn_chain_fwd",
     "mmn_chain_bwd", "mmn_chain_fwd_bwd", "mmn_wgrad", "mmn_reduce", "mmn_epoch_accumulate", "mmn_train_step",
-    "mmn_eval_step", "mmn_adam_blocks", "mmn_adam_step", "mmn_train_step_adam", "mmn_reduce_adam", "mmn_regroup_rows", "mmn_regroup", "mmn_epoch_reset", "mmn_epoch_read", "mmn_debug_buffer",
+    "mmn_eval_step", "mmn_adam_blocks", "mmn_adam_step", "mmn_adam_step_accumulate", "mmn_train_step_adam", "mmn_reduce_adam", "mmn_regroup_rows", "mmn_regroup", "mmn_epoch_reset", "mmn_epoch_read", "mmn_debug_buffer",
 )
 
 
@@ -136,6 +136,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_adam_blocks.argtypes = [C.c_int64]
     lib.mmn_adam_step.restype = i32
     lib.mmn_adam_step.argtypes = [C.POINTER(AdamDesc), vp]
+    lib.mmn_adam_step_accumulate.restype = i32
+    lib.mmn_adam_step_accumulate.argtypes = [vp, C.POINTER(AdamDesc), f32, f32, vp]
     lib.mmn_train_step_adam.restype = i32
     lib.mmn_train_step_adam.argtypes = [vp, C.POINTER(Batch), f32, f32, i32, C.POINTER(AdamDesc), vp]
     lib.mmn_reduce_adam.restype = i32

@@ -228,7 +228,12 @@ class MultiModN(nn.Module):
         if dp:
             import torch.distributed as dist
             dist.all_reduce(eng.reduce_buf if train else eng.stats, group=self._dp_group)
-            eng.accumulate(float(self.err_penalty) if train else 1.0, float(self.state_change_penalty) if train else 0.0)
+            if train and optimizer is not None and self.nan_policy == "device":
+                # (host policy: a skipped encoder's parameters carry grad None, which the separate
+                #  optimizer.step() honours; the fused tail has no per-step skip list)
+                eng.accumulate_and_step(float(self.err_penalty), float(self.state_change_penalty), optimizer)
+            else:
+                eng.accumulate(float(self.err_penalty) if train else 1.0, float(self.state_change_penalty) if train else 0.0)
         return executed, (xs, y)
 
     def _run_step_per_sample(self, eng, data, target, encoder_sequence, optimizer=None):

@@ -191,3 +191,34 @@ def test_fused_path_is_taken_and_matches_torch_adam():
     assert len(taken) == 2 * len(loader)
     for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
         assert rel_err(p.detach().cpu().numpy(), q.detach().cpu().numpy()) < 1e-5, n
+
+
+def test_data_parallel_tail_in_one_launch_equals_two():
+    """mmn_adam_step_accumulate (epoch accumulation + Adam after the all-reduce, one launch) against
+    mmn_epoch_accumulate followed by k_adam: bit-identical parameters and epoch sums."""
+    import multimodn_amd as mm
+    spec, params, batches, m1 = _c3_like_model(mm, seed=5)
+    _, _, _, m2 = _c3_like_model(mm, seed=5)
+    outs = []
+    for model, fused_tail in ((m1, True), (m2, False)):
+        model.nan_policy = "device"
+        opt = mm.optim.Adam(list(model.parameters()), 1e-3)
+        eng = model._get_engine(batches[0][1].shape[0])
+        eng.epoch_reset()
+        eng.assign_grads(None)
+        for xs, y in batches:
+            dx = [torch.from_numpy(x).cuda() for x in xs]
+            dy = torch.from_numpy(y).cuda()
+            b = eng.make_batch(dx, dy, [(i, i) for i in range(spec.E)], device_nan_flags=True)
+            eng.local_step(b, 1.0, 0.004, accumulate=False)          # what a rank does before the all-reduce
+            if fused_tail:
+                assert eng.accumulate_and_step(1.0, 0.004, opt)
+            else:
+                eng.accumulate(1.0, 0.004)
+            opt.step()
+        torch.cuda.synchronize()
+        outs.append(({n: p.detach().clone() for n, p in model.named_parameters()}, eng.epoch_read()))
+    for n in outs[0][0]:
+        assert torch.equal(outs[0][0][n], outs[1][0][n]), n
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k

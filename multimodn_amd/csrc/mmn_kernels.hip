@@ -3358,6 +3358,9 @@ struct AdamArgs {
     double lr, b1, b2;
     float eps, wd;
     int maximize;
+    // optional (data-parallel tail): tensor i has no gradient this step when state row gate_segs[i].gate
+    // does not exist (its encoder was skipped on a NaN batch) -> left untouched, like seg_skip
+    const Seg* gate_segs; const int32_t* exec_flags;
 };
 
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, float omb1, float b2, float omb2,
@@ -3398,7 +3401,8 @@ __device__ __forceinline__ void adam_block(const AdamArgs& a) {
     }
     for (int i = tid; i <= a.n_seg; i += ADAM_NT) s_start[i] = a.seg_start[i];
     for (int i = tid; i < a.n_seg; i += ADAM_NT) {
-        const int skip = a.seg_skip ? a.seg_skip[i] : 0;
+        int skip = a.seg_skip ? a.seg_skip[i] : 0;
+        if (a.gate_segs && !a.exec_flags[a.gate_segs[i].gate]) skip = 1;
         const float t0 = my_steps[i];
         const unsigned t = (unsigned)t0 + 1u;
         if (!skip) my_steps[i] = t0 + 1.f;
@@ -4399,6 +4403,7 @@ static AdamArgs adam_args(const mmn_adam* d) {
     a.n = (int)d->n; a.n_seg = d->n_seg;
     a.lr = d->lr; a.b1 = d->beta1; a.b2 = d->beta2; a.eps = (float)d->eps; a.wd = (float)d->weight_decay;
     a.maximize = d->maximize;
+    a.gate_segs = nullptr; a.exec_flags = nullptr;
     return a;
 }
 
@@ -4540,7 +4545,11 @@ int mmn_adam_step_accumulate(mmn_plan* p, const mmn_adam* d, float err_penalty, 
     const int rc = check_adam(d);
     if (rc != MMN_OK) return rc;
     const int blocks = mmn_adam_blocks(d->n);
-    hipLaunchKernelGGL(k_adam_accumulate, dim3(blocks + 1), dim3(ADAM_NT), 0, static_cast<hipStream_t>(stream), adam_args(d),
+    AdamArgs aa = adam_args(d);
+    if (adam_fusable(p, d) == MMN_OK) {                    // the optimizer's tensors ARE the plan's: honour skipped encoders
+        aa.gate_segs = p->rd.segs; aa.exec_flags = p->rd.exec_flags;
+    }
+    hipLaunchKernelGGL(k_adam_accumulate, dim3(blocks + 1), dim3(ADAM_NT), 0, static_cast<hipStream_t>(stream), aa,
                        blocks, p->dev, err_penalty, sc_pen_x001);
     HIP_TRY(hipGetLastError());
     return MMN_OK;

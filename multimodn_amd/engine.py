@@ -308,6 +308,16 @@ class HipChainEngine:
     def eval_step(self, b: hip.Batch, accumulate: bool = False) -> None:
         hip.check(self.lib.mmn_eval_step(self._plan, C.byref(b), 1 if accumulate else 0, self._stream()), "mmn_eval_step")
 
+    def nan_scan(self, b: hip.Batch) -> None:
+        """The NaN scan of a batch that carries device flags, on its own (data parallel: the flags are
+        OR-ed across the ranks before the step; the step's own scan then only re-sets local ones)."""
+        hip.check(self.lib.mmn_nan_scan(self._plan, C.byref(b), self._stream()), "mmn_nan_scan")
+
+    def nan_flags_tensor(self) -> torch.Tensor:
+        """int32 [MAX_ENCODERS] view of the plan's per-data-slot NaN flags (device)."""
+        off = self._nan_flags_ptr - self.workspace.data_ptr()
+        return self.workspace[off:off + 4 * hip.MAX_ENCODERS].view(torch.int32)
+
     def accumulate_and_step(self, err_penalty: float, sc_penalty_x001: float, optimizer) -> bool:
         """Data-parallel tail after the all-reduce: epoch accumulation + the optimizer's Adam step in ONE
         launch when `optimizer` is a multimodn_amd.optim.Adam over this model (returns True: its next

@@ -218,6 +218,18 @@ class MultiModN(nn.Module):
         b = eng.make_batch(xs, y, exec_pairs, batch_global=batch_global or B * self._dp_world,
                            device_nan_flags=executed is None)
         dp = self._dp_group is not None
+        if dp and executed is None and exec_pairs:
+            # device NaN policy under data parallel: the skip decision belongs to the GLOBAL batch
+            # (multimodn.py:168 looks at the whole batch): OR the per-slot flags over the ranks first
+            import torch.distributed as dist
+            eng.nan_scan(b)
+            flags = eng.nan_flags_tensor()
+            if dist.get_backend(self._dp_group) == "nccl":
+                dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self._dp_group)
+            else:
+                host_flags = flags.cpu()
+                dist.all_reduce(host_flags, op=dist.ReduceOp.MAX, group=self._dp_group)
+                flags.copy_(host_flags)
         if train:
             # single GPU + multimodn_amd.optim.Adam: optimizer.step() rides in the last launch
             fuse = optimizer if (not dp and hasattr(optimizer, "fused_descriptor")) else None
@@ -227,10 +239,16 @@ class MultiModN(nn.Module):
             eng.eval_step(b, accumulate=not dp)
         if dp:
             import torch.distributed as dist
-            dist.all_reduce(eng.reduce_buf if train else eng.stats, group=self._dp_group)
-            if train and optimizer is not None and self.nan_policy == "device":
-                # (host policy: a skipped encoder's parameters carry grad None, which the separate
-                #  optimizer.step() honours; the fused tail has no per-step skip list)
+            buf = eng.reduce_buf if train else eng.stats
+            if buf.is_cuda and dist.get_backend(self._dp_group) != "nccl":       # e.g. gloo in tests: stage through the host
+                host_buf = buf.cpu()
+                dist.all_reduce(host_buf, group=self._dp_group)
+                buf.copy_(host_buf)
+            else:
+                dist.all_reduce(buf, group=self._dp_group)
+            if train and optimizer is not None:
+                # epoch accumulation + Adam in one launch when the optimizer is multimodn_amd.optim.Adam
+                # (it leaves the parameters of encoders that did not run untouched, like grad None)
                 eng.accumulate_and_step(float(self.err_penalty), float(self.state_change_penalty), optimizer)
             else:
                 eng.accumulate(float(self.err_penalty) if train else 1.0, float(self.state_change_penalty) if train else 0.0)

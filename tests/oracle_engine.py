@@ -134,6 +134,10 @@ class OracleEngine:
     def executed_rows(self):
         return [True] + [bool(v) for v in self._last[1].executed]
 
+    def accumulate_and_step(self, alpha, beta, optimizer):
+        self.accumulate(alpha, beta)
+        return False                     # the caller's optimizer.step() still has to run
+
     def accumulate(self, alpha, beta):
         """numpy twin of k_epoch_accumulate."""
         st = self.stats.numpy()

@@ -349,3 +349,32 @@ def test_reference_pipeline_shape_runs_end_to_end(lib, device_loader):
     assert tr.shape == (12, 2, 1) and np.stack(hist.loss["val"]).shape == (12, 2, 1)
     assert tr[-1, -1, 0] < tr[0, -1, 0] - 0.02          # the decoder on the last state learns
     assert 0.6 < float(results[0][1]) <= 1.0           # AUC of the validation report
+
+
+def test_integration_md_stub_runs(lib):
+    """The ctypes stub printed in INTEGRATION.md (what a reference maintainer would paste) is executed
+    verbatim - only the library path is made absolute - on a model with the reference's attribute
+    names, and its step is checked against the oracle."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes as C, torch\n.*?)```", text, re.S).group(1)
+    code = code.replace('C.CDLL("libmmn_hip.so")', f'C.CDLL(r"{lib.hip.LIB_PATH}")')
+    ns = {}
+    exec(code, ns)
+    spec = O.ModelSpec(128, [O.EncoderSpec(64, (32, 32), O.ACT_RELU) for _ in range(4)], 3, 1.0, 0.3)
+    params = O.init_params(spec, 1)
+    model = build_torch_model(spec, params, "cuda", lib)
+    xs, y = O.synthetic_batches(spec, 256, 256, seed=2)[0]
+    plan, ws, flat_g = ns["build_plan"](model, 256)
+    data = [torch.from_numpy(x).cuda() for x in xs]
+    target = torch.from_numpy(y).cuda()
+    ns["step"](plan, data, target, [(k, k) for k in range(4)], 1.0, 0.003)
+    torch.cuda.synchronize()
+    ref = O.forward_backward(params, spec, xs, y)
+    n_params = sum(p.numel() for p in model.parameters())
+    stats = flat_g[n_params:].cpu().numpy()
+    assert rel_err(stats[:15].reshape(5, 3), ref.err_loss) < 1e-5
+    for n, p in model.named_parameters():
+        assert rel_err(p.grad.cpu().numpy().reshape(ref.grads[n].shape), ref.grads[n]) < 2e-5, n

@@ -113,6 +113,37 @@ def cpu_faithful_step(O, spec, batch_size):
     return {"value": batch_size / el, "unit": "samples/s", "sample": f"1 step of batch {batch_size}, {el:.2f} s"}
 
 
+def cpu_match(O, mm, w, device, batch_size, steps=3):
+    """The metric's second half, "CPU-match delta-loss": the HIP path and the CPU oracle take the same
+    `steps` training steps (same initial weights, same batches, Adam) at the workload's full size;
+    reported are the largest relative difference of the (E+1) x D loss grid over the steps and of
+    the trained weights (relative to each tensor's max).  Target: <= 1e-5 on the loss."""
+    model = build_model(mm, w, device)
+    spec = oracle_spec(O, w)
+    params = {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
+    assert list(params) == spec.param_names()
+    opt = mm.optim.Adam(list(model.parameters()), w["lr"])
+    oopt = O.Adam(w["lr"])
+    eng = model._get_engine(batch_size)
+    eng.assign_grads(None)
+    alpha, beta = float(model.err_penalty), float(model.state_change_penalty)
+    worst = 0.0
+    for xs, y in synthetic_batches(w, batch_size * steps, batch_size, seed=77):
+        dx = [torch.from_numpy(x).to(device) for x in xs]
+        dy = torch.from_numpy(y).to(device)
+        b = eng.make_batch(dx, dy, [(k, k) for k in range(len(xs))], device_nan_flags=False)
+        eng.local_step(b, alpha, beta, accumulate=True, optimizer=opt)
+        opt.step()
+        got = eng.step_values()["err_loss"]
+        r = O.forward_backward(params, spec, xs, y)
+        oopt.step(params, r.grads)
+        worst = max(worst, float(np.max(np.abs(got - r.err_loss)) / np.max(np.abs(r.err_loss))))
+    dw = max(float(np.max(np.abs(p.detach().cpu().numpy() - params[n])) / max(np.max(np.abs(params[n])), 1e-30))
+             for n, p in model.named_parameters())
+    return {"delta_loss": worst, "delta_weights": dw, "steps": steps, "batch": batch_size,
+            "against": "numpy fp32 oracle (oracle/multimodn_oracle.py), itself pinned to the reference by tests/golden"}
+
+
 def cpu_baseline(O, spec, batch_size, budget_s=15.0):
     """The numpy oracle (a port of the reference step, oracle/multimodn_oracle.py) timed on the
     host cores on a bounded sample of the same workload."""
@@ -399,6 +430,8 @@ def main():
         spec = oracle_spec(O, wl)
         out["cpu_baseline"] = cpu_baseline(O, spec, B, args.cpu_budget)
         out["cpu_baseline"]["reference_style_step"] = cpu_faithful_step(O, spec, B)
+        if not per_sample:
+            out["cpu_match"] = cpu_match(O, mm, wl, dev, B)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -192,6 +192,7 @@ def main():
                     help="testing aid: take the data-parallel code path (process group, all-reduce, separate Adam) "
                          "even with one rank")
     ap.add_argument("--no-fused-adam", action="store_true", help="keep optimizer.step() a separate k_adam launch")
+    ap.add_argument("--preroll", type=float, default=0.5, help="seconds of untimed load before the warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -335,6 +336,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed pre-roll, before the W warm-up steps the contract asks for: the GPU leaves its idle power
+    # state only after tens of milliseconds of load; without this the first timed steps of a short run
+    # execute at a fraction of the clock (measured: 76 us/step steady, up to 400 us/step averaged over a
+    # cold 200-step region).
+    t_ramp = time.perf_counter()
+    while True:
+        go = time.perf_counter() - t_ramp < args.preroll
+        if dp:                                               # every rank must run the same number of collectives:
+            flag = torch.tensor([1 if go else 0], device=dev)    # rank 0's clock decides
+            dist.broadcast(flag, src=0)
+            go = bool(flag.item())
+        if not go:
+            break
+        run_range(0, group * 8)
+        torch.cuda.synchronize()
     run_range(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -348,6 +364,20 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
+
+    # distribution of the step time: HIP events around groups of `group` steps
+    dist_us = None
+    if world == 1 and not dp:
+        samples = []
+        for rep_i in range(40):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run_range(start + rep_i * group, group)
+            e1.record()
+            torch.cuda.synchronize()
+            samples.append(e0.elapsed_time(e1) * 1e3 / group)
+        dist_us = {"median": float(np.median(samples)), "p10": float(np.percentile(samples, 10)),
+                   "p90": float(np.percentile(samples, 90)), "groups": len(samples), "steps_per_group": group}
 
     # ---- per-kernel durations with HIP events on the launch stream.  Each kernel of the step is
     # launched REP times back to back between one event pair (same stream the step uses), so the
@@ -424,6 +454,7 @@ def main():
                    "launch": f"hipGraph replay ({group} steps per graph)" if graphs is not None else "eager",
                    "samples_per_sec_per_gpu": value / world},
         "roofline": roofline,
+        "step_us_hip_events": dist_us,
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         from oracle import multimodn_oracle as O      # the CPU oracle: imported for this leg ONLY, never measured as `value`

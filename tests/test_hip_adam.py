@@ -222,3 +222,50 @@ def test_data_parallel_tail_in_one_launch_equals_two():
         assert torch.equal(outs[0][0][n], outs[1][0][n]), n
     for k in outs[0][1]:
         assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def test_graph_replayed_fused_training_step_equals_eager():
+    """bench.py's mode of operation: the whole fused step (prepare, k_fb8, k_wgrad, k_reduce + Adam)
+    captured into a hipGraph and replayed: bit-identical parameters, moments and step counts to the
+    same number of eager steps."""
+    import multimodn_amd as mm
+    spec, params, batches, m1 = _c3_like_model(mm, seed=9)
+    _, _, _, m2 = _c3_like_model(mm, seed=9)
+    xs, y = batches[0]
+    res = []
+    for model, use_graph in ((m1, True), (m2, False)):
+        model.nan_policy = "device"
+        opt = mm.optim.Adam(list(model.parameters()), 3e-3)
+        eng = model._get_engine(len(y))
+        eng.epoch_reset()
+        eng.assign_grads(None)
+        dx = [torch.from_numpy(x).cuda() for x in xs]
+        dy = torch.from_numpy(y).cuda()
+        b = eng.make_batch(dx, dy, [(i, i) for i in range(spec.E)], device_nan_flags=True)
+
+        def step():
+            assert eng.local_step(b, 1.0, 0.004, accumulate=True, optimizer=opt)
+            opt.step()
+        step()                                                   # eager: builds the optimizer's flat state
+        torch.cuda.synchronize()
+        if use_graph:
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            for _ in range(5):
+                g.replay()
+        else:
+            for _ in range(5):
+                step()
+        torch.cuda.synchronize()
+        res.append(({n: p.detach().clone() for n, p in model.named_parameters()},
+                    {n: float(opt.state[p]["step"]) for n, p in model.named_parameters()}, eng.epoch_read()))
+    for n in res[0][0]:
+        assert torch.equal(res[0][0][n], res[1][0][n]), n
+        assert res[0][1][n] == res[1][1][n] == 6.0
+    for k in res[0][2]:
+        assert np.array_equal(res[0][2][k], res[1][2][k]), k

@@ -78,8 +78,12 @@ struct WTask {
     int32_t in1_kind, k1;
     int32_t bias, ntot;
     int32_t gate;                      // exec_flags index that must be set, else slab tile = 0
-    int32_t pad;
-    int64_t slab_base, pstride;
+    int32_t w_ld;                      // row stride of the weight gradient in flat order (in_dim; decoders: S)
+    // Partial slabs are FLAT-GRADIENT shaped: partial k of a task lives at part_base + k * part_stride +
+    // (flat index of the gradient element), so k_reduce sums element i straight from its own index.
+    int64_t part_base, part_stride;    // encoders / init state: 0, nA ; decoder row r: nA*ks + r*ks*nB, nB
+    int64_t w_flat, b_flat;            // flat index (inside the region) of the weight / bias gradient tensor
+    int32_t dec_stride, pad2;          // decoder tasks: flat distance between consecutive decoders, else 0
 };
 
 struct WItem {
@@ -95,13 +99,15 @@ enum { IN_INIT = 5 };
 struct WRec {
     int64_t a_off;                      // float offset of A inside its region (dpre / dS / dz)
     int64_t in_off;                     // float offset of the In source inside its region (hid / states)
-    int64_t slab_off;                   // float offset of this item's partial output inside the slabs
+    int64_t w_off, b_off;               // float offsets of this item's partial of the weight / bias gradient (flat order)
     int32_t a_kind, lda, M, m0;
     int32_t in_kind, in_enc, ldi, ncols;
-    int32_t n0, ntot, col_off, gate;
+    int32_t n0, w_ld, col_off, gate;
     int32_t ks;
     int16_t mt, nt, has_in, bias;
     int32_t nks;                        // row-range splits of this item's task
+    int32_t dec_stride;                 // decoder tasks: row m belongs to decoder m >> 1, class m & 1
+    int32_t pad3;
 };
 struct WgArgs {
     const WRec* recs;
@@ -3095,8 +3101,8 @@ __device__ __forceinline__ void wgrad_tile(const WgArgs& w, const WRec& it, cons
     }
     __syncthreads();
     if (w.stamps && blockIdx.x == 200 && threadIdx.x == 0) w.stamps[111] = (long long)wall_clock64();
-    float* slab = w.slabs + it.slab_off;
-    const int ntot = it.ntot;
+    // flat-gradient-shaped slab: element (m, n) of this task's weight gradient at w_off + row(m) + n
+    const int w_ld = it.w_ld, ds = it.dec_stride;
     const int col_off = it.col_off;
     if (has_in) {
         constexpr int TW = 16 * NTL, TH = 16 * MT;
@@ -3105,7 +3111,8 @@ __device__ __forceinline__ void wgrad_tile(const WgArgs& w, const WRec& it, cons
             const int m = it.m0 + ml, n = it.n0 + nl;
             if (m < M && n < ncols) {
                 const clp s = sTile + ml * TILE_LD + nl;
-                g_st(slab + (int64_t)m * ntot + col_off + nl,
+                const int64_t rowf = ds ? (int64_t)(m >> 1) * ds + (int64_t)(m & 1) * w_ld : (int64_t)m * w_ld;
+                g_st(w.slabs + it.w_off + rowf + col_off + nl,
                      ((lds_ld(s) + lds_ld(s + 64 * TILE_LD)) + lds_ld(s + 2 * 64 * TILE_LD)) + lds_ld(s + 3 * 64 * TILE_LD));
             }
         }
@@ -3114,7 +3121,7 @@ __device__ __forceinline__ void wgrad_tile(const WgArgs& w, const WRec& it, cons
         for (int ml = threadIdx.x; ml < 16 * MT; ml += NT) {
             const int m = it.m0 + ml;
             if (m < M)
-                g_st(slab + (int64_t)m * ntot + (ntot - 1),
+                g_st(w.slabs + it.b_off + (ds ? (int64_t)(m >> 1) * ds + (m & 1) : (int64_t)m),
                      ((lds_ld(sBias + ml) + lds_ld(sBias + 64 + ml)) + lds_ld(sBias + 128 + ml)) + lds_ld(sBias + 192 + ml));
         }
     }
@@ -3513,6 +3520,8 @@ struct RdArgs {
     const int32_t* exec_flags; float* stats; double* epoch;
     int64_t n_grad_elems;
     int32_t n_segs, R, D, E, S, pad;
+    int64_t nA, nB;                     // gradient elements of (init state + encoders) / of the decoders
+    int32_t ksA, ksB;                   // partial slabs per element in the two regions (ks, R * ks)
 };
 
 // adam_on: optimizer.step() (multimodn.py:204) fused behind the gradient sum - the thread that has
@@ -3534,6 +3543,25 @@ __global__ __launch_bounds__(NTR) void k_reduce(const RdArgs r, const AdamArgs a
         if (adam_on) {
             const int64_t ci = mine ? idx : 0;
             pv = g_ld(ad.p + ci); mv = g_ld(ad.m + ci); vv = g_ld(ad.v + ci);
+        }
+        // ... and so do the partial sums: the slabs are flat-gradient shaped, element idx of partial k
+        // sits at region base + k * region size + idx
+        float sum = 0.f;
+        {
+            const int64_t ci = mine ? idx : 0;
+            const bool inA = ci < r.nA;
+            const float* src = inA ? r.slabs + ci : r.slabs + r.nA * r.ksA + (ci - r.nA);
+            const int64_t pstride = inA ? r.nA : r.nB;
+            const int np = inA ? r.ksA : r.ksB;
+            int k = 0;
+            for (; k + 8 <= np; k += 8) {                  // 8 independent loads in flight, fixed order
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = g_ld(src + (int64_t)(k + j) * pstride);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += v[j];
+            }
+            for (; k < np; ++k) sum += g_ld(src + (int64_t)k * pstride);
         }
         // the segment table goes to LDS once per block: no dependent global reads before the partials
         __shared__ Seg sseg[MAXSEG];
@@ -3574,26 +3602,7 @@ __global__ __launch_bounds__(NTR) void k_reduce(const RdArgs r, const AdamArgs a
         }
         const Seg sg = sseg[lo];
         const int local = (int)(idx - sg.start);
-        const int m = local / sg.kdiv, n = local - m * sg.kdiv;
-        const float* src = r.slabs + sg.slab_base + (int64_t)(sg.row_off + m) * sg.ntot + n + sg.coff;
-        float sum = 0.f;
-        int k = 0;
-        for (; k + 16 <= sg.n_partials; k += 16) {          // 16 independent loads in flight, fixed order
-            float v[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = g_ld(src + (int64_t)(k + j) * sg.pstride);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) sum += v[j];
-        }
-        for (; k + 4 <= sg.n_partials; k += 4) {
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = g_ld(src + (int64_t)(k + j) * sg.pstride);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sum += v[j];
-        }
-        for (; k < sg.n_partials; ++k) sum += g_ld(src + (int64_t)k * sg.pstride);
-        g_st(sg.dst + local, sum);
+        if (sg.dst) g_st(sg.dst + local, sum);
         if (adam_on) {
             const float ss = s_ss[lo];
             if (ss >= 0.f) {
@@ -3773,7 +3782,7 @@ struct Layout {
     std::vector<WRec> recs;         // items with their task resolved: what k_wgrad reads
     std::vector<Seg> segs;
     std::vector<PackTask> ptasks;   // dst = offset until plan creation patches in the workspace address
-    int64_t slab_floats, n_grad_elems;
+    int64_t slab_floats, n_grad_elems, nA, nB;
     int KS, max_tiles, ldS, ldH;
 };
 
@@ -3853,7 +3862,14 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     L.pack_elems = L.ptasks.back().start + (int64_t)L.ptasks.back().ntiles * L.ptasks.back().T * 256;
 
     // ---- wgrad tasks, work items, slabs, gradient segments
-    int64_t slab = 0, gstart = 0;
+    int64_t gstart = 0;
+    // flat gradient order = init state, encoders (layer by layer: weight, bias), decoders (weight, bias):
+    // region A = everything before the decoders (ks partials per element), region B = decoders (R * ks)
+    int64_t nA = S, nB = (int64_t)D * (2 * S + 2);
+    for (int e = 0; e < E; ++e)
+        for (int l = 0; l < m.enc[e].n_layers; ++l)
+            nA += (int64_t)m.enc[e].layer[l].out_dim * m.enc[e].layer[l].in_dim + m.enc[e].layer[l].out_dim;
+    L.nA = nA; L.nB = nB;
     auto add_items = [&](int task, int M, int src, int ncols, bool bias_here, int nks) {
         // tile the [M x ncols] block of one source with interleave widths matched to what is left
         for (int m0 = 0; m0 < M;) {
@@ -3871,10 +3887,8 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
             m0 += 16 * mt;
         }
     };
-    auto add_seg = [&](float* dst, int count, int64_t base, int64_t pstride, int nparts, int kdiv, int ntot,
-                       int coff, int row_off, int gate) {
-        if (!dst) return;
-        L.segs.push_back(Seg{dst, gstart, base, pstride, count, nparts, kdiv, ntot, coff, row_off, gate, 0});
+    auto add_seg = [&](float* dst, int count, int gate) {   // dst may be NULL: the tensor keeps its place, nothing is stored
+        L.segs.push_back(Seg{dst, gstart, 0, 0, count, 0, 1, 0, 0, 0, gate, 0});
         gstart += count;
     };
     // init state: column sums of dS0
@@ -3882,12 +3896,11 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
         WTask t{};
         t.a_kind = A_DS; t.a_idx = E; t.M = S;
         t.in0_kind = IN_NONE; t.in1_kind = IN_NONE; t.k0 = 0; t.k1 = 0; t.bias = 1; t.ntot = 1; t.gate = 0;
-        t.slab_base = slab; t.pstride = (int64_t)S;
+        t.part_base = 0; t.part_stride = nA; t.w_flat = 0; t.b_flat = gstart; t.w_ld = 1; t.dec_stride = 0;
         const int id = (int)L.tasks.size();
         L.tasks.push_back(t);
         add_items(id, S, 2, 0, true, ks);
-        add_seg(m.g_init_state, S, slab, t.pstride, ks, 1, 1, 0, 0, 0);
-        slab += (int64_t)ks * t.pstride;
+        add_seg(m.g_init_state, S, 0);
     }
     for (int e = 0; e < E; ++e) {
         const mmn_encoder& enc = m.enc[e];
@@ -3904,40 +3917,38 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
             t.in1_kind = last ? IN_PREV_STATE : IN_NONE;
             t.k1 = last ? S : 0;
             t.bias = 1; t.ntot = lin.in_dim + 1; t.gate = e + 1;
-            t.slab_base = slab; t.pstride = (int64_t)t.M * t.ntot;
+            t.part_base = 0; t.part_stride = nA; t.w_ld = lin.in_dim; t.dec_stride = 0;
+            t.w_flat = gstart; t.b_flat = gstart + (int64_t)lin.out_dim * lin.in_dim;
             const int id = (int)L.tasks.size();
             L.tasks.push_back(t);
-            // (per-task split counts are supported; doubling them for the big state-update tiles was
-            // measured slower: every extra work item costs ~5 us of fixed prologue/epilogue)
-            const int kst = ks;
-            add_items(id, t.M, 0, t.k0, true, kst);
-            if (last) add_items(id, t.M, 1, t.k1, false, kst);
-            add_seg(lin.gw, lin.out_dim * lin.in_dim, slab, t.pstride, kst, lin.in_dim, t.ntot, 0, 0, e + 1);
-            add_seg(lin.gb, lin.out_dim, slab, t.pstride, kst, 1, t.ntot, lin.in_dim, 0, e + 1);
-            slab += (int64_t)kst * t.pstride;
+            // (doubling the row-range splits for the big state-update tiles was measured slower: every
+            // extra work item costs ~5 us of fixed prologue/epilogue)
+            add_items(id, t.M, 0, t.k0, true, ks);
+            if (last) add_items(id, t.M, 1, t.k1, false, ks);
+            add_seg(lin.gw, lin.out_dim * lin.in_dim, e + 1);
+            add_seg(lin.gb, lin.out_dim, e + 1);
         }
     }
     // decoders: one task per grid row, all rows share one output of [2D x (S+1)] x (R*ks) partials
     {
-        const int64_t pstride = (int64_t)(2 * D) * (S + 1);
-        const int64_t base = slab;
         for (int r = 0; r < R; ++r) {
             WTask t{};
             t.a_kind = A_DZ; t.a_idx = r; t.M = 2 * D;
             t.in0_kind = IN_STATE_ROW; t.in0_idx = r; t.k0 = S; t.in1_kind = IN_NONE; t.k1 = 0;
             t.bias = 1; t.ntot = S + 1; t.gate = r;
-            t.slab_base = base + (int64_t)r * ks * pstride; t.pstride = pstride;
+            // region B: decoder d's weight [2 x S] at d * (2S + 2), its bias [2] right behind
+            t.part_base = nA * ks + (int64_t)r * ks * nB; t.part_stride = nB;
+            t.w_flat = 0; t.b_flat = 2 * S; t.w_ld = S; t.dec_stride = 2 * S + 2;
             const int id = (int)L.tasks.size();
             L.tasks.push_back(t);
             add_items(id, t.M, 0, S, true, ks);
         }
         for (int d = 0; d < D; ++d) {
-            add_seg(m.dec[d].gw, 2 * S, base, pstride, R * ks, S, S + 1, 0, 2 * d, 0);
-            add_seg(m.dec[d].gb, 2, base, pstride, R * ks, 1, S + 1, S, 2 * d, 0);
+            add_seg(m.dec[d].gw, 2 * S, 0);
+            add_seg(m.dec[d].gb, 2, 0);
         }
-        slab += (int64_t)R * ks * pstride;
     }
-    L.slab_floats = slab;
+    L.slab_floats = nA * ks + nB * (int64_t)R * ks;
     L.n_grad_elems = gstart;
     // Launch order of the work items.  One workgroup per item; the dispatcher fills the 256 CUs
     // round-robin, so items beyond the first 256 double up on the CUs that got the first ones.  Put
@@ -3977,10 +3988,11 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
             if (t.in0_idx == 0) r.in_kind = IN_INIT;
             else { r.in_off = (int64_t)(t.in0_idx - 1) * maxB * S; r.ldi = S; }
         }
-        r.ntot = t.ntot;
+        r.w_ld = t.w_ld; r.dec_stride = t.dec_stride;
         r.col_off = (it.src == 1 ? t.k0 : 0) + it.n0;
         r.gate = t.gate;
-        r.slab_off = t.slab_base + (int64_t)it.ks * t.pstride;
+        r.w_off = t.part_base + (int64_t)it.ks * t.part_stride + t.w_flat;
+        r.b_off = t.part_base + (int64_t)it.ks * t.part_stride + t.b_flat;
         r.nks = it.nks;
         L.recs.push_back(r);
     }
@@ -4120,7 +4132,7 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     pl->dev = reinterpret_cast<DevPlan*>(ws + L.off_plan);
     pl->wg = WgArgs{h.recs, h.dpre, h.dS, h.dz, h.states, h.hid, m->init_state, h.slabs, h.stamps, h.sin, h.maxB, h.S};
     pl->rd = RdArgs{h.segs, h.slabs, h.lossp, h.scp, h.cnt, h.exec_flags, h.stats, h.epoch, L.n_grad_elems,
-                    (int32_t)L.segs.size(), h.R, h.D, h.E, h.S, 0};
+                    (int32_t)L.segs.size(), h.R, h.D, h.E, h.S, 0, L.nA, L.nB, h.KS, h.R * h.KS};
     pl->segs = L.segs;
     pl->ps_scratch = reinterpret_cast<int32_t*>(ws + L.off_ps);
     pl->adam_ok_seg_start = nullptr; pl->adam_ok_grads = nullptr;

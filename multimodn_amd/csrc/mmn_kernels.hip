@@ -2577,8 +2577,6 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
             ub[pr][1] = g_ld(pe.bias[Lh] + min(nn[1] + i, S - 1));
         }
     }
-    issue_fwd(wsA, 0);
-    issue_fwd(wsB, 1);
 
     // ---- phase A: u_e = W_x h_e + b of this pair's encoder
     if (Lmax >= 1) {                                       // hidden layer 0 (mlp_encoder.py:75-76), tile = half
@@ -2619,6 +2617,10 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
             wave_store_tile(a.hid + pe.hid[1] + (int64_t)(row0 + r0) * N, sHg[1] + r0 * ldH, ldH, nr, N);
         }
     }
+    // the first two chain steps' weights are asked for here: they stream in underneath the u_e GEMM
+    // instead of queueing in front of the hidden layers
+    issue_fwd(wsA, 0);
+    issue_fwd(wsB, 1);
     if (act) {                                             // u_e = W_x h + b (mlp_encoder.py:78), this half's 4 tiles
         clp in = Lh == 0 ? (clp)sXg : (clp)sHg[Lh - 1];
         const int ldin = Lh == 0 ? ldX : ldH;

@@ -123,8 +123,8 @@ typedef struct mmn_batch {
      * list; a missing modality is simply absent from the list).  Then: batch = 16 * number of tiles,
      * batch_global = the true number of samples, data slot k holds encoder k's features
      * (seq_data[t] = seq_enc[t] = t, n_seq = n_encoders), every feature value is finite (missing
-     * entries zeroed), nan_flags = NULL.  Training steps only, fused-kernel shapes only
-     * (MMN_ERR_UNSUPPORTED otherwise). */
+     * entries zeroed), nan_flags = NULL.  mmn_train_step / mmn_train_step_adam / mmn_eval_step,
+     * fused-kernel shapes only (MMN_ERR_UNSUPPORTED otherwise). */
     const int32_t* tile_rows;
     const int32_t* tile_seq;
 } mmn_batch;
@@ -287,6 +287,7 @@ int mmn_epoch_read(mmn_plan* p, double* out_host, void* stream);
  *   kind 2, index e         : dS of encoder e [batch x S] (e = n_encoders -> dS0), training only
  *   kind 3                  : diagnostic timestamps (MMN_STAMPS=1)
  *   kind 4                  : int32[E+1] "state row exists" flags of the last step (row 0 always 1)
+ *   kind 5                  : int32[rows] of the last mmn_regroup: source row of every position, -1 = padding
  * Rows of encoders that did not run hold stale data.  Returns NULL if out of range. */
 const float* mmn_debug_buffer(mmn_plan* p, int kind, int index);
 

@@ -2788,6 +2788,7 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
             f32x2 dzv;
             dzv.x = cL * g0 * o0 * (1.0f - o0);
             dzv.y = cL * g1 * o1 * (1.0f - o1);
+            if (tiled && cL < 0.f) { dzv.x = o0; dzv.y = o1; }   // forward-only (per-sample eval): the decoder OUTPUTS
             g_st2(a.dz + ((int64_t)r * a.maxB + grow) * (2 * D) + 2 * d, dzv);
             lds_st(sDzA + (r * TB + row) * LDZ + 2 * d, dzv.x);
             lds_st(sDzA + (r * TB + row) * LDZ + 2 * d + 1, dzv.y);
@@ -2821,6 +2822,7 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
     __syncthreads();                                        // dz tiles complete; u_e tiles dead
     STAMP8();
 
+    if (tiled && cL < 0.f) return;                          // forward-only step of per-sample mode (mmn_eval_step)
     // ======================= backward half =======================
     const lp DG = smem + L.sU;                              // R tiles: decoder grad -> G_out, in place
     // ---- phase A': DG[r] = dz[r] Wdec + cS (s_r - s_prev(r)) - cS (s_next(r) - s_r): the decoder
@@ -4545,6 +4547,14 @@ int mmn_regroup(mmn_plan* p, const mmn_batch* in, const int64_t* seq, mmn_batch*
 int mmn_eval_step(mmn_plan* p, const mmn_batch* b, int accumulate_epoch, void* stream) {
     int rc = mmn_prepare(p, b, 0, stream);
     if (rc != MMN_OK) return rc;
+    if (b->tile_seq) {                                     // per-sample mode: the fused kernel, forward half only
+        const int tiles = b->batch / 16;
+        mmn_batch bb = *b;
+        hipLaunchKernelGGL(k_fb8<true>, dim3(tiles), dim3(NT8), p->fb8_lds_bytes, static_cast<hipStream_t>(stream), p->pa, bb,
+                           -1.0f, 0.0f);
+        HIP_TRY(hipGetLastError());
+        return launch_reduce(p, b, 0, accumulate_epoch, 1.0f, 0.0f, stream);
+    }
     if ((rc = mmn_chain_fwd(p, b, 1.0f, 0.0f, 0, stream)) != MMN_OK) return rc;
     return launch_reduce(p, b, 0, accumulate_epoch, 1.0f, 0.0f, stream);
 }
@@ -4600,6 +4610,7 @@ const float* mmn_debug_buffer(mmn_plan* p, int kind, int index) {
         case 2: return (index >= 0 && index <= h.E) ? h.dS + (int64_t)index * h.maxB * h.S : nullptr;
         case 3: return reinterpret_cast<const float*>(h.stamps);
         case 4: return reinterpret_cast<const float*>(h.exec_flags);
+        case 5: return reinterpret_cast<const float*>(p->ps_scratch + 2 * (size_t)p->max_batch);   // mmn_regroup: source row of every position
         default: return nullptr;
     }
 }

@@ -267,6 +267,7 @@ class HipChainEngine:
             sq = None if seq is None else seq.to(dev, torch.int64).contiguous()
             hip.check(self.lib.mmn_regroup(self._plan, C.byref(bin_), None if sq is None else sq.data_ptr(),
                                            C.byref(bout), self._stream()), "mmn_regroup")
+            self._ps_layout = ("hip", rows, B, tile_seq)
             return bout, (xs_p, y_p, tile_rows, tile_seq, sq, xs, y)
         present = torch.stack([~torch.isnan(x).any(dim=1) for x in xs], dim=1)           # [B, E] slot present
         enc_of = seq.to(dev, torch.int64) if seq is not None else torch.arange(E, device=dev).expand(B, E)
@@ -303,7 +304,24 @@ class HipChainEngine:
         tile_seq.index_copy_(0, where // 16, scode.to(torch.int32))
         b = self.make_batch(xs_p, y_p, [(k, k) for k in range(E)], batch_global=B)
         b.tile_rows, b.tile_seq = tile_rows.data_ptr(), tile_seq.data_ptr()
+        self._ps_layout = ("torch", where, B, tile_seq)
         return b, (xs_p, y_p, tile_rows, tile_seq)
+
+    def per_sample_positions(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """For the last per_sample_batch: (position of every original row in the regrouped layout
+        [B] int64, packed executed sequence of every original row [B] int64)."""
+        kind, info, B, tile_seq = self._ps_layout
+        if kind == "torch":
+            where = info
+        else:                                               # k_ps_layout's source-row table lives in the plan's scratch
+            rows = info
+            ptr = self.lib.mmn_debug_buffer(self._plan, 5, 0)
+            off = ptr - self.workspace.data_ptr()
+            src_of = self.workspace[off:off + 4 * rows].view(torch.int32).to(torch.int64)
+            pos = torch.nonzero(src_of >= 0).flatten()
+            where = torch.empty(B, dtype=torch.int64, device=self.device)
+            where[src_of[pos]] = pos
+        return where, tile_seq.to(torch.int64)[where // 16]
 
     def eval_step(self, b: hip.Batch, accumulate: bool = False) -> None:
         hip.check(self.lib.mmn_eval_step(self._plan, C.byref(b), 1 if accumulate else 0, self._stream()), "mmn_eval_step")

@@ -254,7 +254,7 @@ class MultiModN(nn.Module):
                 eng.accumulate(float(self.err_penalty) if train else 1.0, float(self.state_change_penalty) if train else 0.0)
         return executed, (xs, y)
 
-    def _run_step_per_sample(self, eng, data, target, encoder_sequence, optimizer=None):
+    def _run_step_per_sample(self, eng, data, target, encoder_sequence, optimizer=None, train: bool = True):
         """One training step in per-sample mode: rows are regrouped on the device into tiles of one
         executed sequence each (engine.per_sample_batch) and run by the fused kernel."""
         if not isinstance(target, Tensor):
@@ -277,6 +277,13 @@ class MultiModN(nn.Module):
         dp = self._dp_group is not None
         b, keep = eng.per_sample_batch(xs, y, seq)
         b.batch_global = B * self._dp_world
+        if not train:                                       # forward-only (test / predict / get_states)
+            eng.eval_step(b, accumulate=not dp)
+            if dp:
+                import torch.distributed as dist
+                dist.all_reduce(eng.stats, group=self._dp_group)
+                eng.accumulate(1.0, 0.0)
+            return None, (xs, y, keep)
         fuse = optimizer if (not dp and hasattr(optimizer, "fused_descriptor")) else None
         eng.local_step(b, float(self.err_penalty), float(self.state_change_penalty), accumulate=not dp, optimizer=fuse)
         if dp:
@@ -384,10 +391,21 @@ class MultiModN(nn.Module):
                 eng.epoch_reset()
             else:
                 eng.ensure(int(target.shape[0]))
+            last = len(self.encoders) - 1
+            if self.per_sample:
+                _, keep = self._run_step_per_sample(eng, data, target, encoder_sequence, train=False)
+                where, codes = eng.per_sample_positions()
+                has_last = torch.zeros_like(codes, dtype=torch.bool)
+                for j in range(len(self.encoders)):
+                    has_last |= ((codes >> (4 * j)) & 15) == last + 1
+                rows_l = torch.nonzero(has_last).flatten()       # samples whose LAST encoder ran (multimodn.py:354-357)
+                targets_epoch.append(keep[1].detach()[rows_l].to("cpu"))
+                bp = int(keep[2][1].shape[0])
+                outputs_epoch.append(eng.decoder_outputs(last + 1, bp)[where[rows_l]].clone())
+                continue
             executed, keep = self._run_step(eng, data, target, encoder_sequence, train=False)
             if executed is None:                               # device NaN policy: ask the GPU which rows exist
                 executed = eng.executed_rows()[1:]
-            last = len(self.encoders) - 1
             targets_epoch.append(keep[1].detach().to("cpu"))
             if executed[last]:                                  # multimodn.py:354-357: only the LAST encoder's row
                 outputs_epoch.append(eng.decoder_outputs(last + 1, int(keep[1].shape[0])).clone())
@@ -424,6 +442,22 @@ class MultiModN(nn.Module):
         full = np.zeros((len(self.encoders) + 1, len(self.decoders), n_samples))
         if n_samples == 0:
             return full
+        if self.per_sample:                                    # every sample its own order / missing modalities (skipped)
+            eng = self._get_engine(n_samples)
+            dummy = torch.zeros((n_samples, len(self.decoders)), dtype=torch.int64)
+            _, keep = self._run_step_per_sample(eng, x, dummy, encoder_sequence, train=False)
+            where, codes = eng.per_sample_positions()
+            bp = int(keep[2][1].shape[0])
+            for row in range(len(self.encoders) + 1):
+                o = eng.decoder_outputs(row, bp)[where]
+                pred = (o[:, 1::2] > o[:, 0::2]).to(torch.float64)
+                if row > 0:
+                    has = torch.zeros_like(codes, dtype=torch.bool)
+                    for j in range(len(self.encoders)):
+                        has |= ((codes >> (4 * j)) & 15) == row
+                    pred = pred * has.unsqueeze(1)
+                full[row] = pred.t().cpu().numpy()
+            return full
         seq = None if encoder_sequence is None else np.asarray(encoder_sequence)
         pairs = self.get_encoder_iterable(seq, self.shuffle_mode, train=False)
         eng = self._get_engine(n_samples)
@@ -448,6 +482,21 @@ class MultiModN(nn.Module):
             n = int(data[0].shape[0])
             eng = self._get_engine(n)
             dummy = torch.zeros((n, len(self.decoders)), dtype=torch.int64)
+            if self.per_sample:
+                _, keep = self._run_step_per_sample(eng, data, dummy, encoder_sequence, train=False)
+                where, codes = eng.per_sample_positions()
+                bp = int(keep[2][1].shape[0])
+                state = self.init_state(n).detach().to(self.device)
+                last_e = torch.full_like(codes, -1)
+                for j in range(len(self.encoders)):                # the last non-zero nibble = last executed encoder
+                    nib = (codes >> (4 * j)) & 15
+                    last_e = torch.where(nib > 0, nib - 1, last_e)
+                for e in range(len(self.encoders)):
+                    sel = torch.nonzero(last_e == e).flatten()
+                    if sel.numel():
+                        state[sel] = eng.state_rows(e, bp)[where[sel]]
+                batch_states.append(state)
+                continue
             pairs = self.get_encoder_iterable(encoder_sequence, self.shuffle_mode, train=False)
             xs, y, exec_pairs, executed = self._ingest(data, dummy, pairs)
             b = eng.make_batch(xs, y, exec_pairs, batch_global=n, device_nan_flags=executed is None)

@@ -563,6 +563,46 @@ def per_sample_step(params, spec: ModelSpec, xs, y, sequences, dtype=np.float32)
     return acc
 
 
+def per_sample_eval(params, spec: ModelSpec, xs, y, sequences, dtype=np.float32):
+    """Forward-only counterpart of per_sample_step: every sample is the reference's batch-size-1
+    forward (test() / predict() / get_states(), multimodn.py:255-492, with the NaN skip of :327).
+    Returns (StepResult summed over samples with row_counts, predictions [(E+1), D, N] (0 where the row
+    does not exist for the sample), final states [N, S], last-row outputs [(N_last, D, 2)], index of the
+    samples whose LAST encoder ran)."""
+    B = np.asarray(y).shape[0]
+    E, D = spec.E, spec.D
+    eval_spec = ModelSpec(spec.state_size, spec.encoders, spec.D, 1.0, 0.0)
+    acc = None
+    counts = np.zeros(E + 1, np.int64); counts[0] = B
+    preds = np.zeros((E + 1, D, B))
+    states = np.zeros((B, spec.state_size), np.dtype(dtype))
+    last_out, last_idx = [], []
+    for b in range(B):
+        xb = [np.asarray(x)[b:b + 1] for x in xs]
+        sb = None if sequences is None else np.asarray(sequences)[b:b + 1]
+        r = forward_backward(params, eval_spec, xb, np.asarray(y)[b:b + 1], sb, batch_global=B, dtype=dtype,
+                             want_grads=False, keep_states=True)
+        counts[1:] += r.executed.astype(np.int64)
+        last = 0
+        for _, e in encoder_iterable(E, sb):
+            if r.executed[e]:
+                last = e + 1
+        states[b] = r.states[last][0]
+        for row, st in r.states.items():
+            o = decoder_outputs(params, spec, st, dtype)
+            preds[row, :, b] = (o[0, :, 1] > o[0, :, 0])
+            if row == E:
+                last_out.append(o[0]); last_idx.append(b)
+        if acc is None:
+            acc = r
+        else:
+            acc.err_loss = acc.err_loss + r.err_loss
+            acc.n_correct += r.n_correct; acc.tp += r.tp; acc.tn += r.tn; acc.fp += r.fp; acc.fn += r.fn
+            acc.executed |= r.executed
+    acc.row_counts = counts
+    return acc, preds, states, (np.stack(last_out) if last_out else np.zeros((0, D, 2))), np.array(last_idx, np.int64)
+
+
 def synthetic_batches(spec: ModelSpec, n_rows: int, batch_size: int, seed: int,
                       learnable: bool = True):
     """SURVEY 8d generator: standard-normal float32 features, binary int64 targets (either

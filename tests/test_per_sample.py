@@ -157,3 +157,31 @@ def test_c5_full_size_against_oracle():
     assert np.array_equal(stats["rows"].astype(np.int64), ref.row_counts)
     for n, g in ref64.grads.items():
         assert rel_err(grads[n].reshape(g.shape), g) < 2e-5, (n, rel_err(grads[n].reshape(g.shape), g))
+
+
+@pytest.mark.gpu
+def test_per_sample_forward_only_entry_points():
+    """test() / predict() / get_states() in per-sample mode against the per-sample loop of the oracle."""
+    mm.hip.load()
+    spec, xs, y, seq = c5_like(150, E=4, seed=21)
+    params = O.init_params(spec, 8)
+    model = build_torch_model(spec, params, "cuda", mm)
+    model.per_sample = True
+    ref, preds, states, last_out, last_idx = O.per_sample_eval(params, spec, xs, y, seq)
+    loader = [([torch.from_numpy(x) for x in xs], torch.from_numpy(y), torch.from_numpy(seq))]
+    hist = mm.MultiModNHistory(["a", "b"])
+    results = model.test(loader, torch.nn.CrossEntropyLoss(), hist, tag="val")
+    ep = O.aggregate_epoch(spec.E, spec.D, [ref], [150])
+    assert rel_err(hist.loss["val"][0], ep.loss) < 1e-5
+    assert np.array_equal(hist.accuracy["val"][0], ep.accuracy)
+    assert np.array_equal(hist.balanced_accuracy["val"][0], ep.balanced_accuracy)
+    # report of the decoders on the last encoder's state, over the samples that have it
+    for d in range(spec.D):
+        p = last_out[:, d, :] / last_out[:, d, :].sum(axis=1, keepdims=True)
+        want = O.performance_metrics(y[last_idx, d], (p[:, 1] > p[:, 0]).astype(np.int64), p[:, 1])
+        got = dict(zip(mm.metrics.performance_metrics, results[d]))
+        assert abs(int(got["tp"]) - want["tp"]) <= 1 and abs(float(got["auc"]) - want["auc"]) < 2e-3
+    got_states = torch.stack(model.get_states(loader)).cpu().numpy()
+    assert rel_err(got_states, states) < 1e-5
+    got_pred = model.predict([torch.from_numpy(x) for x in xs], torch.from_numpy(seq))
+    assert got_pred.shape == preds.shape and (got_pred != preds).mean() < 2e-3

@@ -378,3 +378,37 @@ def test_integration_md_stub_runs(lib):
     assert rel_err(stats[:15].reshape(5, 3), ref.err_loss) < 1e-5
     for n, p in model.named_parameters():
         assert rel_err(p.grad.cpu().numpy().reshape(ref.grads[n].shape), ref.grads[n]) < 2e-5, n
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_random_shapes_against_oracle(lib, seed):
+    """Seeded sweep over model shapes and batch sizes: whatever kernel tier the library picks for the
+    shape (fused / 8-wave / 4-wave parallel / sequential) must reproduce the oracle's step."""
+    rng = np.random.default_rng(1000 + seed)
+    E = int(rng.integers(1, 9))
+    S = int(rng.choice([4, 8, 12, 16, 32, 48, 64, 100, 128]))
+    D = int(rng.integers(1, 5))
+    B = int(rng.choice([1, 7, 16, 33, 100, 257]))
+    hid_choices = [(), (8,), (16, 16), (32,), (5, 5), (32, 32), (7,), (24, 8)]
+    encs = []
+    for _ in range(E):
+        H = hid_choices[int(rng.integers(0, len(hid_choices)))]
+        act = int(rng.choice([O.ACT_RELU, O.ACT_SIGMOID])) if H else O.ACT_IDENTITY
+        encs.append(O.EncoderSpec(int(rng.choice([1, 3, 4, 6, 16, 33, 64, 100])), H, act))
+    spec = O.ModelSpec(S, encs, D, float(rng.choice([0.7, 1.0])), float(rng.choice([0.0, 0.3, 1.0])))
+    params = O.init_params(spec, seed)
+    xs, y = O.synthetic_batches(spec, B, B, seed=seed + 5)[0]
+    order = rng.permutation(E)
+    batch = ([xs[e] for e in order], y, np.tile(order.astype(np.int64), (B, 1)))
+    model = build_torch_model(spec, params, "cuda", lib)
+    stats, grads, _ = run_step(model, batch)
+    ref = O.forward_backward(params, spec, batch[0], batch[1], batch[2])
+    # (a gradient can be a near-total cancellation of per-sample terms ~1e-3: the fp32 noise of that sum,
+    #  ~1e-8 absolute, does not shrink with the result - hence the absolute floor next to 3e-5 of max|g|)
+    assert rel_err(stats["loss"], ref.loss) < 1e-5
+    assert rel_err(stats["err_loss"], ref.err_loss) < 1e-5
+    for k in ("n_correct", "tp", "tn", "fp", "fn"):
+        assert np.array_equal(stats[k].astype(np.int64), getattr(ref, k)), k
+    for n, g in ref.grads.items():
+        got = grads[n].reshape(g.shape)
+        assert np.abs(got - g).max() <= 3e-5 * np.abs(g).max() + 2e-8, (n, np.abs(got - g).max(), np.abs(g).max())

@@ -2,15 +2,13 @@
 import os, sys
 os.environ["MMN_STAMPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import multimodn_amd as mm
-from helpers import build_torch_model
-from oracle import multimodn_oracle as O
-spec = O.ModelSpec(128, [O.EncoderSpec(64, (32, 32), O.ACT_RELU) for _ in range(4)], 3, 1.0, 0.3)
-model = build_torch_model(spec, O.init_params(spec, 0), "cuda", mm)
+import bench                                   # the workload definition and synthetic generator of bench.py
+wl = bench.WORKLOADS["c3"]
+model = bench.build_model(mm, wl, torch.device("cuda"))
 model.nan_policy = "device"
-xs, y = O.synthetic_batches(spec, 4096, 4096, seed=1)[0]
+xs, y = bench.synthetic_batches(wl, 4096, 4096, seed=1)[0]
 eng = model._get_engine(4096)
 dx = [torch.from_numpy(x).cuda() for x in xs]; dy = torch.from_numpy(y).cuda()
 b = eng.make_batch(dx, dy, [(i, i) for i in range(4)], device_nan_flags=True)

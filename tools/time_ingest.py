@@ -1,23 +1,21 @@
 """Diagnostic: where the host-batch path of train_epoch spends its time (C3 shape, host tensors)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import multimodn_amd as mm
-from helpers import build_torch_model
-from oracle import multimodn_oracle as O
+import bench
 nt = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 if nt:
     torch.set_num_threads(nt)
 print("torch threads", torch.get_num_threads())
-spec = O.ModelSpec(128, [O.EncoderSpec(64, (32, 32), O.ACT_RELU) for _ in range(4)], 3, 1.0, 0.3)
+wl = bench.WORKLOADS["c3"]
 B, NB = 4096, 32
-host = O.synthetic_batches(spec, B * NB, B, seed=1)
+host = bench.synthetic_batches(wl, B * NB, B, seed=1)
 loader = [([torch.from_numpy(x) for x in xs], torch.from_numpy(y)) for xs, y in host]
 crit = torch.nn.CrossEntropyLoss()
 for policy in ("host", "device"):
     for staged in (True, False):
-        model = build_torch_model(spec, O.init_params(spec, 0), "cuda", mm)
+        model = bench.build_model(mm, wl, torch.device("cuda"))
         model.nan_policy = policy
         if not staged:
             class NoStage:

@@ -2,21 +2,19 @@
 for host-resident and device-resident batches and both NaN policies."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import multimodn_amd as mm
-from helpers import build_torch_model
-from oracle import multimodn_oracle as O
+import bench
 
-spec = O.ModelSpec(128, [O.EncoderSpec(64, (32, 32), O.ACT_RELU) for _ in range(4)], 3, 1.0, 0.3)
+wl = bench.WORKLOADS["c3"]
 B, NB = 4096, 64
-host = O.synthetic_batches(spec, B * NB, B, seed=1)
+host = bench.synthetic_batches(wl, B * NB, B, seed=1)
 crit = torch.nn.CrossEntropyLoss()
 for where in ("cpu", "cuda"):
     loader = [([torch.from_numpy(x).to(where) for x in xs], torch.from_numpy(y).to(where)) for xs, y in host]
     for policy in ("host", "device"):
         for optname in ("torch", "hip"):
-            model = build_torch_model(spec, O.init_params(spec, 0), "cuda", mm)
+            model = bench.build_model(mm, wl, torch.device("cuda"))
             model.nan_policy = policy
             opt = (torch.optim.Adam if optname == "torch" else mm.optim.Adam)(list(model.parameters()), 1e-3)
             hist = mm.MultiModNHistory(["a", "b", "c"])

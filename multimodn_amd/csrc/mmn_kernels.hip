@@ -3,36 +3,50 @@
 // (v_mfma_f32_16x16x4_f32: bit-exact fp32 FMA chains, so fp32 parity with the reference's ATen
 // path holds up to summation order).  No CUDA names, no dual paths.
 //
-// Launch structure of one training step (reference: multimodn/multimodn.py:137-203):
-//   k_prepare          any(isnan(x_k)) per data slot (:168) + repack of every weight matrix the two
+// Launch structure of one training step (reference: multimodn/multimodn.py:137-204):
+//   k_prepare          any(isnan(x_k)) per data slot (:168) + repack of every weight matrix the
 //                      chain kernels multiply by into MFMA-fragment order (forward W, backward W^T)
-//   k_chain_fwd        row-tile parallel: init broadcast, every encoder, state-change partials,
-//                      all D decoders on all E+1 states, CE-over-sigmoid, argmax, confusion counts
-//   k_chain_bwd        row-tile parallel reverse chain: grads wrt states / pre-activations
-//   k_wgrad            grouped split-K "A^T B" GEMM: weight, bias and init-state grads as slabs
-//   k_reduce           fixed-order slab reduction -> grads; tile partials -> stats block
-//                      (+ loss combination and epoch accumulators, :194-212, when single-GPU)
+//   k_fb8<TILED>       FUSED forward + reverse chain of one 16-row tile, 8 waves (shapes like the
+//                      MIMIC config, E <= 4): init broadcast, hidden MLPs, state updates, state-change
+//                      partials, all D decoders on all E+1 states, CE-over-sigmoid, argmax, confusion
+//                      counts, then grads wrt states / pre-activations; TILED = per-sample mode
+//     k_fwd8 + k_bwd8  the same math as two 8-wave kernels (E <= 8; also the forward-only path)
+//     k_chain_*_par    4-wave parallel-phase kernels (dims that fit LDS)
+//     k_chain_fwd/bwd  sequential form, any shape, 16- or 32-row tiles
+//   k_wgrad            grouped split-K "A^T B" GEMM: weight, bias and init-state grads as
+//                      flat-gradient-shaped partial slabs
+//   k_reduce           fixed-order slab reduction -> grads (+ Adam on the element just summed, :204);
+//                      tile partials -> stats block (+ loss combination and epoch accumulators, :194-212)
+//   k_adam / k_adam_accumulate   optimizer.step() over the flat buffers as its own launch
+//                      (data parallel: after the all-reduce, together with the epoch accumulation)
+//   k_ps_code / k_ps_layout / k_ps_gather   per-sample mode: regrouping of the rows into tiles of one
+//                      executed sequence (mmn_regroup)
+// File order: plan structs and device helpers; k_prepare; sequential chain kernels; 4-wave parallel
+// kernels; 8-wave kernels (k_fwd8, k_bwd8, k_fb8); k_wgrad; k_ps_*; k_adam; k_reduce; host side
+// (layout, plan, C ABI).
 //
 // Data layout in HBM (all fp32 row-major, B = batch rows):
 //   states[e][B][S]     output state of encoder e          hid[e][l][B][H_l]  hidden activations
 //   dz[r][B][2D]        d loss / d decoder logits, row r   dS[e][B][S]        d loss / d state_e (+dS0)
 //   dpre[e][l][B][H_l]  d loss / d hidden pre-activation   slabs              split-K partial grads
+//   sin[e][B][S]        per-sample mode: state that fed encoder e
 //   pack                weights in fragment order: [col tile][k-step][lane][4] (zero padded)
 //
-// Tiling.  A workgroup (256 threads = 4 waves) owns 16*RT batch rows (RT = 1 or 2); the state tile
-// stays in LDS for the whole chain.  Every product is "tile[rows x K] x W'[N x K]^T" with the
+// Tiling.  A workgroup owns 16 batch rows (32 in the sequential tier's RT = 2 form); the state tiles
+// stay in LDS for the whole chain.  Every product is "tile[rows x K] x W'[N x K]^T" with the
 // ACTIVATION tile in LDS and the WEIGHT fragments loaded straight from L2 into registers (each
 // weight element is used by exactly one wave of the workgroup, so an LDS round trip would be pure
-// overhead).  Wave w owns output column tiles {w, w+4} of every group of 8; the contraction is
-// walked 16 at a time: one 16-byte fragment per operand feeds four MFMAs.
+// overhead).  The contraction is walked 16 at a time: one 16-byte fragment per operand feeds four
+// MFMAs.
 //
-// What bounds the chain kernels is not the MFMAs (~5 us per direction at B = 4096) but (a) the
-// number of DEPENDENT global round trips (~0.7 us each on a busy chip) and (b) the rate at which
-// one CU can pull the weights through its L1: every workgroup needs ALL weights (383 KB at the
-// MIMIC shape).  Hence: the plan is copied to LDS once; weights are read from a per-step repack in
-// which one wave-level load is 1 KB contiguous (a row-major fragment touches 16 half cache lines
-// and measured ~12 GB/s per CU); and the forward kernel requests the NEXT encoder's x tile, weight
-// fragments and biases while the current state is being stored and decoded.
+// What bounds the chain kernels is not the MFMAs (~12 us for both directions at B = 4096) but (a) the
+// number of DEPENDENT global round trips (~0.7-2.5 us each on a busy chip), (b) the rate at which one
+// CU can pull the weights through its vector-memory pipe: every workgroup needs ALL weights (~700 KB
+// of fragments over both directions at the MIMIC shape), and (c) hipcc's wait counters: a branch
+// around a load makes it drain the whole queue at the next use.  Hence: descriptors in kernel
+// arguments; weights read from a per-step repack in which one wave-level load is 1 KB contiguous (a
+// row-major fragment touches 16 half cache lines and measured ~12 GB/s per CU); every request
+// unconditional and issued well ahead of its use.  DESIGN.md section 3 has the measurements.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -24,10 +24,13 @@ Parameter naming follows the reference `state_dict()` keys:
     init_state.state_value                 [1, S]        (state.py:25-27)
     encoders.{e}.layers.{l}.weight / .bias               (mlp_encoder.py:64-72)
     decoders.{d}.fc.weight / .bias         [2, S] / [2]  (decoders.py:16)
+MIMIC family: MIMIC_MLPEncoder (mlp_encoder.py:9-47) keeps an nn.Dropout at
+layers.0, so its Linear l is `encoders.{e}.layers.{l+1}`; MLPDecoder (decoders.py:22-46) names
+its Linears `decoders.{d}.layers.{l}`.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass, field, replace
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -43,8 +46,19 @@ class EncoderSpec:
     n_features: int
     hidden: Tuple[int, ...] = ()
     activation: int = ACT_RELU
+    # "mlp": MLPEncoder.  "mimic": MIMIC_MLPEncoder (mlp_encoder.py:9-47): Dropout(p) on
+    # cat([x, state]) feeds the FIRST Linear, the activation follows EVERY Linear incl. the last.
+    kind: str = "mlp"
+    dropout: float = 0.0
+
+    def layer_key(self, l: int) -> int:
+        """Index of Linear l inside the module's `layers` list (state_dict key)."""
+        return l + 1 if self.kind == "mimic" else l
 
     def layer_shapes(self, state_size: int) -> List[Tuple[int, int]]:
+        if self.kind == "mimic":                # mlp_encoder.py:24-29
+            dims = [self.n_features + state_size] + list(self.hidden) + [state_size]
+            return [(dout, din) for din, dout in zip(dims, dims[1:])]
         dims = [self.n_features] + list(self.hidden) + [state_size]
         shapes = []
         for i, (din, dout) in enumerate(zip(dims, dims[1:])):
@@ -56,12 +70,35 @@ class EncoderSpec:
 
 
 @dataclass
+class DecoderSpec:
+    """kind "class": ClassDecoder(n_classes=2, sigmoid) = LogisticDecoder (decoders.py:9-20,49-53).
+    kind "mlp": MLPDecoder (decoders.py:22-46): hidden Linear + hidden_activation layers, then
+    sigmoid(Linear(-> 2))."""
+    kind: str = "class"
+    hidden: Tuple[int, ...] = ()
+    hidden_activation: int = ACT_RELU
+
+    def names(self, d: int) -> List[str]:
+        if self.kind == "class":
+            return [f"decoders.{d}.fc"]
+        return [f"decoders.{d}.layers.{l}" for l in range(len(self.hidden) + 1)]
+
+    def layer_shapes(self, state_size: int) -> List[Tuple[int, int]]:
+        dims = [state_size] + (list(self.hidden) if self.kind == "mlp" else []) + [2]
+        return [(dout, din) for din, dout in zip(dims, dims[1:])]
+
+
+@dataclass
 class ModelSpec:
     state_size: int
     encoders: List[EncoderSpec]
     n_decoders: int
     err_penalty: float = 1.0
     state_change_penalty: float = 0.0       # the *user* value; x0.01 applied here (multimodn.py:86)
+    decoders: Optional[List[DecoderSpec]] = None      # None: n_decoders LogisticDecoders
+
+    def dec(self, d: int) -> DecoderSpec:
+        return self.decoders[d] if self.decoders is not None else DecoderSpec()
 
     @property
     def E(self) -> int:
@@ -76,9 +113,11 @@ class ModelSpec:
         names = ["init_state.state_value"]
         for e, enc in enumerate(self.encoders):
             for l in range(len(enc.hidden) + 1):
-                names += [f"encoders.{e}.layers.{l}.weight", f"encoders.{e}.layers.{l}.bias"]
+                k = enc.layer_key(l)
+                names += [f"encoders.{e}.layers.{k}.weight", f"encoders.{e}.layers.{k}.bias"]
         for d in range(self.n_decoders):
-            names += [f"decoders.{d}.fc.weight", f"decoders.{d}.fc.bias"]
+            for n in self.dec(d).names(d):
+                names += [n + ".weight", n + ".bias"]
         return names
 
     def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
@@ -86,11 +125,14 @@ class ModelSpec:
         shapes: Dict[str, Tuple[int, ...]] = {"init_state.state_value": (1, S)}
         for e, enc in enumerate(self.encoders):
             for l, (o, i) in enumerate(enc.layer_shapes(S)):
-                shapes[f"encoders.{e}.layers.{l}.weight"] = (o, i)
-                shapes[f"encoders.{e}.layers.{l}.bias"] = (o,)
+                k = enc.layer_key(l)
+                shapes[f"encoders.{e}.layers.{k}.weight"] = (o, i)
+                shapes[f"encoders.{e}.layers.{k}.bias"] = (o,)
         for d in range(self.n_decoders):
-            shapes[f"decoders.{d}.fc.weight"] = (2, S)
-            shapes[f"decoders.{d}.fc.bias"] = (2,)
+            dec = self.dec(d)
+            for n, (o, i) in zip(dec.names(d), dec.layer_shapes(S)):
+                shapes[n + ".weight"] = (o, i)
+                shapes[n + ".bias"] = (o,)
         return shapes
 
 
@@ -167,7 +209,8 @@ def forward_backward(params: Dict[str, np.ndarray], spec: ModelSpec,
                      batch_global: Optional[int] = None,
                      present_override: Optional[Sequence[bool]] = None,
                      dtype=np.float32, want_grads: bool = True,
-                     keep_states: bool = False) -> StepResult:
+                     keep_states: bool = False,
+                     drop_masks: Optional[Dict[int, np.ndarray]] = None) -> StepResult:
     """One mini-batch of train_epoch's body (multimodn.py:119-203) with a hand-derived backward.
 
     xs[k]: [B, F_k] features of data slot k; y: [B, D] int targets in {0,1}.
@@ -176,6 +219,9 @@ def forward_backward(params: Dict[str, np.ndarray], spec: ModelSpec,
     present_override[k]: NaN-skip decision per data slot (the reference decides it on the whole
     batch, multimodn.py:168; a shard must use the global decision).
     Skipped encoders get grad None (autograd never touches them), everything else an array.
+    drop_masks[e]: MIMIC_MLPEncoder e's dropout multipliers for this step, [B, F_e + S] with entries
+    0 or 1/(1-p) (what nn.Dropout applies to cat([x, state]) in training mode, mlp_encoder.py:34,41);
+    absent = no dropout (eval mode or p = 0).
     """
     S, E, D = spec.state_size, spec.E, spec.D
     dt = np.dtype(dtype)
@@ -198,16 +244,23 @@ def forward_backward(params: Dict[str, np.ndarray], spec: ModelSpec,
     fp = np.zeros_like(tp); fn = np.zeros_like(tp)
     executed = np.zeros(E, bool)
 
-    Wd = [P[f"decoders.{d}.fc.weight"] for d in range(D)]
-    bd = [P[f"decoders.{d}.fc.bias"] for d in range(D)]
+    dec_names = [spec.dec(d).names(d) for d in range(D)]
     dz_rows: Dict[int, np.ndarray] = {}
+    dec_tape: Dict[int, list] = {}      # row -> per decoder: activations [state, h_1, ..., h_last]
 
     def decode(row: int, s: np.ndarray):
-        """decoders.py:19-20 + multimodn.py:144-157: sigmoid(Linear), argmax (ties -> 0),
-        CrossEntropyLoss = mean_b(-log_softmax(o)[y]) over the sigmoid OUTPUTS, confusion matrix."""
+        """decoders.py:19-20 (ClassDecoder) / :41-46 (MLPDecoder: hidden_activation(Linear) layers,
+        then sigmoid(Linear)) + multimodn.py:144-157: argmax (ties -> 0), CrossEntropyLoss =
+        mean_b(-log_softmax(o)[y]) over the sigmoid OUTPUTS, confusion matrix."""
         dz = np.zeros((B, D, 2), dt)
+        acts_row = []
         for d in range(D):
-            z = s @ Wd[d].T + bd[d]
+            ds = spec.dec(d)
+            hs = [s]
+            for n in dec_names[d][:-1]:
+                hs.append(_act(hs[-1] @ P[n + ".weight"].T + P[n + ".bias"], ds.hidden_activation))
+            acts_row.append(hs)
+            z = hs[-1] @ P[dec_names[d][-1] + ".weight"].T + P[dec_names[d][-1] + ".bias"]
             o = 1.0 / (1.0 + np.exp(-z))
             m = o.max(axis=1, keepdims=True)
             lse = m[:, 0] + np.log(np.exp(o - m).sum(axis=1))
@@ -226,6 +279,7 @@ def forward_backward(params: Dict[str, np.ndarray], spec: ModelSpec,
                 g[np.arange(B), t] -= 1
                 dz[:, d, :] = g * o * (1 - o)
         dz_rows[row] = dz
+        dec_tape[row] = acts_row
 
     state = np.tile(P["init_state.state_value"], (B, 1))      # state.py:29-32
     states = {0: state}
@@ -244,14 +298,26 @@ def forward_backward(params: Dict[str, np.ndarray], spec: ModelSpec,
         executed[e] = True
         enc = spec.encoders[e]
         L = len(enc.hidden)
-        hs = [x]
-        h = x
-        for l in range(L):                                    # mlp_encoder.py:75-76
-            h = _act(h @ P[f"encoders.{e}.layers.{l}.weight"].T + P[f"encoders.{e}.layers.{l}.bias"],
-                     enc.activation)
-            hs.append(h)
-        cat = np.concatenate([h, state], axis=1)              # mlp_encoder.py:78 (h first, state last)
-        new_state = cat @ P[f"encoders.{e}.layers.{L}.weight"].T + P[f"encoders.{e}.layers.{L}.bias"]
+        if enc.kind == "mimic":                               # mlp_encoder.py:40-47
+            h = np.concatenate([x, state], axis=1)
+            if drop_masks is not None and e in drop_masks:
+                h = h * np.asarray(drop_masks[e], dt)         # nn.Dropout in training mode
+            hs = [h]
+            for l in range(L + 1):
+                k = enc.layer_key(l)
+                h = _act(h @ P[f"encoders.{e}.layers.{k}.weight"].T + P[f"encoders.{e}.layers.{k}.bias"],
+                         enc.activation)
+                hs.append(h)
+            new_state = h
+        else:
+            hs = [x]
+            h = x
+            for l in range(L):                                    # mlp_encoder.py:75-76
+                h = _act(h @ P[f"encoders.{e}.layers.{l}.weight"].T + P[f"encoders.{e}.layers.{l}.bias"],
+                         enc.activation)
+                hs.append(h)
+            cat = np.concatenate([h, state], axis=1)              # mlp_encoder.py:78 (h first, state last)
+            new_state = cat @ P[f"encoders.{e}.layers.{L}.weight"].T + P[f"encoders.{e}.layers.{L}.bias"]
         diff = new_state - state
         state_change[e] = (diff * diff).sum(dtype=dt) / dt.type(Bg * S)   # multimodn.py:174
         tape.append((e, prev_row, hs))
@@ -273,17 +339,27 @@ def forward_backward(params: Dict[str, np.ndarray], spec: ModelSpec,
     grads: Dict[str, Optional[np.ndarray]] = {n: None for n in spec.param_names()}
     cL = alpha / dt.type(D * (E + 1) * Bg)
     cS = beta * dt.type(2.0) / dt.type(E * Bg * S)
-    gWd = [np.zeros_like(Wd[d]) for d in range(D)]
-    gbd = [np.zeros_like(bd[d]) for d in range(D)]
+    dec_grads: Dict[str, np.ndarray] = {}
+    for d in range(D):
+        for n in dec_names[d]:
+            dec_grads[n + ".weight"] = np.zeros_like(P[n + ".weight"])
+            dec_grads[n + ".bias"] = np.zeros_like(P[n + ".bias"])
 
     def decoder_back(row: int) -> np.ndarray:
         dz = dz_rows[row] * cL
-        s = states[row]
-        gs = np.zeros_like(s)
+        gs = np.zeros_like(states[row])
         for d in range(D):
-            gWd[d] += dz[:, d, :].T @ s
-            gbd[d] += dz[:, d, :].sum(axis=0)
-            gs += dz[:, d, :] @ Wd[d]
+            hs = dec_tape[row][d]
+            names = dec_names[d]
+            g = dz[:, d, :]                                    # grad wrt the last Linear's output
+            for l in range(len(names) - 1, -1, -1):
+                n = names[l]
+                dec_grads[n + ".weight"] += g.T @ hs[l]
+                dec_grads[n + ".bias"] += g.sum(axis=0)
+                g = g @ P[n + ".weight"]
+                if l > 0:
+                    g = g * _act_grad_from_output(hs[l], spec.dec(d).hidden_activation)
+            gs += g
         return gs
 
     G = np.zeros((B, S), dt)
@@ -293,6 +369,19 @@ def forward_backward(params: Dict[str, np.ndarray], spec: ModelSpec,
         s_out, s_in = states[e + 1], states[in_row]
         diff = s_out - s_in
         G = G + decoder_back(e + 1) + cS * diff
+        if enc.kind == "mimic":
+            F_e = enc.n_features
+            g = G
+            for l in range(L, -1, -1):
+                k = enc.layer_key(l)
+                dpre = g * _act_grad_from_output(hs[l + 1], enc.activation)
+                grads[f"encoders.{e}.layers.{k}.weight"] = dpre.T @ hs[l]
+                grads[f"encoders.{e}.layers.{k}.bias"] = dpre.sum(axis=0)
+                g = dpre @ P[f"encoders.{e}.layers.{k}.weight"]
+            if drop_masks is not None and e in drop_masks:
+                g = g * np.asarray(drop_masks[e], dt)
+            G = g[:, F_e:] - cS * diff                         # no grad flows to x
+            continue
         Wl = P[f"encoders.{e}.layers.{L}.weight"]
         HL = hs[-1].shape[1]
         cat = np.concatenate([hs[-1], s_in], axis=1)
@@ -310,9 +399,7 @@ def forward_backward(params: Dict[str, np.ndarray], spec: ModelSpec,
         G = carry
     G = G + decoder_back(0)
     grads["init_state.state_value"] = G.sum(axis=0, keepdims=True)        # grad of tile = sum_b
-    for d in range(D):
-        grads[f"decoders.{d}.fc.weight"] = gWd[d]
-        grads[f"decoders.{d}.fc.bias"] = gbd[d]
+    grads.update(dec_grads)
     res.grads = grads
     return res
 
@@ -394,13 +481,14 @@ def aggregate_epoch(E: int, D: int, step_results: Sequence[StepResult],
 
 
 def train_epoch(params: Dict[str, np.ndarray], spec: ModelSpec, batches, optimizer: Adam,
-                dtype=np.float32) -> EpochResult:
+                dtype=np.float32, drop_masks: Optional[Sequence[Dict[int, np.ndarray]]] = None) -> EpochResult:
     """One epoch over `batches` = iterable of (xs, y) or (xs, y, encoder_sequence); updates
-    `params` in place (dict entries replaced)."""
+    `params` in place (dict entries replaced).  drop_masks[i]: batch i's dropout multipliers."""
     results, sizes = [], []
-    for batch in batches:
+    for bi, batch in enumerate(batches):
         xs, y, seq = (list(batch) + [None])[:3]
-        r = forward_backward(params, spec, xs, y, seq, dtype=dtype)
+        r = forward_backward(params, spec, xs, y, seq, dtype=dtype,
+                             drop_masks=None if drop_masks is None else drop_masks[bi])
         optimizer.step(params, r.grads)
         results.append(r)
         sizes.append(np.asarray(y).shape[0])
@@ -411,12 +499,17 @@ def train_epoch(params: Dict[str, np.ndarray], spec: ModelSpec, batches, optimiz
 # forward-only entry points: test() / predict() / get_states() (multimodn.py:255-492)
 # ------------------------------------------------------------------------------------------------
 def decoder_outputs(params: Dict[str, np.ndarray], spec: ModelSpec, state: np.ndarray, dtype=np.float32) -> np.ndarray:
-    """sigmoid(Linear(state)) of every decoder (decoders.py:19-20): [B, D, 2]."""
+    """sigmoid(Linear(...)) of every decoder (decoders.py:19-20, :41-46): [B, D, 2]."""
     dt = np.dtype(dtype)
     s = np.asarray(state, dt)
     out = np.zeros((s.shape[0], spec.D, 2), dt)
     for d in range(spec.D):
-        z = s @ np.asarray(params[f"decoders.{d}.fc.weight"], dt).T + np.asarray(params[f"decoders.{d}.fc.bias"], dt)
+        ds = spec.dec(d)
+        names = ds.names(d)
+        h = s
+        for n in names[:-1]:
+            h = _act(h @ np.asarray(params[n + ".weight"], dt).T + np.asarray(params[n + ".bias"], dt), ds.hidden_activation)
+        z = h @ np.asarray(params[names[-1] + ".weight"], dt).T + np.asarray(params[names[-1] + ".bias"], dt)
         out[:, d, :] = 1.0 / (1.0 + np.exp(-z))
     return out
 
@@ -426,7 +519,7 @@ def test_epoch(params, spec: ModelSpec, batches, dtype=np.float32):
     arrays, outputs) where outputs[d] = (y_true [N], y_pred [N], y_prob [N]) for the decoder on the
     state after the LAST encoder (enc_idx == E-1, :354-357), probabilities renormalised to sum to 1
     (:415), prediction = argmax of the renormalised pair (first index wins ties)."""
-    eval_spec = ModelSpec(spec.state_size, spec.encoders, spec.D, 1.0, 0.0)
+    eval_spec = replace(spec, err_penalty=1.0, state_change_penalty=0.0)
     results, sizes = [], []
     outs, tgts = [], []
     for batch in batches:
@@ -571,7 +664,7 @@ def per_sample_eval(params, spec: ModelSpec, xs, y, sequences, dtype=np.float32)
     samples whose LAST encoder ran)."""
     B = np.asarray(y).shape[0]
     E, D = spec.E, spec.D
-    eval_spec = ModelSpec(spec.state_size, spec.encoders, spec.D, 1.0, 0.0)
+    eval_spec = replace(spec, err_penalty=1.0, state_change_penalty=0.0)
     acc = None
     counts = np.zeros(E + 1, np.int64); counts[0] = B
     preds = np.zeros((E + 1, D, B))

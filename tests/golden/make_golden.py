@@ -76,8 +76,8 @@ def install_shims():
 
 install_shims()
 from multimodn.multimodn import MultiModN                      # noqa: E402  (reference)
-from multimodn.encoders import MLPEncoder                      # noqa: E402
-from multimodn.decoders import LogisticDecoder                 # noqa: E402
+from multimodn.encoders import MLPEncoder, MIMIC_MLPEncoder    # noqa: E402
+from multimodn.decoders import LogisticDecoder, MLPDecoder     # noqa: E402
 from multimodn.history import MultiModNHistory                 # noqa: E402
 import datasets as _ref_datasets                               # noqa: E402
 assert _ref_datasets.__file__.startswith(REF), "HuggingFace `datasets` shadowed the reference's"
@@ -138,6 +138,21 @@ CONFIGS = {
                         act="sigmoid", store="all"),
     "mlp_identity": dict(F=[6], H=(4, 4, 4), S=8, D=3, B=8, N=24, lr=0.01, pen=(1.0, 1.0), epochs=2,
                          act="identity", store="all"),
+    # ---- MIMIC family: MIMIC_MLPEncoder (mlp_encoder.py:9-47) + MLPDecoder
+    # (decoders.py:22-46).  enc_kinds: per-encoder class ("mimic" | "mlp"); dec: per-decoder
+    # ("mlp", hidden) | ("class", ()); dropout: MIMIC encoders' p (masks are recorded per step).
+    "mimic_p0": dict(F=[6, 5], H=(8, 8), S=16, D=2, B=16, N=40, lr=0.01, pen=(1.0, 0.5), epochs=2,
+                     act="relu", store="all", enc_kinds=["mimic", "mimic"], dropout=0.0,
+                     dec=[("mlp", (8, 8)), ("mlp", (8, 8))]),
+    "mimic_drop": dict(F=[7, 4, 5], H=(8,), S=24, D=2, B=16, N=40, lr=0.01, pen=(1.0, 0.5), epochs=2,
+                       act="relu", store="all", enc_kinds=["mimic"] * 3, dropout=0.2,
+                       dec=[("mlp", (6,)), ("mlp", (6,))]),
+    "mimic_mixed": dict(F=[4, 3, 5], H=(6,), S=16, D=3, B=16, N=48, lr=0.01, pen=(0.7, 0.3), epochs=2,
+                        act="sigmoid", store="all", enc_kinds=["mimic", "mlp", "mimic"], dropout=0.25,
+                        dec=[("mlp", (5,)), ("class", ()), ("mlp", ())], nan=[(1, 0, 3, 1)]),
+    "mimic_c3_small": dict(F=[64] * 4, H=(32, 32), S=128, D=3, B=64, N=128, lr=1e-3, pen=(1.0, 0.3),
+                           epochs=1, act="relu", store="first_last", enc_kinds=["mimic"] * 4, dropout=0.2,
+                           dec=[("mlp", (32, 32))] * 3),
 }
 
 
@@ -168,9 +183,38 @@ def run_reference(name, cfg, seed=0):
     torch.manual_seed(seed)
     torch.set_num_threads(1)
     S, D = cfg["S"], cfg["D"]
-    encoders = [MLPEncoder(S, f, tuple(cfg["H"]), ACTS[cfg["act"]]) for f in cfg["F"]]
-    decoders = [LogisticDecoder(S) for _ in range(D)]
+    kinds = cfg.get("enc_kinds", ["mlp"] * len(cfg["F"]))
+    encoders = [MLPEncoder(S, f, tuple(cfg["H"]), ACTS[cfg["act"]]) if k == "mlp" else
+                MIMIC_MLPEncoder(S, f, tuple(cfg["H"]), dropout=cfg.get("dropout", 0.0), activation=ACTS[cfg["act"]])
+                for f, k in zip(cfg["F"], kinds)]
+    decoders = [LogisticDecoder(S) if k == "class" else MLPDecoder(S, tuple(h), 2)
+                for k, h in cfg.get("dec", [("class", ())] * D)]
     model = MultiModN(S, encoders, decoders, cfg["pen"][0], cfg["pen"][1], device=torch.device("cpu"))
+    # Dropout masks of the MIMIC encoders, observed without touching the reference: a forward hook
+    # rewinds the CPU generator to where the Dropout module found it and draws the same noise again on
+    # a tensor of ones (ATen: noise.bernoulli_(1-p).div_(1-p); out = input * noise), then checks that
+    # the generator ends where the module left it and that out == input * mask bit for bit.
+    masks = {}
+
+    def pre_hook(mod, inp):
+        mod._rng_before = torch.get_rng_state()
+
+    def make_post(e):
+        def post_hook(mod, inp, out):
+            if not mod.training or mod.p == 0:
+                return
+            after = torch.get_rng_state()
+            torch.set_rng_state(mod._rng_before)
+            mask = torch.nn.functional.dropout(torch.ones_like(inp[0]), mod.p, True)
+            assert torch.equal(torch.get_rng_state(), after)
+            assert torch.equal(out, inp[0] * mask)
+            masks[(len(opt.grads), e)] = mask.numpy().copy()
+        return post_hook
+
+    for e, enc in enumerate(encoders):
+        if isinstance(enc, MIMIC_MLPEncoder):
+            enc.layers[0].register_forward_pre_hook(pre_hook)
+            enc.layers[0].register_forward_hook(make_post(e))
     init = {n: p.detach().numpy().copy() for n, p in model.named_parameters()}
     batches_np = make_data(cfg, seed + 1)
     loader = [tuple([[torch.from_numpy(x) for x in b[0]], torch.from_numpy(b[1])] +
@@ -205,12 +249,15 @@ def run_reference(name, cfg, seed=0):
         ev["predict"] = model.predict(b0[0], seq0)
     ev["states"] = torch.stack(model.get_states(loader)).numpy()
     return dict(init=init, batches=batches_np, crit_calls=crit.calls, grads=opt.grads,
-                params=opt.params, losses=losses, hist=hist, eval=ev)
+                params=opt.params, losses=losses, hist=hist, eval=ev, masks=masks, model=model)
 
 
 def spec_of(cfg):
-    return O.ModelSpec(cfg["S"], [O.EncoderSpec(f, tuple(cfg["H"]), ACT_ID[cfg["act"]]) for f in cfg["F"]],
-                       cfg["D"], cfg["pen"][0], cfg["pen"][1])
+    kinds = cfg.get("enc_kinds", ["mlp"] * len(cfg["F"]))
+    encs = [O.EncoderSpec(f, tuple(cfg["H"]), ACT_ID[cfg["act"]], kind=k,
+                          dropout=cfg.get("dropout", 0.0) if k == "mimic" else 0.0) for f, k in zip(cfg["F"], kinds)]
+    decs = [O.DecoderSpec(k, tuple(h)) for k, h in cfg["dec"]] if "dec" in cfg else None
+    return O.ModelSpec(cfg["S"], encs, cfg["D"], cfg["pen"][0], cfg["pen"][1], decoders=decs)
 
 
 def rel(a, b):
@@ -220,7 +267,10 @@ def rel(a, b):
 
 def main():
     worst = {}
+    only = set(sys.argv[1:])                                  # optional: regenerate just these configurations
     for name, cfg in CONFIGS.items():
+        if only and name not in only:
+            continue
         ref = run_reference(name, cfg)
         spec = spec_of(cfg)
         n_steps = len(ref["losses"])
@@ -256,6 +306,8 @@ def main():
             if store == "all":
                 for n, p in ref["params"][s].items():
                     out[f"step{s}/param/{n}"] = p
+        for (ms, e), mk in ref["masks"].items():          # every step's masks: the run cannot be replayed without them
+            out[f"step{ms}/mask{e}"] = mk
         for n, p in ref["params"][-1].items():
             out[f"final/{n}"] = p
         for k, v in ref["eval"].items():
@@ -272,7 +324,8 @@ def main():
             for bi, b in enumerate(ref["batches"]):
                 s = ep * nb + bi
                 xs, y, seq = (list(b) + [None])[:3]
-                r = O.forward_backward(params, spec, xs, y, seq)
+                r = O.forward_backward(params, spec, xs, y, seq,
+                                       drop_masks={e: mk for (ms, e), mk in ref["masks"].items() if ms == s})
                 w["loss"] = max(w["loss"], abs(r.loss - ref["losses"][s]) / abs(ref["losses"][s]))
                 # criterion call order: row 0 decoders, then each executed encoder in sequence order
                 rows = [0] + [e + 1 for _, e in O.encoder_iterable(spec.E, seq) if r.executed[e]]

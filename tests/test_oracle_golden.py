@@ -2,11 +2,11 @@
 import numpy as np
 import pytest
 
-from helpers import GOLDEN_NAMES, Golden, rel_err
+from helpers import GOLDEN_NAMES, MIMIC_GOLDEN_NAMES, Golden, rel_err
 from oracle import multimodn_oracle as O
 
 
-@pytest.mark.parametrize("name", GOLDEN_NAMES)
+@pytest.mark.parametrize("name", GOLDEN_NAMES + MIMIC_GOLDEN_NAMES)
 def test_oracle_reproduces_reference_run(name):
     g = Golden(name)
     params = g.init_params()
@@ -17,7 +17,8 @@ def test_oracle_reproduces_reference_run(name):
         results, sizes = [], []
         for bi in range(g.n_batches):
             b = g.batch(bi)
-            r = O.forward_backward(params, g.spec, b[0], b[1], b[2] if len(b) > 2 else None)
+            r = O.forward_backward(params, g.spec, b[0], b[1], b[2] if len(b) > 2 else None,
+                                   drop_masks=g.step_masks(s))
             assert abs(r.loss - z["step_loss"][s]) / abs(z["step_loss"][s]) < 2e-6
             if g.has_step(s):
                 none = set(str(x) for x in z[f"step{s}/grad_none"])
@@ -50,11 +51,28 @@ def test_fp64_oracle_agrees_with_fp32():
         assert rel_err(r32.grads[n], r64.grads[n]) < 1e-5
 
 
-def test_gradients_by_finite_differences():
-    spec = O.ModelSpec(6, [O.EncoderSpec(3, (4,), O.ACT_SIGMOID), O.EncoderSpec(2, (), O.ACT_RELU)], 2, 0.8, 50.0)
+FD_SPECS = {
+    "mlp": O.ModelSpec(6, [O.EncoderSpec(3, (4,), O.ACT_SIGMOID), O.EncoderSpec(2, (), O.ACT_RELU)], 2, 0.8, 50.0),
+    # MIMIC family: sigmoid everywhere (smooth, so central differences are valid), explicit dropout masks
+    "mimic": O.ModelSpec(6, [O.EncoderSpec(3, (4,), O.ACT_SIGMOID, kind="mimic", dropout=0.3),
+                             O.EncoderSpec(2, (), O.ACT_SIGMOID, kind="mimic"),
+                             O.EncoderSpec(2, (3,), O.ACT_SIGMOID)], 2, 0.8, 50.0,
+                         decoders=[O.DecoderSpec("mlp", (4, 3), O.ACT_SIGMOID), O.DecoderSpec("mlp", ())]),
+}
+
+
+@pytest.mark.parametrize("family", ["mlp", "mimic"])
+def test_gradients_by_finite_differences(family):
+    spec = FD_SPECS[family]
     params = O.init_params(spec, 0, np.float64)
     xs, y = O.synthetic_batches(spec, 5, 5, seed=0)[0]
-    r = O.forward_backward(params, spec, xs, y, dtype=np.float64)
+    masks = None
+    if family == "mimic":
+        keep = np.random.default_rng(5).random((5, 3 + 6)) >= 0.3
+        masks = {0: keep / 0.7}
+    import functools
+    fb = functools.partial(O.forward_backward, drop_masks=masks)
+    r = fb(params, spec, xs, y, dtype=np.float64)
     rng = np.random.default_rng(0)
     for n in spec.param_names():
         for _ in range(3):
@@ -63,8 +81,8 @@ def test_gradients_by_finite_differences():
             p2 = {k: v.copy() for k, v in params.items()}
             p1[n][idx] += 1e-6
             p2[n][idx] -= 1e-6
-            fd = (O.forward_backward(p1, spec, xs, y, dtype=np.float64, want_grads=False).loss
-                  - O.forward_backward(p2, spec, xs, y, dtype=np.float64, want_grads=False).loss) / 2e-6
+            fd = (fb(p1, spec, xs, y, dtype=np.float64, want_grads=False).loss
+                  - fb(p2, spec, xs, y, dtype=np.float64, want_grads=False).loss) / 2e-6
             assert abs(fd - r.grads[n][idx]) < 1e-7 + 1e-5 * abs(fd), (n, idx)
 
 

@@ -31,11 +31,12 @@
 extern "C" {
 #endif
 
-#define MMN_VERSION 101            /* 0.1.1: mmn_batch grew tile_rows / tile_seq */
+#define MMN_VERSION 102            /* 0.1.2: MIMIC_MLPEncoder / MLPDecoder (mmn_encoder.kind, mmn_decoder.hidden, mmn_batch.drop_mask) */
 #define MMN_MAX_ENCODERS 16
 #define MMN_MAX_DECODERS 8
 #define MMN_MAX_LAYERS 8           /* hidden layers + the state-update Linear */
 #define MMN_MAX_DIM 256            /* state_size and every hidden width; n_features is unbounded */
+#define MMN_MAX_DEC_HIDDEN 3       /* hidden layers of an MLPDecoder */
 
 /* activation of MLPEncoder hidden layers (multimodn/encoders/mlp_encoder.py:56,75-76) */
 #define MMN_ACT_IDENTITY 0
@@ -65,21 +66,36 @@ typedef struct mmn_linear {
 /* MLPEncoder (multimodn/encoders/mlp_encoder.py:49-80): n_layers-1 hidden Linear+activation on x
  * only, then Linear(cat[h, state]) with no activation.  layer[n_layers-1].in_dim = h_dim + S with
  * the h columns FIRST (mlp_encoder.py:78).  n_layers == 1 is SLP/Linear/LogisticEncoder. */
+/* kind MMN_ENC_MIMIC = MIMIC_MLPEncoder (multimodn/encoders/mlp_encoder.py:9-47): the FIRST Linear
+ * reads Dropout(cat[x, state]) (x columns first, :40-41: layer[0].in_dim = n_features + S), every
+ * further Linear reads the previous output, the activation follows EVERY Linear including the last
+ * one, whose output is the new state (:42-47).  The Dropout module (layers.0 of the reference) has no
+ * parameters: layer[l] here is the reference's layers.{l+1}; its multipliers arrive per step through
+ * mmn_batch.drop_mask. */
+#define MMN_ENC_MLP 0
+#define MMN_ENC_MIMIC 1
 typedef struct mmn_encoder {
     int32_t n_features;
     int32_t n_layers;
     int32_t activation;
-    int32_t reserved;
+    int32_t kind;                  /* MMN_ENC_MLP / MMN_ENC_MIMIC */
     mmn_linear layer[MMN_MAX_LAYERS];
 } mmn_encoder;
 
 /* ClassDecoder with sigmoid and n_classes = 2 = LogisticDecoder (decoders.py:9-20,49-53):
  * fc.weight [2, S], fc.bias [2]. */
+/* n_hidden > 0 = MLPDecoder(state_size, hidden_layers, 2, sigmoid, hidden_activation)
+ * (decoders.py:22-46): hidden[l] are layers.0 .. layers.{n_hidden-1} (Linear + hidden_activation),
+ * w/b the last Linear [2, hidden[n_hidden-1].out_dim] followed by the sigmoid.  n_hidden == 0 with an
+ * MLPDecoder's parameter names is the same arithmetic as ClassDecoder. */
 typedef struct mmn_decoder {
     const float* w;
     const float* b;
     float* gw;
     float* gb;
+    int32_t n_hidden;
+    int32_t hidden_activation;     /* MMN_ACT_* */
+    mmn_linear hidden[MMN_MAX_DEC_HIDDEN];
 } mmn_decoder;
 
 /* MultiModN(state_size, encoders, decoders, ...) with TrainableInitState
@@ -127,6 +143,12 @@ typedef struct mmn_batch {
      * fused-kernel shapes only (MMN_ERR_UNSUPPORTED otherwise). */
     const int32_t* tile_rows;
     const int32_t* tile_seq;
+    /* MIMIC_MLPEncoder dropout (mlp_encoder.py:34,41), indexed by ENCODER id: drop_mask[e] = device
+     * [batch x (n_features_e + S)] multipliers (0 or 1/(1-p), row stride n_features_e + S) applied to
+     * cat([x, state]) before the first Linear of encoder e, forward and backward.  NULL = no dropout
+     * for that encoder this step (eval mode, p = 0, or an MLPEncoder).  The caller draws them (the
+     * reference draws them from torch's generator; multimodn_amd does the same on the device). */
+    const float* drop_mask[MMN_MAX_ENCODERS];
 } mmn_batch;
 
 /* Per-step statistics block, fp32, written by mmn_reduce (local sums, ready for an all-reduce)
@@ -171,7 +193,8 @@ int mmn_nan_scan(mmn_plan* p, const mmn_batch* b, void* stream);
 
 /* Which device kernel mmn_chain_fwd (backward = 0) / mmn_chain_bwd (backward = 1) launches for this
  * plan and batch: "k_fwd8"/"k_bwd8" (8-wave tier for MIMIC-like shapes), "k_chain_fwd_par"/
- * "k_chain_bwd_par" (4-wave parallel-phase tier) or "k_chain_fwd"/"k_chain_bwd" (any shape).  For
+ * "k_chain_bwd_par" (4-wave parallel-phase tier), "k_chain_fwd"/"k_chain_bwd" (any MLPEncoder /
+ * ClassDecoder shape) or "k_gen_fwd"/"k_gen_bwd" (models with a MIMIC_MLPEncoder or an MLPDecoder).  For
  * matching rocprof rows.  backward = 2 asks for the fused forward+backward kernel ("k_fb8" or ""). */
 const char* mmn_chain_kernel_name(mmn_plan* p, const mmn_batch* b, int backward);
 

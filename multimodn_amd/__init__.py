@@ -2,8 +2,8 @@
 path behind the reference's plugin surface (MultiModN / MultiModEncoder / MultiModDecoder /
 InitState / MultiModDataset / MultiModNHistory)."""
 from .state import InitState, TrainableInitState, StaticInitState
-from .encoders import MultiModEncoder, MLPEncoder, SLPEncoder, LinearEncoder, LogisticEncoder
-from .decoders import MultiModDecoder, ClassDecoder, LogisticDecoder
+from .encoders import MultiModEncoder, MLPEncoder, MIMIC_MLPEncoder, SLPEncoder, LinearEncoder, LogisticEncoder
+from .decoders import MultiModDecoder, ClassDecoder, MLPDecoder, LogisticDecoder
 from .history import MultiModNHistory
 from .datasets import MultiModDataset, PartitionDataset, FeatureWiseDataset, JointDatasets, DeviceResidentLoader
 from .multimodn import MultiModN
@@ -12,7 +12,8 @@ from . import optim, metrics
 
 __all__ = [
     "InitState", "TrainableInitState", "StaticInitState", "MultiModEncoder", "MLPEncoder", "SLPEncoder",
-    "LinearEncoder", "LogisticEncoder", "MultiModDecoder", "ClassDecoder", "LogisticDecoder",
+    "LinearEncoder", "LogisticEncoder", "MultiModDecoder", "ClassDecoder", "LogisticDecoder", "MIMIC_MLPEncoder",
+    "MLPDecoder",
     "MultiModNHistory", "MultiModDataset", "PartitionDataset", "FeatureWiseDataset", "JointDatasets",
     "MultiModN", "HipChainEngine", "UnsupportedModelError", "optim", "DeviceResidentLoader", "metrics",
 ]

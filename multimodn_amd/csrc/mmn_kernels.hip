@@ -82,8 +82,8 @@ __host__ __device__ inline int pick_ld(int k) {
 // ------------------------------------------------------------------------------------------------
 // device-side plan (lives at the start of the workspace)
 // ------------------------------------------------------------------------------------------------
-enum { A_DPRE = 0, A_DS = 1, A_DZ = 2 };
-enum { IN_NONE = 0, IN_X = 1, IN_HID = 2, IN_STATE_ROW = 3, IN_PREV_STATE = 4 };
+enum { A_DPRE = 0, A_DS = 1, A_DZ = 2, A_GEN = 3 };
+enum { IN_NONE = 0, IN_X = 1, IN_HID = 2, IN_STATE_ROW = 3, IN_PREV_STATE = 4 };   // + IN_INIT = 5, IN_GEN = 6 below
 
 struct WTask {
     int32_t a_kind, a_enc, a_idx;      // A_DPRE: (enc, layer) ; A_DS: idx ; A_DZ: row
@@ -98,6 +98,10 @@ struct WTask {
     int64_t part_base, part_stride;    // encoders / init state: 0, nA ; decoder row r: nA*ks + r*ks*nB, nB
     int64_t w_flat, b_flat;            // flat index (inside the region) of the weight / bias gradient tensor
     int32_t dec_stride, pad2;          // decoder tasks: flat distance between consecutive decoders, else 0
+    // generic tier (MIMIC_MLPEncoder / MLPDecoder): operands in the gdpre / gact regions
+    int64_t a_gen_off, in_gen_off;     // A_GEN: float offset into gdpre ; IN_GEN: float offset into gact
+    int32_t gen_lda, gen_ldi;          // their row strides
+    int32_t a_col, pad4;               // A_DZ: first column (decoder d's pair) when M < 2D
 };
 
 struct WItem {
@@ -109,7 +113,7 @@ struct WItem {
 // One k_wgrad work item, fully resolved at plan creation: a workgroup reads ONE record (a
 // wave-uniform, scalar load) and knows its operands, instead of chasing plan -> item -> task ->
 // flags through four dependent global loads.
-enum { IN_INIT = 5 };
+enum { IN_INIT = 5, IN_GEN = 6 };
 struct WRec {
     int64_t a_off;                      // float offset of A inside its region (dpre / dS / dz)
     int64_t in_off;                     // float offset of the In source inside its region (hid / states)
@@ -130,6 +134,7 @@ struct WgArgs {
     long long* stamps;
     const float* sin;                   // per-sample mode: In operand of the state-update weights
     int32_t maxB, S;
+    const float* gact; const float* gdpre;   // generic tier: layer inputs / pre-activation gradients
 };
 
 struct Seg {                            // one gradient tensor
@@ -172,6 +177,17 @@ struct DevPlan {
     WTask* tasks; WItem* items; Seg* segs; PackTask* ptasks; WRec* recs;
     int32_t n_tasks, n_items, n_segs, n_ptasks;
     int64_t n_grad_elems, n_pack_elems;
+    // ---- generic tier (k_gen_fwd / k_gen_bwd: models with a MIMIC_MLPEncoder or an MLPDecoder)
+    int32_t generic, pad5;
+    float* gact;               // xin[e] [maxB x (F_e+S)] (MIMIC encoders: (masked) cat[x, state]) and the decoders'
+                               // hidden activations dhid[r][d][l] [maxB x H]
+    float* gdpre;              // d loss / d pre-activation of the decoders' hidden layers, same shape as dhid
+    int64_t xin_off[MMN_MAX_ENCODERS];                           // float offsets into gact (-1: not a MIMIC encoder)
+    int64_t dh_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN];        // offset of (d, l) inside one grid row's block
+    int64_t dh_row_stride;                                       // floats per grid row (gact and gdpre alike)
+    int64_t dh_base;                                             // start of the dhid blocks inside gact
+    int64_t pkdf_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];  // forward operand of decoder layer l (last = output Linear)
+    int64_t pkdb_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];  // backward operand (W^T)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -491,7 +507,8 @@ __global__ __launch_bounds__(NT) void k_prepare(const DevPlan* __restrict__ P, m
     }
     // ---- repack: one thread per pack element; the task table is read into LDS once per block
     // (searching it in global memory was ~6 dependent round trips per thread)
-    constexpr int MAXPT = 2 * MMN_MAX_ENCODERS * MMN_MAX_LAYERS + MMN_MAX_ENCODERS + MMN_MAX_DECODERS;
+    constexpr int MAXPT = 2 * MMN_MAX_ENCODERS * MMN_MAX_LAYERS + MMN_MAX_ENCODERS + MMN_MAX_DECODERS +
+                          2 * MMN_MAX_DECODERS * (MMN_MAX_DEC_HIDDEN + 1);
     __shared__ PackTask stk[MAXPT];
     const int npt = min(p.n_ptasks, MAXPT);
     {
@@ -1155,6 +1172,515 @@ __global__ __launch_bounds__(NT) void k_chain_bwd(const DevPlan* __restrict__ P,
         if (col < S) lds_st(G + row * ldS + col, lds_ld(G + row * ldS + col) + v);
     });
     __syncthreads();
+    store_rows(p.dS + ((int64_t)E * p.maxB + row0) * S, G, ldS, nrows, S);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic tier: k_gen_fwd / k_gen_bwd.  Any mix of MLPEncoder and MIMIC_MLPEncoder
+// (multimodn/encoders/mlp_encoder.py:9-47: Dropout(cat[x, state]) -> Linear+act ... -> Linear+act =
+// new state) with ClassDecoder and MLPDecoder heads (multimodn/decoders/decoders.py:22-46: hidden
+// Linear+act layers, then sigmoid(Linear -> 2)).  Sequential form of the chain, one 16- or 32-row
+// tile per workgroup; every product is an LDS activation tile times fragment-ordered weights, like
+// the sequential tier above.  With a MIMIC encoder nothing of the encoder is independent of the
+// state (it enters the FIRST layer), so the re-association the 8-wave kernels live on does not exist
+// here: every layer of every encoder is on the dependent chain.
+// What the backward half and k_wgrad read is written by the forward half when want_grads:
+//   states[e], hid[e][l] (outputs of the non-final layers), gact.xin[e] = the (masked) cat[x, state]
+//   a MIMIC encoder's first Linear saw, gact.dhid[r][d][l] = decoder d's hidden activations on grid
+//   row r, dz[r]; the backward half adds dS[e] (MIMIC: d loss / d PRE-activation of the state layer),
+//   dpre[e][l], gdpre[r][d][l].
+// ------------------------------------------------------------------------------------------------
+// copy a global [nrows x ncols] tile times an optional multiplier tile into an LDS image (zero padded)
+__device__ __forceinline__ void stage_rows_mul(lp dst, int ld_dst, const float* __restrict__ src, int64_t ld_src,
+                                               const float* __restrict__ mul, int64_t ld_mul, int nrows, int rows_pad,
+                                               int ncols) {
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int cpad = round_up(ncols, 16);
+    for (int r = wave; r < rows_pad; r += 4)
+        for (int c = lane; c < cpad; c += 64) {
+            float v = 0.f;
+            if (r < nrows && c < ncols) {
+                v = g_ld(src + (int64_t)r * ld_src + c);
+                if (mul) v *= g_ld(mul + (int64_t)r * ld_mul + c);
+            }
+            lds_st(dst + r * ld_dst + c, v);
+        }
+}
+
+// out[rows x N] = [sState (B.T0 k-steps, may be 0)] ++ [x columns streamed from global, XCH at a time] times W'^T
+template <int RT, class Epi>
+__device__ __forceinline__ void layer_state_x(clp sState, int ldS, const PB& B, lp sX, const float* __restrict__ xg,
+                                              int64_t ldx, const float* __restrict__ mg, int64_t ldm, int F, int nrows,
+                                              Epi&& epi) {
+    constexpr int TB = 16 * RT;
+    const int wave = wave_id();
+    const int ntiles = (B.N + 15) >> 4;
+    for (int base = 0; base < ntiles; base += 8) {
+        const int m0[2] = {16 * (base + wave), 16 * (base + wave + 4)};
+        f32x4 acc[2][RT];
+        zero_acc<RT>(acc);
+        if (B.T0 > 0 && m0[0] < B.N) {
+            const ASrc A{sState, ldS, sState, ldS};
+            wave_gemm_any<RT>(acc, A, B, m0, 0, B.T0);
+        }
+        for (int xc = 0; xc < F; xc += XCH) {
+            const int kw = min(XCH, F - xc);
+            if (mg) stage_rows_mul(sX, LDX, xg + xc, ldx, mg + xc, ldm, nrows, TB, kw);
+            else stage_rows(sX, LDX, xg + xc, ldx, nrows, TB, kw);
+            __syncthreads();
+            if (m0[0] < B.N) {
+                const ASrc A{sState, ldS, sX - xc, LDX};       // step t reads image column 16 (t - T0) - xc
+                wave_gemm_any<RT>(acc, A, B, m0, B.T0 + (xc >> 4), B.T0 + ((xc + kw + 15) >> 4));
+            }
+            __syncthreads();
+        }
+        if (m0[0] < B.N) run_epilogue<RT>(acc, m0, B.N, epi);
+    }
+}
+
+struct GenDecodeCtx {
+    LPlan* p;
+    lp sZ; lp sH0; lp sH1;
+    int y;                 // this thread's target (row, d)
+    int row0, nrows, tile;
+    float cL;
+    int want_grads;
+};
+
+// all D decoders on one state tile: hidden layers (decoders.py:42-43), output Linear + sigmoid (:44-45),
+// CrossEntropy over the sigmoid outputs, argmax, confusion counts (multimodn.py:141-157,176-191)
+template <int RT>
+__device__ __forceinline__ void gen_decode(const GenDecodeCtx& c, clp sS, int grid_row) {
+    constexpr int TB = 16 * RT;
+    LPlan& p = *c.p;
+    const int ldS = p.ldS, ldH = p.ldH, D = p.D, R = p.R, S = p.S;
+    const int lane = threadIdx.x & 63;
+    for (int d = 0; d < D; ++d) {
+        const auto& dec = p.m.dec[d];
+        const int nh = dec.n_hidden, hk = dec.hidden_activation;
+        clp in = sS; int ldi = ldS, K = S;
+        for (int l = 0; l < nh; ++l) {
+            const auto& lin = dec.hidden[l];
+            const int N = lin.out_dim;
+            const lp out = (l & 1) ? c.sH1 : c.sH0;
+            const float* bias = lin.b;
+            const ASrc A{in, ldi, in, ldi};
+            const PB B = make_pb(p.pack + p.pkdf_off[d][l], N, K, 0);
+            layer_nt<RT>(A, B, [&](int row, int col, float v) {
+                if (col < N) lds_st(out + row * ldH + col, act_fwd(v + g_ld(bias + col), hk));
+            });
+            __syncthreads();
+            if (c.want_grads)
+                store_rows(p.gact + p.dh_base + (int64_t)grid_row * p.dh_row_stride + p.dh_off[d][l] + (int64_t)c.row0 * N,
+                           out, ldH, c.nrows, N);
+            in = out; ldi = ldH; K = N;
+        }
+        const float* bias = dec.b;
+        const ASrc A{in, ldi, in, ldi};
+        const PB B = make_pb(p.pack + p.pkdf_off[d][nh], 2, K, 0);
+        layer_nt<RT>(A, B, [&](int row, int col, float v) {
+            if (col < 2) lds_st(c.sZ + row * 16 + 2 * d + col, v + g_ld(bias + col));
+        });
+        __syncthreads();
+    }
+    const int t = threadIdx.x;
+    const int row = t & (TB - 1), d = t / TB;
+    float lossv = 0.f;
+    int correct = 0, tp = 0, tn = 0, fp = 0, fn = 0;
+    if (d < D && row < c.nrows) {
+        const float za = lds_ld(c.sZ + row * 16 + 2 * d), zb = lds_ld(c.sZ + row * 16 + 2 * d + 1);
+        const int64_t grow = (int64_t)c.row0 + row;
+        const int y = c.y;
+        const float o0 = 1.0f / (1.0f + expf(-za));
+        const float o1 = 1.0f / (1.0f + expf(-zb));
+        const float mx = fmaxf(o0, o1);
+        const float lse = mx + logf(expf(o0 - mx) + expf(o1 - mx));
+        lossv = lse - (y ? o1 : o0);
+        const int pred = o1 > o0 ? 1 : 0;          // torch.max: first index wins ties
+        correct = pred == y;
+        tp = pred & y; tn = (1 - pred) & (1 - y); fp = pred & (1 - y); fn = (1 - pred) & y;
+        f32x2 ov;
+        if (c.want_grads) {
+            const float g0 = expf(o0 - lse) - (y == 0 ? 1.0f : 0.0f);
+            const float g1 = expf(o1 - lse) - (y == 1 ? 1.0f : 0.0f);
+            ov.x = c.cL * g0 * o0 * (1.0f - o0);
+            ov.y = c.cL * g1 * o1 * (1.0f - o1);
+        } else {                                    // forward-only: the decoder OUTPUTS take dz's place (test()/predict())
+            ov.x = o0; ov.y = o1;
+        }
+        g_st2(p.dz + ((int64_t)grid_row * p.maxB + grow) * (2 * D) + 2 * d, ov);
+    }
+#pragma unroll
+    for (int off = TB / 2; off >= 1; off >>= 1) lossv += __shfl_xor(lossv, off);
+    const unsigned long long mc = __ballot(correct), mtp = __ballot(tp), mtn = __ballot(tn),
+                             mfp = __ballot(fp), mfn = __ballot(fn);
+    if (row == 0 && d < D) {
+        const int sh = lane & ~(TB - 1);
+        const unsigned long long msk = (TB == 32) ? 0xFFFFFFFFull : 0xFFFFull;
+        const int64_t cell = (int64_t)c.tile * (R * D) + grid_row * D + d;
+        g_st(p.lossp + cell, lossv);
+        int32_t* cp = p.cnt + cell * 5;
+        g_sti(cp + 0, __popcll((mc >> sh) & msk));
+        g_sti(cp + 1, __popcll((mtp >> sh) & msk));
+        g_sti(cp + 2, __popcll((mtn >> sh) & msk));
+        g_sti(cp + 3, __popcll((mfp >> sh) & msk));
+        g_sti(cp + 4, __popcll((mfn >> sh) & msk));
+    }
+    __syncthreads();
+}
+
+template <int RT>
+__global__ __launch_bounds__(NT) void k_gen_fwd(const DevPlan* __restrict__ P, mmn_batch b, float cL, int want_grads) {
+    constexpr int TB = 16 * RT;
+    extern __shared__ __attribute__((aligned(16))) float smem_generic[];
+    const lp smem = (lp)smem_generic;
+    const int ldS = P->ldS, ldH = P->ldH;
+    const ChainLds L = chain_lds(TB, ldS, ldH);
+    copy_plan_to_lds(P, smem + L.sPlan);
+    lp sS[2] = {smem + L.sS0, smem + L.sS1};
+    const lp sM = smem + L.sDiff;                          // masked state tile (MIMIC encoders under dropout)
+    lp sH[2] = {smem + L.sH0, smem + L.sH1};
+    const lp sX = smem + L.sX;
+    const lp sRed = smem + L.sRed;
+    const int tile = blockIdx.x;
+    const int row0 = tile * TB;
+    const int nrows = min(TB, b.batch - row0);
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    __syncthreads();
+    LPlan& p = *(LPlan*)(smem + L.sPlan);
+    const int S = p.S, E = p.E;
+
+    for (int idx = threadIdx.x; idx < TB * ldS; idx += NT) {
+        const int k = idx % ldS;
+        lds_st(sS[0] + idx, k < S ? g_ld(p.m.init_state + k) : 0.f);   // state.py:29-32 (tile, never materialised)
+        lds_st(sS[1] + idx, 0.f);
+        lds_st(sM + idx, 0.f);
+    }
+    for (int idx = threadIdx.x; idx < TB * ldH; idx += NT) { lds_st(sH[0] + idx, 0.f); lds_st(sH[1] + idx, 0.f); }
+    for (int idx = threadIdx.x; idx < TB * LDX; idx += NT) lds_st(sX + idx, 0.f);
+    for (int idx = threadIdx.x; idx < 4 * TB * 16; idx += NT) lds_st(smem + L.sZ + idx, 0.f);
+    if (tile == 0 && threadIdx.x == 0) {                   // which state rows exist this step
+        g_sti(p.exec_flags, 1);
+        for (int e = 0; e < E; ++e) g_sti(p.exec_flags + e + 1, 0);
+        int prev = 0;
+        for (int t = 0; t < b.n_seq; ++t) {
+            if (!slot_present(b, b.seq_data[t])) continue;
+            const int e = b.seq_enc[t];
+            g_sti(p.exec_flags + e + 1, 1);
+            g_sti(p.prev_row + e, prev);
+            prev = e + 1;
+        }
+    }
+    GenDecodeCtx dc;
+    dc.p = &p; dc.sZ = smem + L.sZ; dc.sH0 = sH[0]; dc.sH1 = sH[1];
+    dc.row0 = row0; dc.nrows = nrows; dc.tile = tile; dc.cL = cL; dc.want_grads = want_grads;
+    {
+        const int row = threadIdx.x & (TB - 1), d = threadIdx.x / TB;
+        const bool ok = d < p.D && row < nrows;
+        dc.y = ok ? (int)*(const MMN_AS1 int64_t*)(b.y + ((int64_t)row0 + row) * p.D + d) : 0;
+    }
+    __syncthreads();
+
+    int cur = 0;
+    gen_decode<RT>(dc, sS[cur], 0);
+
+    for (int tn = next_exec(b, 0); tn < b.n_seq; tn = next_exec(b, tn + 1)) {
+        const int slot = b.seq_data[tn], e = b.seq_enc[tn];
+        const auto& enc = p.m.enc[e];
+        const int nl = enc.n_layers, F = enc.n_features, akind = enc.activation;
+        const float* xg = b.x[slot] + (int64_t)row0 * b.ldx[slot];
+        const int64_t ldx = b.ldx[slot];
+        float scacc = 0.f;
+        const clp sC = sS[cur];
+        const lp sN = sS[cur ^ 1];
+        // epilogue of the layer that produces the new state (act_out: MIMIC applies the activation there too)
+        auto state_epi = [&](const float* bias, int act_out) {
+            return [&, bias, act_out](int row, int col, int, float v) {
+                if (col < S) {
+                    const float ns = act_fwd(v + g_ld(bias + col), act_out);
+                    const float dlt = ns - lds_ld(sC + row * ldS + col);
+                    if (row < nrows) scacc += dlt * dlt;              // multimodn.py:174
+                    lds_st(sN + row * ldS + col, ns);
+                }
+            };
+        };
+        if (enc.kind == MMN_ENC_MIMIC) {
+            // ---- layer 0 reads Dropout(cat[x, state]) (mlp_encoder.py:40-41)
+            const int FS = F + S;
+            const float* mk = b.drop_mask[e] ? b.drop_mask[e] + (int64_t)row0 * FS : nullptr;
+            clp sIn = sC;
+            if (mk || want_grads) {
+                float* xin = p.gact + p.xin_off[e] + (int64_t)row0 * FS;
+                for (int r = wave; r < TB; r += 4)
+                    for (int c = lane; c < FS; c += 64) {
+                        float v = 0.f;
+                        if (r < nrows) {
+                            v = c < F ? g_ld(xg + (int64_t)r * ldx + c) : lds_ld(sC + r * ldS + (c - F));
+                            if (mk) v *= g_ld(mk + (int64_t)r * FS + c);
+                            if (want_grads) g_st(xin + (int64_t)r * FS + c, v);
+                        }
+                        if (mk && c >= F) lds_st(sM + r * ldS + (c - F), v);
+                    }
+                if (mk) sIn = sM;
+                __syncthreads();
+            }
+            for (int l = 0; l < nl; ++l) {
+                const auto& lin = enc.layer[l];
+                const int N = lin.out_dim;
+                const bool last = l == nl - 1;
+                const lp out = sH[l & 1];
+                const float* bias = lin.b;
+                auto hid_epi = [&](int row, int col, int, float v) {
+                    if (col < N) lds_st(out + row * ldH + col, act_fwd(v + g_ld(bias + col), akind));
+                };
+                if (l == 0) {
+                    const PB B = make_pb(p.pack + p.pkf_off[e][0], N, S, F);           // state columns first in the pack
+                    if (last) layer_state_x<RT>(sIn, ldS, B, sX, xg, ldx, mk, FS, F, nrows, state_epi(bias, akind));
+                    else layer_state_x<RT>(sIn, ldS, B, sX, xg, ldx, mk, FS, F, nrows, hid_epi);
+                } else {
+                    const clp in = sH[(l - 1) & 1];
+                    const ASrc A{in, ldH, in, ldH};
+                    const PB B = make_pb(p.pack + p.pkf_off[e][l], N, lin.in_dim, 0);
+                    if (last) {
+                        auto se = state_epi(bias, akind);
+                        layer_nt<RT>(A, B, [&](int row, int col, float v) { se(row, col, 0, v); });
+                    } else {
+                        layer_nt<RT>(A, B, [&](int row, int col, float v) { hid_epi(row, col, 0, v); });
+                    }
+                }
+                __syncthreads();
+                if (!last && want_grads) store_rows(p.hid + p.hid_off[e][l] + (int64_t)row0 * N, out, ldH, nrows, N);
+            }
+        } else {
+            // ---- MLPEncoder (mlp_encoder.py:74-80): hidden layers on x only, then Linear(cat[h, state])
+            const int Lh = nl - 1;
+            const int HL = enc.layer[Lh].in_dim - S;
+            for (int l = 0; l < Lh; ++l) {
+                const auto& lin = enc.layer[l];
+                const int N = lin.out_dim;
+                const lp out = sH[(Lh - 1 - l) & 1];
+                const float* bias = lin.b;
+                auto epi = [&](int row, int col, int, float v) {
+                    if (col < N) lds_st(out + row * ldH + col, act_fwd(v + g_ld(bias + col), akind));
+                };
+                if (l == 0) {
+                    const PB B = make_pb(p.pack + p.pkf_off[e][0], N, 0, lin.in_dim);
+                    layer_state_x<RT>(sC, ldS, B, sX, xg, ldx, nullptr, 0, F, nrows, epi);
+                } else {
+                    const clp in = sH[(Lh - l) & 1];
+                    const ASrc A{in, ldH, in, ldH};
+                    const PB B = make_pb(p.pack + p.pkf_off[e][l], N, lin.in_dim, 0);
+                    layer_nt<RT>(A, B, [&](int row, int col, float v) { epi(row, col, 0, v); });
+                }
+                __syncthreads();
+                if (want_grads) store_rows(p.hid + p.hid_off[e][l] + (int64_t)row0 * N, out, ldH, nrows, N);
+            }
+            const float* bias = enc.layer[Lh].b;
+            const PB B = make_pb(p.pack + p.pkf_off[e][Lh], S, S, HL);
+            if (Lh > 0) {
+                const ASrc A{sC, ldS, sH[0], ldH};
+                auto se = state_epi(bias, MMN_ACT_IDENTITY);
+                layer_nt<RT>(A, B, [&](int row, int col, float v) { se(row, col, 0, v); });
+            } else {
+                layer_state_x<RT>(sC, ldS, B, sX, xg, ldx, nullptr, 0, F, nrows, state_epi(bias, MMN_ACT_IDENTITY));
+            }
+        }
+        scacc = wave_sum(scacc);
+        if (lane == 0) lds_st(sRed + wave, scacc);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            g_st(p.scp + (int64_t)tile * E + e, ((lds_ld(sRed) + lds_ld(sRed + 1)) + lds_ld(sRed + 2)) + lds_ld(sRed + 3));
+        store_rows(p.states + ((int64_t)e * p.maxB + row0) * S, sN, ldS, nrows, S);   // also forward-only: get_states()
+        cur ^= 1;
+        gen_decode<RT>(dc, sS[cur], e + 1);
+    }
+}
+
+// G += d loss / d state through all D decoders of one grid row; stores the hidden layers' dpre
+template <int RT>
+__device__ __forceinline__ void gen_decoder_back(LPlan& p, lp G, lp sDz, lp sDd, lp sH0, lp sH1, int grid_row, int row0,
+                                                 int nrows) {
+    constexpr int TB = 16 * RT;
+    const int ldS = p.ldS, ldH = p.ldH, S = p.S, D = p.D;
+    load_dz_tile<TB>(p, sDz, grid_row, row0, nrows);
+    __syncthreads();
+    for (int d = 0; d < D; ++d) {
+        const auto& dec = p.m.dec[d];
+        const int nh = dec.n_hidden, hk = dec.hidden_activation;
+        for (int idx = threadIdx.x; idx < TB * 2; idx += NT) {        // this decoder's dz pair -> columns 0, 1 of its own tile
+            const int row = idx >> 1, c = idx & 1;
+            lds_st(sDd + row * LDZ + c, lds_ld(sDz + row * LDZ + 2 * d + c));
+        }
+        __syncthreads();
+        const ASrc Ad{sDd, LDZ, sDd, LDZ};
+        if (nh == 0) {
+            const PB B = make_pb(p.pack + p.pkdb_off[d][0], S, 2, 0);                 // W_f^T [S x 2]
+            layer_nt<RT>(Ad, B, [&](int row, int col, float v) {
+                if (col < S) lds_st(G + row * ldS + col, lds_ld(G + row * ldS + col) + v);
+            });
+            __syncthreads();
+            continue;
+        }
+        lp cbuf = sH0, nbuf = sH1;
+        {
+            const int Hl = dec.hidden[nh - 1].out_dim;
+            const PB B = make_pb(p.pack + p.pkdb_off[d][nh], Hl, 2, 0);               // W_f^T [H_last x 2]
+            layer_nt<RT>(Ad, B, [&](int row, int col, float v) {
+                if (col < Hl) lds_st(cbuf + row * ldH + col, v);
+            });
+            __syncthreads();
+        }
+        for (int l = nh - 1; l >= 0; --l) {
+            const int Hl = dec.hidden[l].out_dim, Kin = dec.hidden[l].in_dim;
+            const int64_t off = (int64_t)grid_row * p.dh_row_stride + p.dh_off[d][l] + (int64_t)row0 * Hl;
+            apply_act_grad(cbuf, ldH, p.gact + p.dh_base + off, p.gdpre + off, nrows, TB, Hl, hk);
+            __syncthreads();
+            const ASrc A{cbuf, ldH, cbuf, ldH};
+            const PB B = make_pb(p.pack + p.pkdb_off[d][l], Kin, Hl, 0);              // W_l^T [in x out]
+            if (l == 0) {
+                layer_nt<RT>(A, B, [&](int row, int col, float v) {
+                    if (col < S) lds_st(G + row * ldS + col, lds_ld(G + row * ldS + col) + v);
+                });
+            } else {
+                layer_nt<RT>(A, B, [&](int row, int col, float v) {
+                    if (col < Kin) lds_st(nbuf + row * ldH + col, v);
+                });
+                const lp t = cbuf; cbuf = nbuf; nbuf = t;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int RT>
+__global__ __launch_bounds__(NT) void k_gen_bwd(const DevPlan* __restrict__ P, mmn_batch b, float cS) {
+    constexpr int TB = 16 * RT;
+    extern __shared__ __attribute__((aligned(16))) float smem_generic[];
+    const lp smem = (lp)smem_generic;
+    const int ldS = P->ldS, ldH = P->ldH;
+    const ChainLds L = chain_lds(TB, ldS, ldH);
+    copy_plan_to_lds(P, smem + L.sPlan);
+    __syncthreads();
+    LPlan& p = *(LPlan*)(smem + L.sPlan);
+    const int S = p.S, E = p.E;
+    lp sG[2] = {smem + L.sS0, smem + L.sS1};
+    const lp sDiff = smem + L.sDiff;
+    lp sH[2] = {smem + L.sH0, smem + L.sH1};
+    const lp sDz = smem + L.sZ;
+    const lp sDd = smem + L.sX;                            // one decoder's dz pair, [TB x LDZ]
+    const int tile = blockIdx.x;
+    const int row0 = tile * TB;
+    const int nrows = min(TB, b.batch - row0);
+    const int lane = threadIdx.x & 63, wave = wave_id();
+
+    for (int idx = threadIdx.x; idx < TB * ldS; idx += NT) { lds_st(sG[0] + idx, 0.f); lds_st(sG[1] + idx, 0.f); lds_st(sDiff + idx, 0.f); }
+    for (int idx = threadIdx.x; idx < TB * ldH; idx += NT) { lds_st(sH[0] + idx, 0.f); lds_st(sH[1] + idx, 0.f); }
+    for (int idx = threadIdx.x; idx < 4 * TB * 16; idx += NT) lds_st(sDz + idx, 0.f);
+    for (int idx = threadIdx.x; idx < TB * LDX; idx += NT) lds_st(sDd + idx, 0.f);
+    __syncthreads();
+    int cur = 0;
+
+    for (int t = b.n_seq - 1; t >= 0; --t) {
+        const int slot = b.seq_data[t];
+        if (!slot_present(b, slot)) continue;
+        const int e = b.seq_enc[t];
+        int tp = t - 1;
+        while (tp >= 0 && !slot_present(b, b.seq_data[tp])) --tp;
+        const int prev_row = tp >= 0 ? b.seq_enc[tp] + 1 : 0;
+        const auto& enc = p.m.enc[e];
+        const int nl = enc.n_layers, F = enc.n_features, akind = enc.activation;
+        const lp G = sG[cur];
+        const lp Gn = sG[cur ^ 1];
+        // diff = s_out - s_in
+        {
+            const float* so = p.states + ((int64_t)e * p.maxB + row0) * S;
+            const float* si = prev_row ? p.states + ((int64_t)(prev_row - 1) * p.maxB + row0) * S : nullptr;
+            for (int r = wave; r < nrows; r += 4)
+                for (int c = lane; c < S; c += 64) {
+                    const float a = g_ld(so + (int64_t)r * S + c);
+                    const float d = si ? g_ld(si + (int64_t)r * S + c) : g_ld(p.m.init_state + c);
+                    lds_st(sDiff + r * ldS + c, a - d);
+                }
+        }
+        // G_out = carry + decoder grads of row e+1 + cS * diff
+        gen_decoder_back<RT>(p, G, sDz, sDd, sH[0], sH[1], e + 1, row0, nrows);
+        for (int r = wave; r < TB; r += 4)
+            for (int c = lane; c < S; c += 64) lds_st(G + r * ldS + c, lds_ld(G + r * ldS + c) + cS * lds_ld(sDiff + r * ldS + c));
+        __syncthreads();
+        if (enc.kind == MMN_ENC_MIMIC) {
+            const int FS = F + S;
+            const float* mk = b.drop_mask[e] ? b.drop_mask[e] + (int64_t)row0 * FS + F : nullptr;   // the state columns
+            // the state layer carries the activation too: dpre_last = G .* act'(s_out); that is what k_wgrad multiplies
+            apply_act_grad(G, ldS, p.states + ((int64_t)e * p.maxB + row0) * S, p.dS + ((int64_t)e * p.maxB + row0) * S,
+                           nrows, TB, S, akind);
+            __syncthreads();
+            clp cbuf = G; int ldc = ldS;
+            for (int l = nl - 1; l >= 1; --l) {
+                const int Hl = enc.layer[l].out_dim, Hp = enc.layer[l].in_dim;
+                const lp nbuf = sH[l & 1];
+                const ASrc A{cbuf, ldc, cbuf, ldc};
+                const PB B = make_pb(p.pack + p.pkb_off[e][l], Hp, Hl, 0);            // W_l^T [in x out]
+                layer_nt<RT>(A, B, [&](int row, int col, float v) {
+                    if (col < Hp) lds_st(nbuf + row * ldH + col, v);
+                });
+                __syncthreads();
+                apply_act_grad(nbuf, ldH, p.hid + p.hid_off[e][l - 1] + (int64_t)row0 * Hp,
+                               p.dpre + p.hid_off[e][l - 1] + (int64_t)row0 * Hp, nrows, TB, Hp, akind);
+                __syncthreads();
+                cbuf = nbuf; ldc = ldH;
+            }
+            // carry = (dpre_0 * W_0[:, F:F+S]) .* mask_state - cS * diff ; no grad flows to x
+            const int H0 = enc.layer[0].out_dim;
+            const ASrc A{cbuf, ldc, cbuf, ldc};
+            const PB B = make_pb(p.pack + p.pkb_off[e][0], S, H0, 0);
+            layer_nt<RT>(A, B, [&](int row, int col, float v) {
+                if (col < S) {
+                    const float m = (mk && row < nrows) ? g_ld(mk + (int64_t)row * FS + col) : 1.0f;
+                    lds_st(Gn + row * ldS + col, v * m - cS * lds_ld(sDiff + row * ldS + col));
+                }
+            });
+            __syncthreads();
+        } else {
+            const int Lh = nl - 1;
+            const int HL = enc.layer[nl - 1].in_dim - S;
+            store_rows(p.dS + ((int64_t)e * p.maxB + row0) * S, G, ldS, nrows, S);
+            {
+                const ASrc A{G, ldS, G, ldS};
+                const lp dh = sH[0];
+                if (Lh > 0) {
+                    const PB Bh = make_pb(p.pack + p.pkh_off[e], HL, S, 0);
+                    layer_nt<RT>(A, Bh, [&](int row, int col, float v) {
+                        if (col < HL) lds_st(dh + row * ldH + col, v);
+                    });
+                }
+                const PB Bc = make_pb(p.pack + p.pkb_off[e][nl - 1], S, S, 0);
+                layer_nt<RT>(A, Bc, [&](int row, int col, float v) {
+                    if (col < S) lds_st(Gn + row * ldS + col, v - cS * lds_ld(sDiff + row * ldS + col));
+                });
+            }
+            __syncthreads();
+            for (int l = Lh - 1; l >= 0; --l) {
+                const int Hl = enc.layer[l].out_dim;
+                const lp cbuf = sH[(Lh - 1 - l) & 1];
+                apply_act_grad(cbuf, ldH, p.hid + p.hid_off[e][l] + (int64_t)row0 * Hl,
+                               p.dpre + p.hid_off[e][l] + (int64_t)row0 * Hl, nrows, TB, Hl, akind);
+                __syncthreads();
+                if (l == 0) break;
+                const int Hp = enc.layer[l].in_dim;
+                const lp nbuf = sH[(Lh - l) & 1];
+                const ASrc A{cbuf, ldH, cbuf, ldH};
+                const PB B = make_pb(p.pack + p.pkb_off[e][l], Hp, Hl, 0);
+                layer_nt<RT>(A, B, [&](int row, int col, float v) {
+                    if (col < Hp) lds_st(nbuf + row * ldH + col, v);
+                });
+                __syncthreads();
+            }
+        }
+        cur ^= 1;
+    }
+    // row 0: decoders on the init state; dS0 = d loss / d tiled init state
+    const lp G = sG[cur];
+    gen_decoder_back<RT>(p, G, sDz, sDd, sH[0], sH[1], 0, row0, nrows);
     store_rows(p.dS + ((int64_t)E * p.maxB + row0) * S, G, ldS, nrows, S);
 }
 
@@ -3159,7 +3685,7 @@ __global__ __launch_bounds__(NT) void k_wgrad(const WgArgs w, const mmn_batch b)
     int rb = it.ks * rows_per_split, re = min(b.batch, rb + rows_per_split);
     const bool tiled = b.tile_seq != nullptr;              // per-sample mode: dead rows are zero in A, no gating
     if ((!tiled && !row_executed(b, pm, it.gate)) || rb >= re) { rb = 0; re = 0; }   // writes zeros
-    const float* Ap = (it.a_kind == A_DPRE ? w.dpre : (it.a_kind == A_DS ? w.dS : w.dz)) + it.a_off;
+    const float* Ap = (it.a_kind == A_DPRE ? w.dpre : (it.a_kind == A_DS ? w.dS : (it.a_kind == A_DZ ? w.dz : w.gdpre))) + it.a_off;
     SrcRef in{nullptr, 0};
     switch (it.in_kind) {
         case IN_X: {
@@ -3171,6 +3697,7 @@ __global__ __launch_bounds__(NT) void k_wgrad(const WgArgs w, const mmn_batch b)
         case IN_HID: in.p = w.hid + it.in_off; in.ld = it.ldi; break;
         case IN_STATE_ROW: in.p = w.states + it.in_off; in.ld = it.ldi; break;
         case IN_INIT: in.p = w.init; in.ld = 0; break;
+        case IN_GEN: in.p = w.gact + it.in_off; in.ld = it.ldi; break;
         case IN_PREV_STATE: {
             if (tiled) { in.p = w.sin + (int64_t)it.in_enc * w.maxB * w.S; in.ld = w.S; break; }
             const int r = prev_row_of(b, pm, it.in_enc);
@@ -3528,7 +4055,7 @@ __device__ __forceinline__ void epoch_apply(const PlanLike& p, const float* st, 
 }
 
 constexpr int NTR = 1024;     // k_reduce block size
-constexpr int MAXSEG = 2 * MMN_MAX_ENCODERS * MMN_MAX_LAYERS + 1 + 2 * MMN_MAX_DECODERS;
+constexpr int MAXSEG = 2 * MMN_MAX_ENCODERS * MMN_MAX_LAYERS + 1 + 2 * MMN_MAX_DECODERS * (MMN_MAX_DEC_HIDDEN + 1);
 static_assert(MAXSEG <= ADAM_MAX_SEG, "k_reduce's fused Adam shares the segment tables");
 static_assert(NTR == 4 * ADAM_NT, "k_reduce and k_adam must use the same number of workgroups (step-counter rows)");
 
@@ -3754,6 +4281,7 @@ struct mmn_plan {
     int f8_ok, fb8_ok;
     int grad_blocks;
     int rt_override;
+    int generic;             // k_gen_fwd / k_gen_bwd (a MIMIC_MLPEncoder or an MLPDecoder in the model)
 };
 
 static thread_local int g_last_hip = 0;
@@ -3772,17 +4300,39 @@ static int validate_model(const mmn_model* m) {
         const mmn_encoder& enc = m->enc[e];
         if (enc.n_layers < 1 || enc.n_layers > MMN_MAX_LAYERS || enc.n_features < 1) return MMN_ERR_ARG;
         if (enc.activation < 0 || enc.activation > 2) return MMN_ERR_UNSUPPORTED;
-        int in = enc.n_features;
+        if (enc.kind != MMN_ENC_MLP && enc.kind != MMN_ENC_MIMIC) return MMN_ERR_UNSUPPORTED;
+        const bool mimic = enc.kind == MMN_ENC_MIMIC;
+        int in = enc.n_features + (mimic ? m->state_size : 0);      // mlp_encoder.py:22 (n_concat)
         for (int l = 0; l < enc.n_layers; ++l) {
             const mmn_linear& lin = enc.layer[l];
             const bool last = l == enc.n_layers - 1;
-            if (lin.in_dim != in + (last ? m->state_size : 0)) return MMN_ERR_ARG;
+            if (lin.in_dim != in + (last && !mimic ? m->state_size : 0)) return MMN_ERR_ARG;
             if (lin.out_dim < 1 || (last && lin.out_dim != m->state_size)) return MMN_ERR_ARG;
             if (!last && lin.out_dim > MMN_MAX_DIM) return MMN_ERR_UNSUPPORTED;
             in = lin.out_dim;
         }
     }
+    for (int d = 0; d < m->n_decoders; ++d) {
+        const mmn_decoder& dec = m->dec[d];
+        if (dec.n_hidden < 0 || dec.n_hidden > MMN_MAX_DEC_HIDDEN) return MMN_ERR_UNSUPPORTED;
+        if (dec.n_hidden > 0 && (dec.hidden_activation < 0 || dec.hidden_activation > 2)) return MMN_ERR_UNSUPPORTED;
+        int in = m->state_size;
+        for (int l = 0; l < dec.n_hidden; ++l) {
+            const mmn_linear& lin = dec.hidden[l];
+            if (lin.in_dim != in || lin.out_dim < 1) return MMN_ERR_ARG;
+            if (lin.out_dim > MMN_MAX_DIM) return MMN_ERR_UNSUPPORTED;
+            in = lin.out_dim;
+        }
+    }
     return MMN_OK;
+}
+
+// models the sequential / parallel / 8-wave tiers do not cover go to k_gen_fwd / k_gen_bwd
+static bool model_is_generic(const mmn_model& m) {
+    if (const char* g = getenv("MMN_GENERIC")) { if (atoi(g)) return true; }
+    for (int e = 0; e < m.n_encoders; ++e) if (m.enc[e].kind == MMN_ENC_MIMIC) return true;
+    for (int d = 0; d < m.n_decoders; ++d) if (m.dec[d].n_hidden > 0) return true;
+    return false;
 }
 
 namespace {
@@ -3802,6 +4352,14 @@ struct Layout {
     std::vector<PackTask> ptasks;   // dst = offset until plan creation patches in the workspace address
     int64_t slab_floats, n_grad_elems, nA, nB;
     int KS, max_tiles, ldS, ldH;
+    // generic tier
+    int generic;
+    size_t off_gact, off_gdpre;
+    int64_t xin_off[MMN_MAX_ENCODERS];
+    int64_t dh_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN];
+    int64_t dh_row_stride, dh_base, gact_floats, gdpre_floats;
+    int64_t pkdf_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];
+    int64_t pkdb_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -3828,6 +4386,28 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
             maxh = maxh > m.enc[e].layer[l].out_dim ? maxh : m.enc[e].layer[l].out_dim;
         }
     L.hid_floats = ho;
+    L.generic = model_is_generic(m) ? 1 : 0;
+    // generic tier buffers: xin[e] for MIMIC encoders, then per grid row the decoders' hidden activations
+    {
+        int64_t go = 0;
+        for (int e = 0; e < MMN_MAX_ENCODERS; ++e) L.xin_off[e] = -1;
+        memset(L.dh_off, 0, sizeof(L.dh_off));
+        if (L.generic)
+            for (int e = 0; e < E; ++e)
+                if (m.enc[e].kind == MMN_ENC_MIMIC) { L.xin_off[e] = go; go += (int64_t)maxB * (m.enc[e].n_features + S); }
+        L.dh_base = go;
+        int64_t ro = 0;
+        if (L.generic)
+            for (int d = 0; d < D; ++d)
+                for (int l = 0; l < m.dec[d].n_hidden; ++l) {
+                    L.dh_off[d][l] = ro;
+                    ro += (int64_t)maxB * m.dec[d].hidden[l].out_dim;
+                    maxh = maxh > m.dec[d].hidden[l].out_dim ? maxh : m.dec[d].hidden[l].out_dim;
+                }
+        L.dh_row_stride = ro;
+        L.gact_floats = go + ro * R;
+        L.gdpre_floats = ro * R;
+    }
     L.ldH = pick_ld(maxh);
 
     // ---- fragment-order repack of every operand of the two chain kernels
@@ -3845,6 +4425,22 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     };
     for (int e = 0; e < E; ++e) {
         const int nl = m.enc[e].n_layers;
+        if (m.enc[e].kind == MMN_ENC_MIMIC) {
+            // MIMIC_MLPEncoder: layer 0 contracts [state columns F..F+S) first, then the x columns]; its backward
+            // operand is the carry W_0[:, F:F+S]^T (no grad flows to x); every further layer is plain W / W^T
+            const int F = m.enc[e].n_features;
+            L.pkh_off[e] = -1;
+            for (int l = 0; l < nl; ++l) {
+                const mmn_linear& lin = m.enc[e].layer[l];
+                L.pkf_off[e][l] = po;
+                po += l == 0 ? add_pack(lin.w, lin.in_dim, 0, lin.out_dim, S, F, F, 0, 0, 0, po)
+                             : add_pack(lin.w, lin.in_dim, 0, lin.out_dim, lin.in_dim, 0, 0, 0, 0, 0, po);
+                L.pkb_off[e][l] = po;
+                po += l == 0 ? add_pack(lin.w + F, lin.in_dim, 1, S, lin.out_dim, 0, 0, 0, 0, 0, po)
+                             : add_pack(lin.w, lin.in_dim, 1, lin.in_dim, lin.out_dim, 0, 0, 0, 0, 0, po);
+            }
+            continue;
+        }
         for (int l = 0; l < nl; ++l) {
             const mmn_linear& lin = m.enc[e].layer[l];
             const bool last = l == nl - 1;
@@ -3876,6 +4472,26 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
         for (int d = 0; d < D; ++d) sz = add_pack(m.dec[d].w, S, 1, S, 2, 0, 0, 0, 2 * d, 1, po);
         po += sz;
     }
+    memset(L.pkdf_off, 0, sizeof(L.pkdf_off));
+    memset(L.pkdb_off, 0, sizeof(L.pkdb_off));
+    if (L.generic) {                                       // per-decoder operands of the generic tier
+        for (int d = 0; d < D; ++d) {
+            const mmn_decoder& dec = m.dec[d];
+            int in = S;
+            for (int l = 0; l < dec.n_hidden; ++l) {
+                const mmn_linear& lin = dec.hidden[l];
+                L.pkdf_off[d][l] = po;
+                po += add_pack(lin.w, lin.in_dim, 0, lin.out_dim, lin.in_dim, 0, 0, 0, 0, 0, po);
+                L.pkdb_off[d][l] = po;
+                po += add_pack(lin.w, lin.in_dim, 1, lin.in_dim, lin.out_dim, 0, 0, 0, 0, 0, po);
+                in = lin.out_dim;
+            }
+            L.pkdf_off[d][dec.n_hidden] = po;              // output Linear [2 x in]
+            po += add_pack(dec.w, in, 0, 2, in, 0, 0, 0, 0, 0, po);
+            L.pkdb_off[d][dec.n_hidden] = po;              // its transpose [in x 2]
+            po += add_pack(dec.w, in, 1, in, 2, 0, 0, 0, 0, 0, po);
+        }
+    }
     L.pack_floats = po;
     L.pack_elems = L.ptasks.back().start + (int64_t)L.ptasks.back().ntiles * L.ptasks.back().T * 256;
 
@@ -3884,6 +4500,17 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     // flat gradient order = init state, encoders (layer by layer: weight, bias), decoders (weight, bias):
     // region A = everything before the decoders (ks partials per element), region B = decoders (R * ks)
     int64_t nA = S, nB = (int64_t)D * (2 * S + 2);
+    if (L.generic) {
+        nB = 0;
+        for (int d = 0; d < D; ++d) {
+            int in = S;
+            for (int l = 0; l < m.dec[d].n_hidden; ++l) {
+                nB += (int64_t)m.dec[d].hidden[l].out_dim * (m.dec[d].hidden[l].in_dim + 1);
+                in = m.dec[d].hidden[l].out_dim;
+            }
+            nB += 2 * (in + 1);
+        }
+    }
     for (int e = 0; e < E; ++e)
         for (int l = 0; l < m.enc[e].n_layers; ++l)
             nA += (int64_t)m.enc[e].layer[l].out_dim * m.enc[e].layer[l].in_dim + m.enc[e].layer[l].out_dim;
@@ -3934,6 +4561,11 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
             t.k0 = last ? lin.in_dim - S : lin.in_dim;
             t.in1_kind = last ? IN_PREV_STATE : IN_NONE;
             t.k1 = last ? S : 0;
+            const bool mimic = enc.kind == MMN_ENC_MIMIC;
+            if (mimic) {       // every layer has ONE input: xin[e] = (masked) cat[x, state] for layer 0, else the previous output
+                t.k0 = lin.in_dim; t.in1_kind = IN_NONE; t.k1 = 0;
+                if (l == 0) { t.in0_kind = IN_GEN; t.in_gen_off = L.xin_off[e]; t.gen_ldi = lin.in_dim; }
+            }
             t.bias = 1; t.ntot = lin.in_dim + 1; t.gate = e + 1;
             t.part_base = 0; t.part_stride = nA; t.w_ld = lin.in_dim; t.dec_stride = 0;
             t.w_flat = gstart; t.b_flat = gstart + (int64_t)lin.out_dim * lin.in_dim;
@@ -3942,11 +4574,52 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
             // (doubling the row-range splits for the big state-update tiles was measured slower: every
             // extra work item costs ~5 us of fixed prologue/epilogue)
             add_items(id, t.M, 0, t.k0, true, ks);
-            if (last) add_items(id, t.M, 1, t.k1, false, ks);
+            if (last && !mimic) add_items(id, t.M, 1, t.k1, false, ks);
             add_seg(lin.gw, lin.out_dim * lin.in_dim, e + 1);
             add_seg(lin.gb, lin.out_dim, e + 1);
         }
     }
+    if (L.generic) {
+        // generic tier: one task per (grid row, decoder, layer); region B holds the decoders' parameters in flat order
+        // (hidden layers first, the output Linear last), R * ks partials per element
+        for (int r = 0; r < R; ++r) {
+            int64_t fo = 0;
+            for (int d = 0; d < D; ++d) {
+                const mmn_decoder& dec = m.dec[d];
+                const int nh = dec.n_hidden;
+                for (int l = 0; l <= nh; ++l) {
+                    const bool out_layer = l == nh;
+                    const int odim = out_layer ? 2 : dec.hidden[l].out_dim;
+                    const int idim = l == 0 ? S : dec.hidden[l - 1].out_dim;
+                    WTask t{};
+                    t.M = odim;
+                    if (out_layer) { t.a_kind = A_DZ; t.a_idx = r; t.a_col = 2 * d; }
+                    else { t.a_kind = A_GEN; t.a_gen_off = (int64_t)r * L.dh_row_stride + L.dh_off[d][l]; t.gen_lda = odim; }
+                    if (l == 0) { t.in0_kind = IN_STATE_ROW; t.in0_idx = r; }
+                    else { t.in0_kind = IN_GEN; t.in_gen_off = L.dh_base + (int64_t)r * L.dh_row_stride + L.dh_off[d][l - 1]; t.gen_ldi = idim; }
+                    t.k0 = idim; t.in1_kind = IN_NONE; t.k1 = 0;
+                    t.bias = 1; t.ntot = idim + 1; t.gate = r;
+                    t.part_base = nA * ks + (int64_t)r * ks * nB; t.part_stride = nB;
+                    t.w_flat = fo; t.b_flat = fo + (int64_t)odim * idim; t.w_ld = idim; t.dec_stride = 0;
+                    fo += (int64_t)odim * (idim + 1);
+                    const int id = (int)L.tasks.size();
+                    L.tasks.push_back(t);
+                    add_items(id, t.M, 0, t.k0, true, ks);
+                }
+            }
+        }
+        for (int d = 0; d < D; ++d) {
+            const mmn_decoder& dec = m.dec[d];
+            int in = S;
+            for (int l = 0; l < dec.n_hidden; ++l) {
+                add_seg(dec.hidden[l].gw, dec.hidden[l].out_dim * dec.hidden[l].in_dim, 0);
+                add_seg(dec.hidden[l].gb, dec.hidden[l].out_dim, 0);
+                in = dec.hidden[l].out_dim;
+            }
+            add_seg(dec.gw, 2 * in, 0);
+            add_seg(dec.gb, 2, 0);
+        }
+    } else
     // decoders: one task per grid row, all rows share one output of [2D x (S+1)] x (R*ks) partials
     {
         for (int r = 0; r < R; ++r) {
@@ -3995,13 +4668,15 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
         r.a_kind = t.a_kind;
         if (t.a_kind == A_DPRE) { r.a_off = L.hid_off[t.a_enc][t.a_idx]; r.lda = t.M; }
         else if (t.a_kind == A_DS) { r.a_off = (int64_t)t.a_idx * maxB * S; r.lda = S; }
-        else { r.a_off = (int64_t)t.a_idx * maxB * (2 * D); r.lda = 2 * D; }
+        else if (t.a_kind == A_GEN) { r.a_off = t.a_gen_off; r.lda = t.gen_lda; }
+        else { r.a_off = (int64_t)t.a_idx * maxB * (2 * D) + t.a_col; r.lda = 2 * D; }
         r.M = t.M; r.m0 = it.m0; r.n0 = it.n0; r.mt = it.mt; r.nt = it.nt; r.bias = it.bias; r.ks = it.ks;
         r.has_in = it.src != 2 ? 1 : 0;
         const int kind = it.src == 0 ? t.in0_kind : (it.src == 1 ? t.in1_kind : IN_NONE);
         r.in_kind = kind; r.in_enc = t.in0_enc; r.in_off = 0; r.ldi = 0;
         r.ncols = it.src == 0 ? t.k0 : (it.src == 1 ? t.k1 : 0);
         if (kind == IN_HID) { r.in_off = L.hid_off[t.in0_enc][t.in0_idx]; r.ldi = m.enc[t.in0_enc].layer[t.in0_idx].out_dim; }
+        else if (kind == IN_GEN) { r.in_off = t.in_gen_off; r.ldi = t.gen_ldi; }
         else if (kind == IN_STATE_ROW) {
             if (t.in0_idx == 0) r.in_kind = IN_INIT;
             else { r.in_off = (int64_t)(t.in0_idx - 1) * maxB * S; r.ldi = S; }
@@ -4038,6 +4713,8 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     L.off_recs = take(sizeof(WRec) * L.items.size());
     L.off_sin = take(sizeof(float) * (size_t)E * maxB * S);
     L.off_ps = take(sizeof(int32_t) * 3 * (size_t)maxB);      // per-sample regrouping scratch: codes, masks, source rows
+    L.off_gact = take(sizeof(float) * (size_t)L.gact_floats);
+    L.off_gdpre = take(sizeof(float) * (size_t)L.gdpre_floats);
     L.total = o;
 }
 
@@ -4147,8 +4824,18 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     h.n_grad_elems = L.n_grad_elems;
     h.n_pack_elems = L.pack_elems;
     for (PackTask& t : L.ptasks) t.dst = h.pack + reinterpret_cast<intptr_t>(t.dst);   // offset -> address
+    h.generic = L.generic;
+    h.gact = reinterpret_cast<float*>(ws + L.off_gact);
+    h.gdpre = reinterpret_cast<float*>(ws + L.off_gdpre);
+    memcpy(h.xin_off, L.xin_off, sizeof(h.xin_off));
+    memcpy(h.dh_off, L.dh_off, sizeof(h.dh_off));
+    h.dh_row_stride = L.dh_row_stride; h.dh_base = L.dh_base;
+    memcpy(h.pkdf_off, L.pkdf_off, sizeof(h.pkdf_off));
+    memcpy(h.pkdb_off, L.pkdb_off, sizeof(h.pkdb_off));
+    pl->generic = L.generic;
     pl->dev = reinterpret_cast<DevPlan*>(ws + L.off_plan);
-    pl->wg = WgArgs{h.recs, h.dpre, h.dS, h.dz, h.states, h.hid, m->init_state, h.slabs, h.stamps, h.sin, h.maxB, h.S};
+    pl->wg = WgArgs{h.recs, h.dpre, h.dS, h.dz, h.states, h.hid, m->init_state, h.slabs, h.stamps, h.sin, h.maxB, h.S,
+                    h.gact, h.gdpre};
     pl->rd = RdArgs{h.segs, h.slabs, h.lossp, h.scp, h.cnt, h.exec_flags, h.stats, h.epoch, L.n_grad_elems,
                     (int32_t)L.segs.size(), h.R, h.D, h.E, h.S, 0, L.nA, L.nB, h.KS, h.R * h.KS};
     pl->segs = L.segs;
@@ -4166,6 +4853,7 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
         ok = ok && pl->par_lds_fwd <= 160 * 1024 && pl->par_lds_bwd <= 160 * 1024;
         const char* pe = getenv("MMN_PAR");
         if (pe && atoi(pe) == 0) ok = false;
+        if (L.generic) ok = false;                         // the other tiers know MLPEncoder + ClassDecoder only
         pl->par_ok = ok ? 1 : 0;
         h.par_ok = pl->par_ok;
         if (getenv("MMN_VERBOSE"))
@@ -4241,6 +4929,18 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     // activations / gradient operands start finite: per-sample mode multiplies rows nobody wrote by zero rows
     if ((e = hipMemset(h.states, 0, L.off_pack - L.off_states)) != hipSuccess) return fail(e);
     if ((e = hipMemset(h.sin, 0, sizeof(float) * (size_t)h.E * h.maxB * h.S)) != hipSuccess) return fail(e);
+    if (L.gact_floats && (e = hipMemset(h.gact, 0, sizeof(float) * (size_t)L.gact_floats)) != hipSuccess) return fail(e);
+    if (L.gdpre_floats && (e = hipMemset(h.gdpre, 0, sizeof(float) * (size_t)L.gdpre_floats)) != hipSuccess) return fail(e);
+    if (L.generic) {
+        const void* gf[4] = {reinterpret_cast<const void*>(k_gen_fwd<1>), reinterpret_cast<const void*>(k_gen_fwd<2>),
+                             reinterpret_cast<const void*>(k_gen_bwd<1>), reinterpret_cast<const void*>(k_gen_bwd<2>)};
+        for (int k = 0; k < 4; ++k) {
+            const size_t need = pl->lds_bytes[1 + (k & 1)];
+            if (need <= 160 * 1024 &&
+                (e = hipFuncSetAttribute(gf[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)) != hipSuccess)
+                return fail(e);
+        }
+    }
     const void* fns[4] = {reinterpret_cast<const void*>(k_chain_fwd<1>), reinterpret_cast<const void*>(k_chain_fwd<2>),
                           reinterpret_cast<const void*>(k_chain_bwd<1>), reinterpret_cast<const void*>(k_chain_bwd<2>)};
     for (int k = 0; k < 4; ++k) {
@@ -4294,6 +4994,8 @@ static int check_batch(const mmn_plan* p, const mmn_batch* b) {
         seen_e |= 1u << e; seen_k |= 1u << k;
         if (!b->x[k] || b->ldx[k] < p->m.enc[e].n_features) return MMN_ERR_ARG;
     }
+    for (int e = 0; e < MMN_MAX_ENCODERS; ++e)             // dropout multipliers exist for MIMIC encoders only
+        if (b->drop_mask[e] && (e >= p->m.n_encoders || p->m.enc[e].kind != MMN_ENC_MIMIC)) return MMN_ERR_ARG;
     if (b->tile_seq || b->tile_rows) {                     // per-sample mode
         if (!b->tile_seq || !b->tile_rows || b->nan_flags) return MMN_ERR_ARG;
         if ((b->batch & 15) != 0 || b->n_seq != p->m.n_encoders) return MMN_ERR_ARG;
@@ -4327,6 +5029,7 @@ static int rt_for(const mmn_plan* p, const mmn_batch* b) {
 const char* mmn_chain_kernel_name(mmn_plan* p, const mmn_batch* b, int backward) {
     if (!p || !b) return "";
     if (backward == 2) return use_fb8(p, b) ? "k_fb8" : "";
+    if (p->generic) return backward ? "k_gen_bwd" : "k_gen_fwd";
     if (use_fast8(p, b)) return backward ? "k_bwd8" : "k_fwd8";
     if (p->par_ok) return backward ? "k_chain_bwd_par" : "k_chain_fwd_par";
     return backward ? "k_chain_bwd" : "k_chain_fwd";
@@ -4366,7 +5069,10 @@ int mmn_chain_fwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float sc_p
     const float cL = err_penalty / ((float)p->m.n_decoders * (float)(p->m.n_encoders + 1) * (float)b->batch_global);
     mmn_batch bb = *b;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (use_fast8(p, b)) hipLaunchKernelGGL(k_fwd8, dim3(tiles), dim3(NT8), p->f8_lds_fwd, st, p->pa, bb, cL, want_grads);
+    if (p->generic) {
+        if (rt == 1) hipLaunchKernelGGL(k_gen_fwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cL, want_grads);
+        else hipLaunchKernelGGL(k_gen_fwd<2>, dim3(tiles), dim3(NT), p->lds_bytes[2], st, p->dev, bb, cL, want_grads);
+    } else if (use_fast8(p, b)) hipLaunchKernelGGL(k_fwd8, dim3(tiles), dim3(NT8), p->f8_lds_fwd, st, p->pa, bb, cL, want_grads);
     else if (p->par_ok) hipLaunchKernelGGL(k_chain_fwd_par, dim3(tiles), dim3(NT), p->par_lds_fwd, st, p->dev, bb, cL, want_grads);
     else if (rt == 1) hipLaunchKernelGGL(k_chain_fwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cL, want_grads);
     else hipLaunchKernelGGL(k_chain_fwd<2>, dim3(tiles), dim3(NT), p->lds_bytes[2], st, p->dev, bb, cL, want_grads);
@@ -4387,7 +5093,10 @@ int mmn_chain_bwd(mmn_plan* p, const mmn_batch* b, float sc_pen_x001, void* stre
     mmn_batch bb = *b;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float cS = sc_coeff(p, b, sc_pen_x001);
-    if (use_fast8(p, b)) hipLaunchKernelGGL(k_bwd8, dim3(tiles), dim3(NT8), p->f8_lds_bwd, st, p->pa, bb, cS);
+    if (p->generic) {
+        if (rt == 1) hipLaunchKernelGGL(k_gen_bwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cS);
+        else hipLaunchKernelGGL(k_gen_bwd<2>, dim3(tiles), dim3(NT), p->lds_bytes[2], st, p->dev, bb, cS);
+    } else if (use_fast8(p, b)) hipLaunchKernelGGL(k_bwd8, dim3(tiles), dim3(NT8), p->f8_lds_bwd, st, p->pa, bb, cS);
     else if (p->par_ok) hipLaunchKernelGGL(k_chain_bwd_par, dim3(tiles), dim3(NT), p->par_lds_bwd, st, p->dev, bb, cS);
     else if (rt == 1) hipLaunchKernelGGL(k_chain_bwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cS);
     else hipLaunchKernelGGL(k_chain_bwd<2>, dim3(tiles), dim3(NT), p->lds_bytes[2], st, p->dev, bb, cS);

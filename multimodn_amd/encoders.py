@@ -49,6 +49,35 @@ class MLPEncoder(MultiModEncoder):
         return self.layers[-1](torch.cat([h, state], dim=1))
 
 
+class MIMIC_MLPEncoder(MultiModEncoder):
+    """The MIMIC pipelines' encoder (mlp_encoder.py:9-47): Dropout(p) on cat([x, state]) feeds the
+    FIRST Linear, the activation follows EVERY Linear including the last one, whose output is the
+    new state.  `layers[0]` is the nn.Dropout, so the Linears are layers.1 .. layers.n exactly as in
+    the reference's state_dict."""
+
+    def __init__(self, state_size: int, n_features: int, hidden_layers: Tuple[int, ...], dropout: float = .2,
+                 activation: Callable = F.relu, device: Optional[torch.device] = None):
+        super().__init__(state_size)
+        self.activation = activation
+        self.dropout = dropout
+        self.n_features = n_features
+        self.hidden_layers = tuple(hidden_layers)
+        widths = [n_features + state_size, *self.hidden_layers, state_size]
+        self.layers = nn.ModuleList([nn.Dropout(dropout)])
+        for fan_in, fan_out in zip(widths, widths[1:]):
+            self.layers.append(nn.Linear(fan_in, fan_out, device=device))
+
+    @property
+    def linears(self):
+        return list(self.layers)[1:]
+
+    def forward(self, state: Tensor, x: Tensor) -> Tensor:
+        h = self.layers[0](torch.cat([x, state], dim=1))
+        for lin in self.linears:
+            h = self.activation(lin(h))
+        return h
+
+
 class SLPEncoder(MLPEncoder):
     """hidden_layers=() : a single Linear on cat([x, state]); `activation` is never applied
     (slp_encoders.py:5-14)."""

@@ -15,8 +15,8 @@ import torch
 import torch.nn.functional as F
 
 from . import hip
-from .decoders import ClassDecoder
-from .encoders import MLPEncoder, _identity
+from .decoders import ClassDecoder, MLPDecoder
+from .encoders import MIMIC_MLPEncoder, MLPEncoder, _identity
 from .state import TrainableInitState
 
 
@@ -37,22 +37,37 @@ def activation_code(fn) -> int:
 
 
 def check_supported(model) -> None:
-    """The HIP path covers exactly the reference's tabular hot path:
-    TrainableInitState + MLPEncoder family + two-class sigmoid ClassDecoder."""
+    """The HIP path covers the reference's tabular hot path: TrainableInitState +
+    MLPEncoder family + two-class sigmoid ClassDecoder, and the MIMIC pipelines' modules (8f #1):
+    MIMIC_MLPEncoder + two-class sigmoid MLPDecoder."""
     if not isinstance(model.init_state, TrainableInitState):
         raise UnsupportedModelError("init_state must be TrainableInitState")
     if len(model.encoders) > hip.MAX_ENCODERS or len(model.decoders) > hip.MAX_DECODERS:
         raise UnsupportedModelError("too many encoders / decoders for libmmn_hip")
     for enc in model.encoders:
+        if isinstance(enc, MIMIC_MLPEncoder):
+            if len(enc.linears) > hip.MAX_LAYERS:
+                raise UnsupportedModelError("too many encoder layers")
+            activation_code(enc.activation)
+            continue
         if not isinstance(enc, MLPEncoder):
-            raise UnsupportedModelError(f"encoder {type(enc).__name__} is not on the HIP path (MLPEncoder family only)")
+            raise UnsupportedModelError(f"encoder {type(enc).__name__} is not on the HIP path "
+                                        f"(MLPEncoder family and MIMIC_MLPEncoder only)")
         if len(enc.layers) > hip.MAX_LAYERS:
             raise UnsupportedModelError("too many encoder layers")
         if len(enc.layers) > 1:
             activation_code(enc.activation)
     for dec in model.decoders:
+        if isinstance(dec, MLPDecoder):
+            if dec.n_classes != 2 or dec.output_activation not in (torch.sigmoid, F.sigmoid):
+                raise UnsupportedModelError("MLPDecoder must have n_classes=2 and a sigmoid output")
+            if len(dec.layers) - 1 > hip.MAX_DEC_HIDDEN:
+                raise UnsupportedModelError(f"MLPDecoder: at most {hip.MAX_DEC_HIDDEN} hidden layers")
+            if len(dec.layers) > 1:
+                activation_code(dec.hidden_activation)
+            continue
         if not isinstance(dec, ClassDecoder) or dec.n_classes != 2 or dec.activation not in (torch.sigmoid, F.sigmoid):
-            raise UnsupportedModelError("decoders must be ClassDecoder(n_classes=2, sigmoid) / LogisticDecoder")
+            raise UnsupportedModelError("decoders must be ClassDecoder(n_classes=2, sigmoid) / LogisticDecoder / MLPDecoder")
 
 
 def check_criterion(criterion) -> None:
@@ -132,10 +147,13 @@ class HipChainEngine:
         for e, enc in enumerate(model.encoders):
             me = m.enc[e]
             me.n_features = enc.n_features
-            me.n_layers = len(enc.layers)
-            me.activation = activation_code(enc.activation) if len(enc.layers) > 1 else hip.ACT_IDENTITY
+            mimic = isinstance(enc, MIMIC_MLPEncoder)
+            linears = enc.linears if mimic else list(enc.layers)
+            me.kind = hip.ENC_MIMIC if mimic else hip.ENC_MLP
+            me.n_layers = len(linears)
+            me.activation = activation_code(enc.activation) if (mimic or len(linears) > 1) else hip.ACT_IDENTITY
             ids = []
-            for l, lin in enumerate(enc.layers):
+            for l, lin in enumerate(linears):
                 ml = me.layer[l]
                 ml.w, ml.gw = ptrs(lin.weight)
                 ml.b, ml.gb = ptrs(lin.bias)
@@ -144,8 +162,20 @@ class HipChainEngine:
             self.enc_param_ids.append(ids)
         for d, dec in enumerate(model.decoders):
             md = m.dec[d]
-            md.w, md.gw = ptrs(dec.fc.weight)
-            md.b, md.gb = ptrs(dec.fc.bias)
+            if isinstance(dec, MLPDecoder):
+                lins = list(dec.layers)
+                md.n_hidden = len(lins) - 1
+                md.hidden_activation = activation_code(dec.hidden_activation) if md.n_hidden else hip.ACT_IDENTITY
+                for l, lin in enumerate(lins[:-1]):
+                    mh = md.hidden[l]
+                    mh.w, mh.gw = ptrs(lin.weight)
+                    mh.b, mh.gb = ptrs(lin.bias)
+                    mh.out_dim, mh.in_dim = lin.out_features, lin.in_features
+                out = lins[-1]
+            else:
+                out = dec.fc
+            md.w, md.gw = ptrs(out.weight)
+            md.b, md.gb = ptrs(out.bias)
         self._m = m
         self.max_batch = int(max_batch)
         ws_bytes = int(lib.mmn_workspace_bytes(C.byref(m), self.max_batch))
@@ -163,6 +193,9 @@ class HipChainEngine:
         self.n_epoch = int(lib.mmn_epoch_doubles(C.byref(m)))
         self._sig = tuple(p.data_ptr() for p in self.params)
         self.E, self.D, self.S = m.n_encoders, m.n_decoders, m.state_size
+        # (encoder id, mask width F + S, p) of the MIMIC encoders whose nn.Dropout is active in training
+        self.dropout_encoders = [(e, enc.n_features + self.S, float(enc.dropout))
+                                 for e, enc in enumerate(model.encoders) if isinstance(enc, MIMIC_MLPEncoder) and enc.dropout > 0]
 
     def __del__(self):
         try:
@@ -209,6 +242,31 @@ class HipChainEngine:
             b.seq_data[t] = k
             b.seq_enc[t] = e
         return b
+
+    def draw_dropout_masks(self, b: hip.Batch, provider=None) -> List[torch.Tensor]:
+        """Training-mode nn.Dropout of the MIMIC encoders (mlp_encoder.py:34,41): one [batch, F_e + S]
+        multiplier tensor (0 or 1/(1-p)) per encoder that runs this step, drawn on the device from
+        torch's generator like the reference's modules draw theirs (torch.manual_seed governs both),
+        and handed to the kernels through mmn_batch.drop_mask.  `provider(e, batch, width)` (tests:
+        the masks the reference drew) replaces the draw.  Returns the tensors: keep them alive until
+        the step's launches have run."""
+        keep = []
+        running = {b.seq_enc[t] for t in range(b.n_seq)}
+        for e, width, p in self.dropout_encoders:
+            if e not in running:
+                continue
+            if provider is not None:
+                mk = provider(e, b.batch, width)
+                if mk is None:
+                    continue
+                mk = mk.to(self.device, torch.float32).contiguous()
+            else:
+                mk = torch.empty((b.batch, width), dtype=torch.float32, device=self.device).bernoulli_(1.0 - p).div_(1.0 - p)
+            if tuple(mk.shape) != (b.batch, width):
+                raise ValueError(f"dropout mask of encoder {e}: expected {(b.batch, width)}, got {tuple(mk.shape)}")
+            b.drop_mask[e] = mk.data_ptr()
+            keep.append(mk)
+        return keep
 
     def local_step(self, b: hip.Batch, err_penalty: float, sc_penalty_x001: float, accumulate: bool = False,
                    optimizer=None) -> bool:

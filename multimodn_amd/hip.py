@@ -17,7 +17,9 @@ MAX_LAYERS = 8
 MAX_DIM = 256
 ADAM_MAX_SEG = 512
 ERR_UNSUPPORTED = -2
-VERSION = 101
+VERSION = 102
+MAX_DEC_HIDDEN = 3
+ENC_MLP, ENC_MIMIC = 0, 1
 
 ACT_IDENTITY, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -41,11 +43,12 @@ class Linear(C.Structure):
 
 class Encoder(C.Structure):
     _fields_ = [("n_features", C.c_int32), ("n_layers", C.c_int32), ("activation", C.c_int32),
-                ("reserved", C.c_int32), ("layer", Linear * MAX_LAYERS)]
+                ("kind", C.c_int32), ("layer", Linear * MAX_LAYERS)]
 
 
 class Decoder(C.Structure):
-    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("gw", C.c_void_p), ("gb", C.c_void_p)]
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("gw", C.c_void_p), ("gb", C.c_void_p),
+                ("n_hidden", C.c_int32), ("hidden_activation", C.c_int32), ("hidden", Linear * MAX_DEC_HIDDEN)]
 
 
 class Model(C.Structure):
@@ -60,7 +63,8 @@ class Batch(C.Structure):
                 ("batch", C.c_int32), ("batch_global", C.c_int32), ("n_seq", C.c_int32),
                 ("reserved", C.c_int32),
                 ("seq_data", C.c_int32 * MAX_ENCODERS), ("seq_enc", C.c_int32 * MAX_ENCODERS),
-                ("tile_rows", C.c_void_p), ("tile_seq", C.c_void_p)]
+                ("tile_rows", C.c_void_p), ("tile_seq", C.c_void_p),
+                ("drop_mask", C.c_void_p * MAX_ENCODERS)]
 
 
 class AdamDesc(C.Structure):

@@ -121,6 +121,9 @@ class MultiModN(nn.Module):
         #: rows) and carry its own encoder order; the batch result is the mean over the samples of the
         #: reference's batch-size-1 result (the only case the reference defines, multimodn.py:168,518-523)
         self.per_sample = False
+        # tests: callable (encoder id, batch, width) -> [batch, width] multipliers replacing the device draw
+        # of the MIMIC encoders' dropout masks (parity runs feed the masks the reference drew)
+        self.dropout_mask_provider = None
 
     # nn.Module pickling: the engine holds raw device handles and is rebuilt on demand
     def __getstate__(self):
@@ -230,6 +233,9 @@ class MultiModN(nn.Module):
                 host_flags = flags.cpu()
                 dist.all_reduce(host_flags, op=dist.ReduceOp.MAX, group=self._dp_group)
                 flags.copy_(host_flags)
+        masks = None
+        if train and eng.dropout_encoders:                  # nn.Dropout of the MIMIC encoders is live in train mode only
+            masks = eng.draw_dropout_masks(b, self.dropout_mask_provider)
         if train:
             # single GPU + multimodn_amd.optim.Adam: optimizer.step() rides in the last launch
             fuse = optimizer if (not dp and hasattr(optimizer, "fused_descriptor")) else None
@@ -252,7 +258,7 @@ class MultiModN(nn.Module):
                 eng.accumulate_and_step(float(self.err_penalty), float(self.state_change_penalty), optimizer)
             else:
                 eng.accumulate(float(self.err_penalty) if train else 1.0, float(self.state_change_penalty) if train else 0.0)
-        return executed, (xs, y)
+        return executed, (xs, y, masks)
 
     def _run_step_per_sample(self, eng, data, target, encoder_sequence, optimizer=None, train: bool = True):
         """One training step in per-sample mode: rows are regrouped on the device into tiles of one

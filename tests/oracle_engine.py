@@ -21,11 +21,23 @@ class OracleEngine:
         self.params = list(model.parameters())
         self.names = [n for n, _ in model.named_parameters()]
         self.E, self.D, self.S = len(model.encoders), len(model.decoders), model.init_state.state_size
+        from multimodn_amd.encoders import MIMIC_MLPEncoder
+        from multimodn_amd.decoders import MLPDecoder
         encs = []
         for enc in model.encoders:
+            if isinstance(enc, MIMIC_MLPEncoder):
+                encs.append(O.EncoderSpec(enc.n_features, tuple(enc.hidden_layers), activation_code(enc.activation),
+                                          kind="mimic", dropout=float(enc.dropout)))
+                continue
             act = activation_code(enc.activation) if len(enc.layers) > 1 else O.ACT_IDENTITY
             encs.append(O.EncoderSpec(enc.n_features, tuple(enc.hidden_layers), act))
-        self.spec = O.ModelSpec(self.S, encs, self.D, float(model.err_penalty), float(model.state_change_penalty) / 0.01)
+        decs = [O.DecoderSpec("mlp", tuple(l.out_features for l in list(dec.layers)[:-1]),
+                              activation_code(dec.hidden_activation) if len(dec.layers) > 1 else O.ACT_IDENTITY)
+                if isinstance(dec, MLPDecoder) else O.DecoderSpec() for dec in model.decoders]
+        self.spec = O.ModelSpec(self.S, encs, self.D, float(model.err_penalty), float(model.state_change_penalty) / 0.01,
+                                decoders=decs)
+        self.dropout_encoders = [(e, enc.n_features + self.S, float(enc.dropout)) for e, enc in enumerate(model.encoders)
+                                 if isinstance(enc, MIMIC_MLPEncoder) and enc.dropout > 0]
         self.n_params = sum(p.numel() for p in self.params)
         R = self.E + 1
         self.n_stats = R * self.D + self.E + 5 * R * self.D + R + 4
@@ -36,7 +48,7 @@ class OracleEngine:
         for p in self.params:
             self.grad_views.append(self.flat_grads[off:off + p.numel()].view(p.shape))
             off += p.numel()
-        self.enc_param_ids = [[id(p) for lin in enc.layers for p in (lin.weight, lin.bias)] for enc in model.encoders]
+        self.enc_param_ids = [[id(p) for p in enc.parameters()] for enc in model.encoders]
         self.epoch = np.zeros(R * self.D + self.E + 5 * R * self.D + R + 1)
         self.max_batch = max_batch
 
@@ -53,7 +65,21 @@ class OracleEngine:
         b.pairs = list(pairs)
         b.batch_global = batch_global or len(b.y)
         b.device_nan = device_nan_flags
+        b.masks = None
         return b
+
+    def draw_dropout_masks(self, b, provider=None):
+        """HipChainEngine.draw_dropout_masks on the host (torch's CPU generator)."""
+        b.masks = {}
+        running = {e for _, e in b.pairs}
+        for e, width, p in self.dropout_encoders:
+            if e not in running:
+                continue
+            mk = provider(e, len(b.y), width) if provider is not None else \
+                torch.empty((len(b.y), width)).bernoulli_(1.0 - p).div_(1.0 - p)
+            if mk is not None:
+                b.masks[e] = mk.numpy()
+        return list(b.masks.values())
 
     def per_sample_batch(self, xs, y, seq):
         b = _Batch()
@@ -83,7 +109,8 @@ class OracleEngine:
         if not b.pairs:
             xs, seq, override = [], np.zeros((len(b.y), 0), np.int64), []
         r = O.forward_backward(params, spec, xs, b.y, seq, batch_global=b.batch_global,
-                               present_override=override, want_grads=want_grads, keep_states=True)
+                               present_override=override, want_grads=want_grads, keep_states=True,
+                               drop_masks=getattr(b, "masks", None))
         self._last = (params, r)
         rows = np.zeros(self.E + 1, np.float32)
         rows[0] = len(b.y)
@@ -114,7 +141,8 @@ class OracleEngine:
 
     def eval_step(self, b, accumulate=False):
         spec = self.spec
-        self.spec = O.ModelSpec(spec.state_size, spec.encoders, spec.D, 1.0, 0.0)
+        import dataclasses
+        self.spec = dataclasses.replace(spec, err_penalty=1.0, state_change_penalty=0.0)
         try:
             self._run(b, False)
         finally:

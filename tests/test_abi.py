@@ -39,11 +39,22 @@ def test_version_and_errors(lib):
     assert b"workspace" in lib.mmn_error_string(-3)
 
 
-def test_struct_sizes_match_header():
-    assert C.sizeof(hip.Linear) == 40
-    assert C.sizeof(hip.Encoder) == 16 + 40 * hip.MAX_LAYERS
-    assert C.sizeof(hip.Model) == 32 + C.sizeof(hip.Encoder) * hip.MAX_ENCODERS + 32 * hip.MAX_DECODERS
-    assert C.sizeof(hip.Batch) == 8 * 16 + 4 * 16 + 16 + 16 + 64 + 64 + 16      # + tile_rows, tile_seq (ABI 101)
+def test_struct_sizes_match_header(tmp_path):
+    """sizeof / offsetof as gcc sees include/mmn_hip.h against the ctypes mirrors in multimodn_amd/hip.py."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "mmn_hip.h"\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mmn_linear), sizeof(mmn_encoder),'
+        ' sizeof(mmn_decoder), sizeof(mmn_model), sizeof(mmn_batch), sizeof(mmn_adam), offsetof(mmn_batch, drop_mask),'
+        ' offsetof(mmn_model, dec), offsetof(mmn_decoder, hidden));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [C.sizeof(hip.Linear), C.sizeof(hip.Encoder), C.sizeof(hip.Decoder), C.sizeof(hip.Model), C.sizeof(hip.Batch),
+            C.sizeof(hip.AdamDesc), hip.Batch.drop_mask.offset, hip.Model.dec.offset, hip.Decoder.hidden.offset]
+    assert got == want
+    assert C.sizeof(hip.Linear) == 40 and C.sizeof(hip.Encoder) == 16 + 40 * hip.MAX_LAYERS
 
 
 def _model(S=128, F=64, H=(32, 32), E=4, D=3):
@@ -69,6 +80,35 @@ def test_host_side_sizing(lib):
     bad = _model()
     bad.enc[0].layer[2].in_dim = 7          # inconsistent with hidden + state
     assert lib.mmn_workspace_bytes(C.byref(bad), 256) == 0
+
+
+def test_mimic_family_sizing_and_validation(lib):
+    """MIMIC_MLPEncoder / MLPDecoder descriptors (ABI 102): layer 0 reads cat[x, state]; decoder hidden chains from S."""
+    S, F, H = 128, 64, (32, 32)
+    m = hip.Model()
+    m.state_size, m.n_encoders, m.n_decoders = S, 4, 3
+    for e in range(4):
+        me = m.enc[e]
+        me.n_features, me.n_layers, me.activation, me.kind = F, 3, hip.ACT_RELU, hip.ENC_MIMIC
+        dims = [F + S, *H, S]
+        for l, (a, b) in enumerate(zip(dims, dims[1:])):
+            me.layer[l].in_dim, me.layer[l].out_dim = a, b
+    for d in range(3):
+        md = m.dec[d]
+        md.n_hidden, md.hidden_activation = 2, hip.ACT_RELU
+        md.hidden[0].in_dim, md.hidden[0].out_dim = S, 32
+        md.hidden[1].in_dim, md.hidden[1].out_dim = 32, 32
+    plain = lib.mmn_workspace_bytes(C.byref(_model()), 4096)
+    ws = lib.mmn_workspace_bytes(C.byref(m), 4096)
+    assert ws > plain > 0                                   # + xin / decoder hidden activations and their gradients
+    m.enc[1].layer[0].in_dim = F                            # a MIMIC first layer must read F + S columns
+    assert lib.mmn_workspace_bytes(C.byref(m), 4096) == 0
+    m.enc[1].layer[0].in_dim = F + S
+    m.dec[2].hidden[1].in_dim = 31                          # broken hidden chain
+    assert lib.mmn_workspace_bytes(C.byref(m), 4096) == 0
+    m.dec[2].hidden[1].in_dim = 32
+    m.dec[0].n_hidden = hip.MAX_DEC_HIDDEN + 1
+    assert lib.mmn_workspace_bytes(C.byref(m), 4096) == 0
 
 
 def test_plan_create_rejects_bad_arguments(lib):

@@ -68,7 +68,7 @@ def check_against(stats, grads, ref: O.StepResult, tol_loss=1e-5, tol_grad=2e-5,
             assert rel_err(grads[n].reshape(g.shape), g) < tol_grad, (n, rel_err(grads[n].reshape(g.shape), g))
 
 
-@pytest.mark.parametrize("mode", ["fused8", "fast8", "par16", "seq16"])
+@pytest.mark.parametrize("mode", ["fused8", "fast8", "par16", "seq16", "gen16"])
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_first_step_matches_reference_golden(lib, name, mode, monkeypatch):
     set_mode(monkeypatch, mode)
@@ -127,14 +127,18 @@ def test_training_matches_reference_golden(lib, name, optimizer):
 
 
 KERNEL_MODES = {"fused8": ("1", "1", "1", "1"), "fast8": ("1", "1", "1", "0"), "par16": ("1", "1", "0", "0"),
-                "seq16": ("1", "0", "0", "0"), "seq32": ("2", "0", "0", "0")}
+                "seq16": ("1", "0", "0", "0"), "seq32": ("2", "0", "0", "0"),
+                # the generic tier (k_gen_fwd / k_gen_bwd: written for MIMIC_MLPEncoder / MLPDecoder models) forced
+                # onto MLPEncoder + LogisticDecoder models: same results through different kernels and plan tables
+                "gen16": ("1", "0", "0", "0", "1"), "gen32": ("2", "0", "0", "0", "1")}
 
 
 def set_mode(monkeypatch, mode):
     """Kernel tier, read at plan creation: 8-wave fast tier (MIMIC-like shapes; other shapes fall
     through to the next tier), 4-wave parallel-phase kernels, or the sequential chain kernels with
     16- / 32-row tiles."""
-    rt, par, fast8, fused = KERNEL_MODES[mode]
+    rt, par, fast8, fused = KERNEL_MODES[mode][:4]
+    monkeypatch.setenv("MMN_GENERIC", "1" if len(KERNEL_MODES[mode]) > 4 else "0")
     monkeypatch.setenv("MMN_RT", rt)
     monkeypatch.setenv("MMN_PAR", par)
     monkeypatch.setenv("MMN_FAST8", fast8)

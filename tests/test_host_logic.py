@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import multimodn_amd as mm
-from helpers import GOLDEN_NAMES, Golden, build_torch_model, rel_err
+from helpers import GOLDEN_NAMES, MIMIC_GOLDEN_NAMES, Golden, build_torch_model, rel_err
 from oracle_engine import OracleEngine
 
 
@@ -43,6 +43,67 @@ def test_train_epoch_host_logic_reproduces_golden_history(name):
     sd = model.state_dict()
     for n, w in g.final_params().items():
         assert rel_err(sd[n].numpy(), w) < tol, n
+
+
+@pytest.mark.parametrize("name", MIMIC_GOLDEN_NAMES)
+def test_mimic_family_host_logic_reproduces_golden_history(name):
+    """MIMIC_MLPEncoder + MLPDecoder through the public surface: state_dict keys of the reference (Dropout at
+    layers.0), train-mode dropout masks handed to the engine per step (here: the ones the reference drew), none
+    in eval mode, History and trained weights of the reference run."""
+    g = Golden(name)
+    model = build_torch_model(g.spec, g.init_params(), "cpu", mm)
+    assert list(model.state_dict().keys()) == [str(n) for n in g.z["param_names"]]
+    model._engine_factory = OracleEngine
+    opt = torch.optim.Adam(list(model.parameters()), g.cfg["lr"])
+    hist = mm.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
+    step = {"i": 0}
+
+    class CountingLoader(list):
+        def __iter__(self):
+            for item in list.__iter__(self):
+                yield item
+                step["i"] += 1
+
+    def provide(e, batch, width):
+        m = g.step_masks(step["i"]).get(e)
+        assert m is None or m.shape == (batch, width)
+        return None if m is None else torch.from_numpy(m)
+
+    model.dropout_mask_provider = provide
+    for _ in range(g.epochs):
+        model.train_epoch(CountingLoader(make_loader(g)), opt, torch.nn.CrossEntropyLoss(), hist)
+    z = g.z
+    assert rel_err(np.stack(hist.loss["train"]), z["hist/loss"]) < 2e-6
+    assert rel_err(np.stack(hist.state_change_loss), z["hist/state_change"]) < 2e-6
+    for k in ("accuracy", "sensitivity", "specificity", "balanced_accuracy"):
+        assert np.array_equal(np.stack(getattr(hist, k)["train"]), z["hist/" + k]), k
+    sd = model.state_dict()
+    for n, w in g.final_params().items():
+        assert rel_err(sd[n].numpy(), w) < 5e-5, n
+    # eval mode: nn.Dropout is the identity, no masks are drawn
+    model.dropout_mask_provider = lambda *a: pytest.fail("dropout mask requested in eval mode")
+    th = mm.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
+    model.test(make_loader(g), torch.nn.CrossEntropyLoss(), th, tag="test")
+    assert rel_err(th.loss["test"][0], z["eval/test_loss"]) < 2e-6
+
+
+def test_mimic_plugin_forward_contract():
+    """The plugins' own forward (module-level contract) equals the oracle's restatement of the reference modules."""
+    torch.manual_seed(0)
+    S, F = 6, 4
+    enc = mm.MIMIC_MLPEncoder(S, F, (5, 3), dropout=0.0)
+    dec = mm.MLPDecoder(S, (4,), 2)
+    assert isinstance(enc.layers[0], torch.nn.Dropout) and enc.layers[1].in_features == F + S
+    assert [n for n, _ in dec.named_parameters()] == ["layers.0.weight", "layers.0.bias", "layers.1.weight", "layers.1.bias"]
+    s, x = torch.randn(7, S), torch.randn(7, F)
+    h = torch.cat([x, s], 1)
+    for lin in enc.linears:
+        h = torch.relu(lin(h))
+    assert torch.allclose(enc.eval()(s, x), h) and float(h.min()) >= 0
+    out = dec(s)
+    assert out.shape == (7, 2) and 0 < float(out.min()) and float(out.max()) < 1
+    enc_t = mm.MIMIC_MLPEncoder(S, F, (5,), dropout=0.5).train()
+    assert not torch.allclose(enc_t(s, x), enc_t(s, x))     # training mode draws a new mask per call
 
 
 def test_nan_skip_leaves_grad_none_and_adam_untouched():

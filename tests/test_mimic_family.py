@@ -1,0 +1,222 @@
+"""GPU parity of the MIMIC family: MIMIC_MLPEncoder (multimodn/encoders/mlp_encoder.py:9-47)
+and MLPDecoder (multimodn/decoders/decoders.py:22-46) through the C ABI (k_gen_fwd / k_gen_bwd + k_wgrad +
+k_reduce) against the golden vectors the reference produced with these modules (tests/golden/make_golden.py,
+dropout masks recorded from the reference's own nn.Dropout draws) and against the numpy oracle.
+
+Tolerances as in tests/test_hip_parity.py: loss / grid 1e-5 relative, integer counters exact, gradients 2e-5 of
+the tensor's max |g| (5e-5 at batch 4096 against the fp64 oracle: 4096-term sums in another order), trained
+weights 1e-4 of max |w|."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import MIMIC_GOLDEN_NAMES, Golden, build_torch_model, rel_err
+from oracle import multimodn_oracle as O
+from test_hip_parity import check_against, lib  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def mask_provider(masks):
+    """masks: {encoder id: numpy [B, F+S]} -> what MultiModN.dropout_mask_provider expects."""
+    def provide(e, batch, width):
+        m = masks.get(e)
+        return None if m is None else torch.from_numpy(np.ascontiguousarray(m, np.float32))
+    return provide
+
+
+def run_step(model, batch, masks=None, batch_global=None, nan_policy="host"):
+    model.nan_policy = nan_policy
+    model.dropout_mask_provider = mask_provider(masks or {})
+    data = [torch.from_numpy(np.ascontiguousarray(x)) for x in batch[0]]
+    target = torch.from_numpy(np.ascontiguousarray(batch[1]))
+    seq = torch.from_numpy(batch[2]) if len(batch) > 2 else None
+    eng = model._get_engine(target.shape[0])
+    eng.epoch_reset()
+    executed, keep = model._run_step(eng, data, target, seq, train=True, batch_global=batch_global)
+    eng.assign_grads(executed)
+    torch.cuda.synchronize()
+    stats = {k: np.array(v) for k, v in eng.step_values().items()}
+    grads = {n: (None if p.grad is None else p.grad.detach().cpu().numpy().copy())
+             for n, p in model.named_parameters()}
+    return stats, grads, executed
+
+
+@pytest.mark.parametrize("rt", ["1", "2"])
+@pytest.mark.parametrize("name", MIMIC_GOLDEN_NAMES)
+def test_first_step_matches_reference_golden(lib, name, rt, monkeypatch):
+    monkeypatch.setenv("MMN_RT", rt)
+    g = Golden(name)
+    model = build_torch_model(g.spec, g.init_params(), "cuda", lib)
+    stats, grads, _ = run_step(model, g.batch(0), g.step_masks(0))
+    assert rel_err(stats["loss"], g.z["step_loss"][0]) < 1e-5
+    ref_grads = g.step_grads(0)
+    none = set(str(s) for s in g.z["step0/grad_none"])
+    for n in g.spec.param_names():
+        if n in none:
+            assert grads[n] is None
+        else:
+            assert rel_err(grads[n], ref_grads[n]) < 2e-5, (n, rel_err(grads[n], ref_grads[n]))
+    b = g.batch(0)
+    ref = O.forward_backward(g.init_params(), g.spec, b[0], b[1], b[2] if len(b) > 2 else None, drop_masks=g.step_masks(0))
+    check_against(stats, grads, ref)
+
+
+@pytest.mark.parametrize("optimizer", ["torch", "hip"])
+@pytest.mark.parametrize("name", MIMIC_GOLDEN_NAMES)
+def test_training_matches_reference_golden(lib, name, optimizer):
+    """Whole train_epoch loops through the public surface with the masks the reference drew."""
+    g = Golden(name)
+    model = build_torch_model(g.spec, g.init_params(), "cuda", lib)
+    Adam = torch.optim.Adam if optimizer == "torch" else lib.optim.Adam
+    opt = Adam(list(model.parameters()), g.cfg["lr"])
+    hist = lib.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
+    crit = torch.nn.CrossEntropyLoss()
+    loader = [tuple([[torch.from_numpy(x) for x in b[0]], torch.from_numpy(b[1])]) for b in g.batches()]
+    step = {"i": 0}
+
+    def provide(e, batch, width):
+        m = g.step_masks(step["i"]).get(e)
+        return None if m is None else torch.from_numpy(m)
+
+    class CountingLoader(list):                     # one optimizer step per batch: advance the mask index with it
+        def __iter__(self_inner):
+            for item in list.__iter__(self_inner):
+                yield item
+                step["i"] += 1
+
+    model.dropout_mask_provider = provide
+    for _ in range(g.epochs):
+        model.train_epoch(CountingLoader(loader), opt, crit, hist)
+    z = g.z
+    assert rel_err(np.stack(hist.loss["train"]), z["hist/loss"]) < 1e-5
+    assert rel_err(np.stack(hist.state_change_loss), z["hist/state_change"]) < 1e-5
+    acc = np.stack(hist.accuracy["train"])
+    assert np.abs(acc - z["hist/accuracy"]).max() <= 1.0 / g.cfg["B"] + 1e-12
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    assert list(sd.keys()) == [str(n) for n in z["param_names"]]          # the reference's state_dict keys, in order
+    for n, w in g.final_params().items():
+        assert rel_err(sd[n], w) < 1e-4, (n, rel_err(sd[n], w))
+
+
+@pytest.mark.parametrize("name", MIMIC_GOLDEN_NAMES)
+def test_eval_entry_points_match_reference(lib, name):
+    """test() History, predict() and get_states() on the reference's TRAINED weights (eval mode: no dropout)."""
+    g = Golden(name)
+    model = build_torch_model(g.spec, {n: w.copy() for n, w in g.final_params().items()}, "cuda", lib)
+    z = g.z
+    loader = [tuple([[torch.from_numpy(x) for x in b[0]], torch.from_numpy(b[1])]) for b in g.batches()]
+    hist = lib.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
+    model.test(loader, torch.nn.CrossEntropyLoss(), hist, tag="test")
+    assert rel_err(hist.loss["test"][0], z["eval/test_loss"]) < 1e-5
+    assert np.abs(hist.accuracy["test"][0] - z["eval/test_accuracy"]).max() <= 1.0 / g.cfg["B"] + 1e-12
+    states = torch.stack(model.get_states(loader)).cpu().numpy()
+    assert rel_err(states, z["eval/states"]) < 1e-5
+    if "eval/predict" in z.files:
+        pred = model.predict(loader[0][0])
+        assert (pred != z["eval/predict"]).mean() < 0.01               # a class can flip only on a rounding-level tie
+
+
+@pytest.mark.parametrize("B", [1, 15, 17, 33, 257])
+def test_ragged_batches_match_oracle(lib, B):
+    spec = O.ModelSpec(20, [O.EncoderSpec(7, (9, 6), O.ACT_RELU, kind="mimic", dropout=0.3),
+                            O.EncoderSpec(3, (), O.ACT_SIGMOID, kind="mimic"),
+                            O.EncoderSpec(70, (33,), O.ACT_SIGMOID),
+                            O.EncoderSpec(150, (40,), O.ACT_RELU, kind="mimic", dropout=0.1)], 3, 1.0, 0.7,
+                       decoders=[O.DecoderSpec("mlp", (12, 5)), O.DecoderSpec("class"), O.DecoderSpec("mlp", (7,), O.ACT_SIGMOID)])
+    params = O.init_params(spec, 3)
+    batch = O.synthetic_batches(spec, B, B, seed=11)[0]
+    rng = np.random.default_rng(B)
+    masks = {0: ((rng.random((B, 27)) >= 0.3) / 0.7).astype(np.float32),
+             3: ((rng.random((B, 170)) >= 0.1) / 0.9).astype(np.float32)}
+    model = build_torch_model(spec, params, "cuda", lib)
+    stats, grads, _ = run_step(model, batch, masks)
+    ref = O.forward_backward(params, spec, batch[0], batch[1], drop_masks=masks)
+    check_against(stats, grads, ref)
+
+
+def mimic_c3_spec(pen=(1.0, 0.3)):
+    """The MIMIC pipelines' modules at BASELINE's MIMIC shape (mimic_multi_task_pipeline.py:118-119)."""
+    return O.ModelSpec(128, [O.EncoderSpec(64, (32, 32), O.ACT_RELU, kind="mimic", dropout=0.2) for _ in range(4)], 3,
+                       pen[0], pen[1], decoders=[O.DecoderSpec("mlp", (32, 32)) for _ in range(3)])
+
+
+@pytest.mark.parametrize("B", [4096, 6000])
+def test_full_size_against_fp64_oracle(lib, B):
+    spec = mimic_c3_spec()
+    params = O.init_params(spec, 5)
+    batch = O.synthetic_batches(spec, B, B, seed=2)[0]
+    rng = np.random.default_rng(7)
+    masks = {e: ((rng.random((B, 192)) >= 0.2) / 0.8).astype(np.float32) for e in range(4)}
+    model = build_torch_model(spec, params, "cuda", lib)
+    stats, grads, _ = run_step(model, batch, masks)
+    ref = O.forward_backward(params, spec, batch[0], batch[1], drop_masks=masks, dtype=np.float64)
+    check_against(stats, grads, ref, tol_grad=5e-5)
+
+
+def test_shard_sum_equals_full_batch(lib):
+    """Size-independent property at full size: four 1024-row shards with the global divisor sum to the full batch."""
+    spec = mimic_c3_spec()
+    params = O.init_params(spec, 6)
+    B = 4096
+    batch = O.synthetic_batches(spec, B, B, seed=3)[0]
+    rng = np.random.default_rng(8)
+    masks = {e: ((rng.random((B, 192)) >= 0.2) / 0.8).astype(np.float32) for e in range(4)}
+    model = build_torch_model(spec, params, "cuda", lib)
+    full_stats, full_grads, _ = run_step(model, batch, masks)
+    acc = None
+    for lo in range(0, B, 1024):
+        sl = slice(lo, lo + 1024)
+        st, gr, _ = run_step(model, ([x[sl] for x in batch[0]], batch[1][sl]), {e: m[sl] for e, m in masks.items()},
+                             batch_global=B)
+        if acc is None:
+            acc = (st["err_loss"].copy(), {n: g.copy() for n, g in gr.items()})
+        else:
+            acc = (acc[0] + st["err_loss"], {n: acc[1][n] + g for n, g in gr.items()})
+    assert rel_err(acc[0], full_stats["err_loss"]) < 1e-5
+    for n, g in full_grads.items():
+        assert rel_err(acc[1][n], g) < 2e-5, n
+
+
+def test_device_dropout_draw(lib):
+    """Without a provider the masks come from torch's device generator: reproducible under manual_seed,
+    multipliers in {0, 1/(1-p)} with the right keep rate, and a dropped model differs from eval mode."""
+    spec = mimic_c3_spec()
+    params = O.init_params(spec, 1)
+    model = build_torch_model(spec, params, "cuda", lib)
+    B = 2048
+    batch = O.synthetic_batches(spec, B, B, seed=4)[0]
+    data = [torch.from_numpy(x) for x in batch[0]]
+    target = torch.from_numpy(batch[1])
+    eng = model._get_engine(B)
+
+    def step(seed):
+        torch.manual_seed(seed)
+        eng.epoch_reset()
+        executed, keep = model._run_step(eng, data, target, None, train=True)
+        torch.cuda.synchronize()
+        return float(eng.step_values()["loss"]), keep[2]
+
+    l1, m1 = step(123)
+    l2, m2 = step(123)
+    l3, _ = step(124)
+    assert l1 == l2 and l1 != l3
+    assert len(m1) == 4
+    for mk in m1:
+        vals = torch.unique(mk).cpu().tolist()
+        assert all(abs(v) < 1e-12 or abs(v - 1.25) < 1e-6 for v in vals)
+        assert abs(float((mk > 0).float().mean()) - 0.8) < 0.01
+    no_drop = O.forward_backward(params, spec, batch[0], batch[1]).loss
+    assert abs(l1 - no_drop) > 1e-6
+
+
+def test_unsupported_combinations_are_refused(lib):
+    """Per-sample mode exists in the fused MLPEncoder kernel only: a MIMIC model must refuse it loudly."""
+    spec = O.ModelSpec(16, [O.EncoderSpec(4, (8,), O.ACT_RELU, kind="mimic"), O.EncoderSpec(4, (8,), O.ACT_RELU, kind="mimic")], 1, 1.0, 0.0,
+                       decoders=[O.DecoderSpec("mlp", (8,))])
+    model = build_torch_model(spec, O.init_params(spec, 0), "cuda", lib)
+    model.per_sample = True
+    xs = [torch.randn(32, 4), torch.randn(32, 4)]
+    with pytest.raises((lib.hip.MmnError, lib.UnsupportedModelError)):
+        eng = model._get_engine(32)
+        model._run_step_per_sample(eng, xs, torch.zeros(32, 1, dtype=torch.int64), None)

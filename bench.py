@@ -40,6 +40,12 @@ WORKLOADS = {
                text="BASELINE configs[4]: the MIMIC-shaped model with per-sample missing modalities (30 % missing not at "
                     "random, NaN rows) and a random encoder order per sample, batch 4096 per GPU; a step includes the "
                     "on-device regrouping of the rows into tiles of one executed sequence (eager launches)"),
+    "mimic": dict(S=128, F=[64] * 4, H=(32, 32), D=3, B=4096, lr=1e-3, pen=(1.0, 0.3), family="mimic", dec_hidden=(32, 32),
+                  dropout=0.2,
+                  text="SURVEY 8f #1, the MIMIC pipelines' own modules at the MIMIC shape: 4 x MIMIC_MLPEncoder(64 features + "
+                       "state 128 -> 32 -> 32 -> 128, relu on every layer, dropout 0.2 on cat[x, state], masks drawn on the "
+                       "device inside the step) and 3 x MLPDecoder(128 -> 32 -> 32 -> 2), batch 4096 per GPU, Adam lr 1e-3, "
+                       "penalties 1.0/0.3; generic chain kernels k_gen_fwd / k_gen_bwd"),
     "c2": dict(S=64, F=[3, 2], H=(5, 5), D=2, B=512, lr=1e-2, pen=(0.7, 0.3),
                text="Titanic-shaped, 2 encoders (features split 3+2), hidden (5,5) relu, 2 binary tasks, state_dim 64, "
                     "batch 512, Adam lr 1e-2, penalties 0.7/0.3 (latency-bound)"),
@@ -51,6 +57,10 @@ WORKLOADS = {
 
 def oracle_spec(O, w):
     """The workload as the CPU oracle describes it (cpu_baseline leg only)."""
+    if w.get("family") == "mimic":
+        return O.ModelSpec(w["S"], [O.EncoderSpec(f, tuple(w["H"]), O.ACT_RELU, kind="mimic", dropout=w["dropout"])
+                                    for f in w["F"]], w["D"], *w["pen"],
+                           decoders=[O.DecoderSpec("mlp", tuple(w["dec_hidden"])) for _ in range(w["D"])])
     return O.ModelSpec(w["S"], [O.EncoderSpec(f, tuple(w["H"]), O.ACT_RELU) for f in w["F"]], w["D"], *w["pen"])
 
 
@@ -58,8 +68,12 @@ def build_model(mm, w, device):
     """The workload's model on the product surface: MLPEncoder / LogisticDecoder / MultiModN with
     torch's default initialisation under a fixed seed (the same weights on every rank)."""
     torch.manual_seed(0)
-    enc = [mm.MLPEncoder(w["S"], f, tuple(w["H"])) for f in w["F"]]
-    dec = [mm.LogisticDecoder(w["S"]) for _ in range(w["D"])]
+    if w.get("family") == "mimic":      # mimic_multi_task_pipeline.py:118-119
+        enc = [mm.MIMIC_MLPEncoder(w["S"], f, tuple(w["H"]), dropout=w["dropout"]) for f in w["F"]]
+        dec = [mm.MLPDecoder(w["S"], tuple(w["dec_hidden"]), 2) for _ in range(w["D"])]
+    else:
+        enc = [mm.MLPEncoder(w["S"], f, tuple(w["H"])) for f in w["F"]]
+        dec = [mm.LogisticDecoder(w["S"]) for _ in range(w["D"])]
     return mm.MultiModN(w["S"], enc, dec, w["pen"][0], w["pen"][1], device=device)
 
 
@@ -80,6 +94,19 @@ def flops_per_sample_of(w):
     """Algorithmic FLOPs (MAC = 2) per sample of each launch (SURVEY.md section 8d formulas)."""
     S, E, D = w["S"], len(w["F"]), w["D"]
     fwd = bwd = wg = 0
+    if w.get("family") == "mimic":
+        # encoder: (F+S) x H1, H1 x H2, ..., Hn x S; backward through the same products except the x columns of the
+        # first layer (no grad flows to x); decoder on each of the E+1 states: S x Hd1, ..., Hdn x 2 (forward, backward
+        # and weight gradient alike)
+        for f in w["F"]:
+            dims = [f + S] + list(w["H"]) + [S]
+            full = sum(a * b for a, b in zip(dims, dims[1:]))
+            fwd += full
+            wg += full
+            bwd += full - f * dims[1]
+        dd = [S] + list(w["dec_hidden"]) + [2]
+        dec = (E + 1) * D * sum(a * b for a, b in zip(dd, dd[1:]))
+        return {"k_chain_fwd": 2 * (fwd + dec), "k_chain_bwd": 2 * (bwd + dec), "k_wgrad": 2 * (wg + dec)}
     for f in w["F"]:
         dims = [f] + list(w["H"])
         hidden = sum(a * b for a, b in zip(dims, dims[1:]))
@@ -132,10 +159,12 @@ def cpu_match(O, mm, w, device, batch_size, steps=3):
         dx = [torch.from_numpy(x).to(device) for x in xs]
         dy = torch.from_numpy(y).to(device)
         b = eng.make_batch(dx, dy, [(k, k) for k in range(len(xs))], device_nan_flags=False)
+        keep = eng.draw_dropout_masks(b) if eng.dropout_encoders else []     # both sides take the device's masks
+        masks = {e: mk.cpu().numpy() for (e, _, _), mk in zip(eng.dropout_encoders, keep)} or None
         eng.local_step(b, alpha, beta, accumulate=True, optimizer=opt)
         opt.step()
         got = eng.step_values()["err_loss"]
-        r = O.forward_backward(params, spec, xs, y)
+        r = O.forward_backward(params, spec, xs, y, drop_masks=masks)
         oopt.step(params, r.grads)
         worst = max(worst, float(np.max(np.abs(got - r.err_loss)) / np.max(np.abs(r.err_loss))))
     dw = max(float(np.max(np.abs(p.detach().cpu().numpy() - params[n])) / max(np.max(np.abs(params[n])), 1e-30))
@@ -157,10 +186,16 @@ def cpu_baseline(O, spec, batch_size, budget_s=15.0):
     opt = O.Adam(1e-3)
     r = O.forward_backward(params, spec, *batches[0])          # warm-up
     opt.step(params, r.grads)
+    rng = np.random.default_rng(9)
+
+    def draw():                                                # nn.Dropout of the MIMIC encoders, drawn per step like the reference
+        return {e: ((rng.random((batch_size, enc.n_features + spec.state_size), dtype=np.float32) >= enc.dropout)
+                    / np.float32(1 - enc.dropout)).astype(np.float32)
+                for e, enc in enumerate(spec.encoders) if enc.kind == "mimic" and enc.dropout > 0} or None
     n, t0 = 0, time.perf_counter()
     while True:
         xs, y = batches[n % 2]
-        r = O.forward_backward(params, spec, xs, y)
+        r = O.forward_backward(params, spec, xs, y, drop_masks=draw())
         opt.step(params, r.grads)
         n += 1
         el = time.perf_counter() - t0
@@ -272,6 +307,8 @@ def main():
             step.keep = keep
         else:
             b = batches[i % len(batches)]
+        if eng.dropout_encoders:                             # train-mode nn.Dropout: this step's multipliers, drawn on the device
+            step.masks = eng.draw_dropout_masks(b)
         # single GPU: Adam rides in the last launch (k_reduce) of the step; N > 1: all-reduce first
         eng.local_step(b, alpha, beta, accumulate=not dp, optimizer=fuse_opt)
         if dp:
@@ -410,6 +447,8 @@ def main():
         times = []
         for rnd in range(ROUNDS):
             b = batches[rnd % len(batches)]
+            if eng.dropout_encoders:
+                step.masks = eng.draw_dropout_masks(b)
             eng.local_step(b, alpha, beta, accumulate=False)        # valid inputs for every kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -250,20 +250,35 @@ class HipChainEngine:
         and handed to the kernels through mmn_batch.drop_mask.  `provider(e, batch, width)` (tests:
         the masks the reference drew) replaces the draw.  Returns the tensors: keep them alive until
         the step's launches have run."""
-        keep = []
         running = {b.seq_enc[t] for t in range(b.n_seq)}
-        for e, width, p in self.dropout_encoders:
-            if e not in running:
-                continue
+        todo = [(e, w, p) for e, w, p in self.dropout_encoders if e in running]
+        if not todo:
+            return []
+        B = int(b.batch)
+        if provider is None and len({p for _, _, p in todo}) == 1:
+            # one draw for all encoders (2 launches per step instead of 2 per encoder); encoder e's mask is a
+            # contiguous [B, width_e] slice of the flat buffer
+            p = todo[0][2]
+            flat = torch.empty(B * sum(w for _, w, _ in todo), dtype=torch.float32, device=self.device)
+            flat.bernoulli_(1.0 - p).div_(1.0 - p)
+            keep, off = [], 0
+            for e, w, _ in todo:
+                mk = flat[off:off + B * w].view(B, w)
+                b.drop_mask[e] = mk.data_ptr()
+                keep.append(mk)
+                off += B * w
+            return keep
+        keep = []
+        for e, width, p in todo:
             if provider is not None:
-                mk = provider(e, b.batch, width)
+                mk = provider(e, B, width)
                 if mk is None:
                     continue
                 mk = mk.to(self.device, torch.float32).contiguous()
             else:
-                mk = torch.empty((b.batch, width), dtype=torch.float32, device=self.device).bernoulli_(1.0 - p).div_(1.0 - p)
-            if tuple(mk.shape) != (b.batch, width):
-                raise ValueError(f"dropout mask of encoder {e}: expected {(b.batch, width)}, got {tuple(mk.shape)}")
+                mk = torch.empty((B, width), dtype=torch.float32, device=self.device).bernoulli_(1.0 - p).div_(1.0 - p)
+            if tuple(mk.shape) != (B, width):
+                raise ValueError(f"dropout mask of encoder {e}: expected {(B, width)}, got {tuple(mk.shape)}")
             b.drop_mask[e] = mk.data_ptr()
             keep.append(mk)
         return keep

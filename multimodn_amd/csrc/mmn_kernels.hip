@@ -183,11 +183,22 @@ struct DevPlan {
                                // hidden activations dhid[r][d][l] [maxB x H]
     float* gdpre;              // d loss / d pre-activation of the decoders' hidden layers, same shape as dhid
     int64_t xin_off[MMN_MAX_ENCODERS];                           // float offsets into gact (-1: not a MIMIC encoder)
-    int64_t dh_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN];        // offset of (d, l) inside one grid row's block
-    int64_t dh_row_stride;                                       // floats per grid row (gact and gdpre alike)
+    int64_t dh_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN];        // first COLUMN of (d, l) inside a grid row's [maxB x dcols] block
+    int64_t dh_row_stride;                                       // floats per grid row = maxB * dcols (gact and gdpre alike)
+    int32_t dcols, pad7;                                         // hidden widths of all decoders side by side
     int64_t dh_base;                                             // start of the dhid blocks inside gact
     int64_t pkdf_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];  // forward operand of decoder layer l (last = output Linear)
     int64_t pkdb_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];  // backward operand (W^T)
+    // the decoders' operands are reused on all E+1 state rows: when they fit they are copied into LDS once per
+    // workgroup (forward operands in k_gen_fwd, backward ones in k_gen_bwd) and no decoder layer waits on global memory
+    int64_t dec_f_off, dec_b_off;      // start of the contiguous forward / backward decoder operands inside pack
+    int32_t dec_f_floats, dec_b_floats, dec_lds, gen_fast;
+    // all biases of the model in one buffer (k_prepare gathers them every step), so that the fast kernels copy them
+    // into LDS with one coalesced read instead of one dependent global load per layer epilogue
+    float* biasbuf; const float* const* bias_src;
+    int32_t n_bias, pad8;
+    int32_t ebias_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
+    int32_t dbias_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -519,7 +530,11 @@ __global__ __launch_bounds__(NT) void k_prepare(const DevPlan* __restrict__ P, m
     }
     __syncthreads();
     const int64_t g = (int64_t)(blockIdx.x - scan_blocks) * NT + threadIdx.x;
-    if (g >= p.n_pack_elems) return;
+    if (g >= p.n_pack_elems) {                              // tail threads: gather the biases
+        const int64_t j = g - p.n_pack_elems;
+        if (j < p.n_bias) g_st(p.biasbuf + j, g_ld(p.bias_src[j]));
+        return;
+    }
     int lo = 0, hi = npt - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -1238,9 +1253,82 @@ __device__ __forceinline__ void layer_state_x(clp sState, int ldS, const PB& B, 
     }
 }
 
+// out[rows x N] = A * W'^T with BOTH operands in LDS (W' = a fragment-ordered pack copied from global memory once
+// per workgroup): one column tile per wave at a time, no global round trip
+template <int RT, class Epi>
+__device__ __forceinline__ void layer_nt_l(const ASrc& A, clp wl, int N, int len0, int len1, Epi&& epi) {
+    const int wave = wave_id(), lane = threadIdx.x & 63;
+    const int i = lane & 15, q = lane >> 4;
+    const int T0 = (len0 + 15) >> 4, T = T0 + ((len1 + 15) >> 4);
+    const int ntiles = (N + 15) >> 4;
+    for (int tile = wave; tile < ntiles; tile += 4) {
+        f32x4 acc[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        clp bp = wl + ((int64_t)tile * T * 64 + lane) * 4;
+        for (int t = 0; t < T; ++t) {
+            const f32x4 bb = lds_ld4(bp + t * 256);
+            const int lda = t < T0 ? A.lda0 : A.lda1;
+            clp ap = (t < T0 ? A.a0 + 16 * t : A.a1 + 16 * (t - T0)) + 4 * q;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const f32x4 a = lds_ld4(ap + (r * 16 + i) * lda);
+                acc[r] = mfma4(a.x, bb.x, acc[r]);
+                acc[r] = mfma4(a.y, bb.y, acc[r]);
+                acc[r] = mfma4(a.z, bb.z, acc[r]);
+                acc[r] = mfma4(a.w, bb.w, acc[r]);
+            }
+        }
+        const int col = 16 * tile + i;
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) epi(r * 16 + q * 4 + k, col, acc[r][k]);
+    }
+}
+
+// a decoder layer: operands from the LDS copy when the plan says they fit, else from global memory
+template <int RT, class Epi>
+__device__ __forceinline__ void dec_layer(LPlan& p, clp sW, int64_t pk_off, int64_t region_off, const ASrc& A, int N, int K,
+                                          Epi&& epi) {
+    if (p.dec_lds) {
+        layer_nt_l<RT>(A, sW + (pk_off - region_off), N, K, 0, epi);
+    } else {
+        const PB B = make_pb(p.pack + pk_off, N, K, 0);
+        layer_nt<RT>(A, B, epi);
+    }
+}
+
+__device__ __forceinline__ void copy_pack_to_lds(lp dst, const float* __restrict__ src, int nfloats) {
+    for (int idx = threadIdx.x * 4; idx < nfloats; idx += NT * 4) lds_st4(dst + idx, g_ld4(src + idx));
+}
+
+// LDS tile [nrows x ncols] -> global rows of stride ld_dst
+__device__ __forceinline__ void store_rows_ld(float* __restrict__ dst, int64_t ld_dst, clp src, int ld_src, int nrows, int ncols) {
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    for (int r = wave; r < nrows; r += 4)
+        for (int c = lane; c < ncols; c += 64) g_st(dst + (int64_t)r * ld_dst + c, lds_ld(src + r * ld_src + c));
+}
+
+// apply_act_grad with the activations / pre-activation gradients in global rows of stride ldg
+__device__ __forceinline__ void apply_act_grad_ld(lp sBuf, int ld, const float* __restrict__ hid_g, float* __restrict__ dpre_g,
+                                                  int64_t ldg, int nrows, int rows_pad, int H, int akind) {
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    for (int r = wave; r < rows_pad; r += 4)
+        for (int c = lane; c < H; c += 64) {
+            float dp = 0.f;
+            if (r < nrows) {
+                dp = lds_ld(sBuf + r * ld + c) * act_grad_from_out(g_ld(hid_g + (int64_t)r * ldg + c), akind);
+                g_st(dpre_g + (int64_t)r * ldg + c, dp);
+            }
+            lds_st(sBuf + r * ld + c, dp);
+        }
+}
+
 struct GenDecodeCtx {
     LPlan* p;
     lp sZ; lp sH0; lp sH1;
+    clp sW;                // LDS copy of the decoders' forward operands (p->dec_lds)
     int y;                 // this thread's target (row, d)
     int row0, nrows, tile;
     float cL;
@@ -1265,20 +1353,18 @@ __device__ __forceinline__ void gen_decode(const GenDecodeCtx& c, clp sS, int gr
             const lp out = (l & 1) ? c.sH1 : c.sH0;
             const float* bias = lin.b;
             const ASrc A{in, ldi, in, ldi};
-            const PB B = make_pb(p.pack + p.pkdf_off[d][l], N, K, 0);
-            layer_nt<RT>(A, B, [&](int row, int col, float v) {
+            dec_layer<RT>(p, c.sW, p.pkdf_off[d][l], p.dec_f_off, A, N, K, [&](int row, int col, float v) {
                 if (col < N) lds_st(out + row * ldH + col, act_fwd(v + g_ld(bias + col), hk));
             });
             __syncthreads();
             if (c.want_grads)
-                store_rows(p.gact + p.dh_base + (int64_t)grid_row * p.dh_row_stride + p.dh_off[d][l] + (int64_t)c.row0 * N,
-                           out, ldH, c.nrows, N);
+                store_rows_ld(p.gact + p.dh_base + (int64_t)grid_row * p.dh_row_stride + (int64_t)c.row0 * p.dcols + p.dh_off[d][l],
+                              p.dcols, out, ldH, c.nrows, N);
             in = out; ldi = ldH; K = N;
         }
         const float* bias = dec.b;
         const ASrc A{in, ldi, in, ldi};
-        const PB B = make_pb(p.pack + p.pkdf_off[d][nh], 2, K, 0);
-        layer_nt<RT>(A, B, [&](int row, int col, float v) {
+        dec_layer<RT>(p, c.sW, p.pkdf_off[d][nh], p.dec_f_off, A, 2, K, [&](int row, int col, float v) {
             if (col < 2) lds_st(c.sZ + row * 16 + 2 * d + col, v + g_ld(bias + col));
         });
         __syncthreads();
@@ -1373,6 +1459,8 @@ __global__ __launch_bounds__(NT) void k_gen_fwd(const DevPlan* __restrict__ P, m
     }
     GenDecodeCtx dc;
     dc.p = &p; dc.sZ = smem + L.sZ; dc.sH0 = sH[0]; dc.sH1 = sH[1];
+    dc.sW = smem + L.total;
+    if (p.dec_lds) copy_pack_to_lds(smem + L.total, p.pack + p.dec_f_off, p.dec_f_floats);
     dc.row0 = row0; dc.nrows = nrows; dc.tile = tile; dc.cL = cL; dc.want_grads = want_grads;
     {
         const int row = threadIdx.x & (TB - 1), d = threadIdx.x / TB;
@@ -1498,8 +1586,8 @@ __global__ __launch_bounds__(NT) void k_gen_fwd(const DevPlan* __restrict__ P, m
 
 // G += d loss / d state through all D decoders of one grid row; stores the hidden layers' dpre
 template <int RT>
-__device__ __forceinline__ void gen_decoder_back(LPlan& p, lp G, lp sDz, lp sDd, lp sH0, lp sH1, int grid_row, int row0,
-                                                 int nrows) {
+__device__ __forceinline__ void gen_decoder_back(LPlan& p, clp sW, lp G, lp sDz, lp sDd, lp sH0, lp sH1, int grid_row,
+                                                 int row0, int nrows) {
     constexpr int TB = 16 * RT;
     const int ldS = p.ldS, ldH = p.ldH, S = p.S, D = p.D;
     load_dz_tile<TB>(p, sDz, grid_row, row0, nrows);
@@ -1514,8 +1602,7 @@ __device__ __forceinline__ void gen_decoder_back(LPlan& p, lp G, lp sDz, lp sDd,
         __syncthreads();
         const ASrc Ad{sDd, LDZ, sDd, LDZ};
         if (nh == 0) {
-            const PB B = make_pb(p.pack + p.pkdb_off[d][0], S, 2, 0);                 // W_f^T [S x 2]
-            layer_nt<RT>(Ad, B, [&](int row, int col, float v) {
+            dec_layer<RT>(p, sW, p.pkdb_off[d][0], p.dec_b_off, Ad, S, 2, [&](int row, int col, float v) {   // W_f^T [S x 2]
                 if (col < S) lds_st(G + row * ldS + col, lds_ld(G + row * ldS + col) + v);
             });
             __syncthreads();
@@ -1524,25 +1611,23 @@ __device__ __forceinline__ void gen_decoder_back(LPlan& p, lp G, lp sDz, lp sDd,
         lp cbuf = sH0, nbuf = sH1;
         {
             const int Hl = dec.hidden[nh - 1].out_dim;
-            const PB B = make_pb(p.pack + p.pkdb_off[d][nh], Hl, 2, 0);               // W_f^T [H_last x 2]
-            layer_nt<RT>(Ad, B, [&](int row, int col, float v) {
+            dec_layer<RT>(p, sW, p.pkdb_off[d][nh], p.dec_b_off, Ad, Hl, 2, [&](int row, int col, float v) {   // W_f^T [H_last x 2]
                 if (col < Hl) lds_st(cbuf + row * ldH + col, v);
             });
             __syncthreads();
         }
         for (int l = nh - 1; l >= 0; --l) {
             const int Hl = dec.hidden[l].out_dim, Kin = dec.hidden[l].in_dim;
-            const int64_t off = (int64_t)grid_row * p.dh_row_stride + p.dh_off[d][l] + (int64_t)row0 * Hl;
-            apply_act_grad(cbuf, ldH, p.gact + p.dh_base + off, p.gdpre + off, nrows, TB, Hl, hk);
+            const int64_t off = (int64_t)grid_row * p.dh_row_stride + (int64_t)row0 * p.dcols + p.dh_off[d][l];
+            apply_act_grad_ld(cbuf, ldH, p.gact + p.dh_base + off, p.gdpre + off, p.dcols, nrows, TB, Hl, hk);
             __syncthreads();
             const ASrc A{cbuf, ldH, cbuf, ldH};
-            const PB B = make_pb(p.pack + p.pkdb_off[d][l], Kin, Hl, 0);              // W_l^T [in x out]
-            if (l == 0) {
-                layer_nt<RT>(A, B, [&](int row, int col, float v) {
+            if (l == 0) {                                                             // W_l^T [in x out]
+                dec_layer<RT>(p, sW, p.pkdb_off[d][l], p.dec_b_off, A, Kin, Hl, [&](int row, int col, float v) {
                     if (col < S) lds_st(G + row * ldS + col, lds_ld(G + row * ldS + col) + v);
                 });
             } else {
-                layer_nt<RT>(A, B, [&](int row, int col, float v) {
+                dec_layer<RT>(p, sW, p.pkdb_off[d][l], p.dec_b_off, A, Kin, Hl, [&](int row, int col, float v) {
                     if (col < Kin) lds_st(nbuf + row * ldH + col, v);
                 });
                 const lp t = cbuf; cbuf = nbuf; nbuf = t;
@@ -1577,6 +1662,8 @@ __global__ __launch_bounds__(NT) void k_gen_bwd(const DevPlan* __restrict__ P, m
     for (int idx = threadIdx.x; idx < TB * ldH; idx += NT) { lds_st(sH[0] + idx, 0.f); lds_st(sH[1] + idx, 0.f); }
     for (int idx = threadIdx.x; idx < 4 * TB * 16; idx += NT) lds_st(sDz + idx, 0.f);
     for (int idx = threadIdx.x; idx < TB * LDX; idx += NT) lds_st(sDd + idx, 0.f);
+    const clp sW = smem + L.total;                         // LDS copy of the decoders' backward operands
+    if (p.dec_lds) copy_pack_to_lds(smem + L.total, p.pack + p.dec_b_off, p.dec_b_floats);
     __syncthreads();
     int cur = 0;
 
@@ -1603,7 +1690,7 @@ __global__ __launch_bounds__(NT) void k_gen_bwd(const DevPlan* __restrict__ P, m
                 }
         }
         // G_out = carry + decoder grads of row e+1 + cS * diff
-        gen_decoder_back<RT>(p, G, sDz, sDd, sH[0], sH[1], e + 1, row0, nrows);
+        gen_decoder_back<RT>(p, sW, G, sDz, sDd, sH[0], sH[1], e + 1, row0, nrows);
         for (int r = wave; r < TB; r += 4)
             for (int c = lane; c < S; c += 64) lds_st(G + r * ldS + c, lds_ld(G + r * ldS + c) + cS * lds_ld(sDiff + r * ldS + c));
         __syncthreads();
@@ -1680,7 +1767,598 @@ __global__ __launch_bounds__(NT) void k_gen_bwd(const DevPlan* __restrict__ P, m
     }
     // row 0: decoders on the init state; dS0 = d loss / d tiled init state
     const lp G = sG[cur];
-    gen_decoder_back<RT>(p, G, sDz, sDd, sH[0], sH[1], 0, row0, nrows);
+    gen_decoder_back<RT>(p, sW, G, sDz, sDd, sH[0], sH[1], 0, row0, nrows);
+    store_rows(p.dS + ((int64_t)E * p.maxB + row0) * S, G, ldS, nrows, S);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast form of the generic tier (k_genf_fwd / k_genf_bwd): all encoders MIMIC_MLPEncoder with <= 3
+// layers, hidden widths <= 64, features and state <= 128, and the decoders' operands resident in LDS.
+// The sequential form above pays one dependent global round trip (~2 us on the busy chip) per LAYER:
+// the weight fragments, the bias in the epilogue, the activations for act'.  With ~60 layer
+// evaluations per tile and direction that is the whole run time.  Here every global read of one
+// encoder step is issued in ONE batch, a whole step ahead of its use:
+//   forward : the next encoder's x tile, dropout multipliers and weight fragments (registers) are
+//             requested before the decoders of the current state run; all biases and the decoders'
+//             operands sit in LDS (one coalesced copy per workgroup)
+//   backward: s_out / s_in / hidden activations / dz / the decoders' hidden activations of the grid
+//             row and the encoder's W^T fragments are requested together at the top of the step and
+//             parked in LDS; act' then reads LDS
+// ------------------------------------------------------------------------------------------------
+struct GenFastLds { ChainLds c; int sW, sBias, sActD, sOut, sActE, total; };
+__host__ __device__ inline GenFastLds gen_fast_lds(int TB, int ldS, int ldH, int wfloats, int nbias, int dcols, bool bwd) {
+    GenFastLds L;
+    L.c = chain_lds(TB, ldS, ldH);
+    int o = L.c.total;
+    L.sW = o; o += round_up(wfloats, 4);
+    L.sBias = o; o += round_up(nbias, 4);
+    L.sActD = o; L.sOut = o; L.sActE = o;
+    if (bwd) {
+        L.sActD = o; o += TB * round_up(dcols > 0 ? dcols : 4, 4);
+        L.sOut = o; o += TB * ldS;
+        L.sActE = o; o += 2 * TB * ldH;
+    }
+    L.total = o;
+    return L;
+}
+
+template <int RT> struct GenEncRegs {
+    f32x4 x[2 * RT], mx[2 * RT], ms[2 * RT];   // thread -> row (tid + NT k) >> 5, 4 columns at ((tid + NT k) & 31) << 2
+    f32x4 b0[TQ][2], b1[4][2], b2[4][2];       // this wave's weight fragments of the (up to) three layers
+};
+
+// unconditional 4-float read from a clamped address, zeroed by select (no branch around the loads)
+__device__ __forceinline__ f32x4 ld4_masked(const float* __restrict__ base, int64_t off, int c, int limit, bool row_ok) {
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool ok = row_ok && (c + j) < limit;
+        const float t = g_ld(base + (ok ? off + j : 0));
+        v[j] = ok ? t : 0.f;
+    }
+    return v;
+}
+
+template <int RT>
+__device__ __forceinline__ void issue_gen_encoder(GenEncRegs<RT>& R, LPlan& p, const mmn_batch& b, int e, int slot, int row0,
+                                                  int nrows) {
+    const int wave = wave_id();
+    const auto& enc = p.m.enc[e];
+    const int S = p.S, F = enc.n_features, FS = F + S, nl = enc.n_layers;
+    const float* xg = b.x[slot] + (int64_t)row0 * b.ldx[slot];
+    const int64_t ldx = b.ldx[slot];
+    const float* mk = b.drop_mask[e] ? b.drop_mask[e] + (int64_t)row0 * FS : nullptr;
+#pragma unroll
+    for (int k = 0; k < 2 * RT; ++k) {
+        const int idx = threadIdx.x + NT * k;
+        const int row = idx >> 5, c = (idx & 31) << 2;
+        const bool rok = row < nrows;
+        R.x[k] = ld4_masked(xg, (int64_t)row * ldx + c, c, F, rok);
+        if (mk) {
+            R.mx[k] = ld4_masked(mk, (int64_t)row * FS + c, c, F, rok);
+            R.ms[k] = ld4_masked(mk, (int64_t)row * FS + F + c, c, S, rok);
+        } else {
+            R.mx[k] = f32x4{1.f, 1.f, 1.f, 1.f};
+            R.ms[k] = f32x4{1.f, 1.f, 1.f, 1.f};
+        }
+    }
+    const int n0[2] = {16 * wave, 16 * (wave + 4)};
+    issue_b<TQ>(R.b0, make_pb(p.pack + p.pkf_off[e][0], enc.layer[0].out_dim, S, F), n0, 0);
+    if (nl >= 2) issue_b<4>(R.b1, make_pb(p.pack + p.pkf_off[e][1], enc.layer[1].out_dim, enc.layer[1].in_dim, 0), n0, 0);
+    if (nl >= 3) issue_b<4>(R.b2, make_pb(p.pack + p.pkf_off[e][2], enc.layer[2].out_dim, enc.layer[2].in_dim, 0), n0, 0);
+}
+
+// one layer from prefetched fragments: this wave's (up to) two column tiles
+template <int RT, int NS, class Epi>
+__device__ __forceinline__ void layer_regs(const ASrc& A, const PB& B, f32x4 (&bq)[NS][2], Epi&& epi) {
+    const int wave = wave_id();
+    const int n0[2] = {16 * wave, 16 * (wave + 4)};
+    if (n0[0] < B.N) {
+        f32x4 acc[2][RT];
+        zero_acc<RT>(acc);
+        consume_b<RT, NS>(acc, A, B, bq, 0, B.T, n0[1] < B.N);
+        run_epilogue<RT>(acc, n0, B.N, epi);
+    }
+}
+
+// gen_decode with the biases in LDS and the decoders' operands in LDS
+template <int RT>
+__device__ __forceinline__ void genf_decode(const GenDecodeCtx& c, clp sBias, clp sS, int grid_row) {
+    constexpr int TB = 16 * RT;
+    LPlan& p = *c.p;
+    const int ldS = p.ldS, ldH = p.ldH, D = p.D, R = p.R, S = p.S;
+    const int lane = threadIdx.x & 63;
+    for (int d = 0; d < D; ++d) {
+        const auto& dec = p.m.dec[d];
+        const int nh = dec.n_hidden, hk = dec.hidden_activation;
+        clp in = sS; int ldi = ldS, K = S;
+        for (int l = 0; l < nh; ++l) {
+            const int N = dec.hidden[l].out_dim;
+            const lp out = (l & 1) ? c.sH1 : c.sH0;
+            const clp bias = sBias + p.dbias_off[d][l];
+            const ASrc A{in, ldi, in, ldi};
+            layer_nt_l<RT>(A, c.sW + (p.pkdf_off[d][l] - p.dec_f_off), N, K, 0, [&](int row, int col, float v) {
+                if (col < N) lds_st(out + row * ldH + col, act_fwd(v + lds_ld(bias + col), hk));
+            });
+            __syncthreads();
+            if (c.want_grads)
+                store_rows_ld(p.gact + p.dh_base + (int64_t)grid_row * p.dh_row_stride + (int64_t)c.row0 * p.dcols + p.dh_off[d][l],
+                              p.dcols, out, ldH, c.nrows, N);
+            in = out; ldi = ldH; K = N;
+        }
+        const clp bias = sBias + p.dbias_off[d][nh];
+        const ASrc A{in, ldi, in, ldi};
+        layer_nt_l<RT>(A, c.sW + (p.pkdf_off[d][nh] - p.dec_f_off), 2, K, 0, [&](int row, int col, float v) {
+            if (col < 2) lds_st(c.sZ + row * 16 + 2 * d + col, v + lds_ld(bias + col));
+        });
+        __syncthreads();
+    }
+    const int t = threadIdx.x;
+    const int row = t & (TB - 1), d = t / TB;
+    float lossv = 0.f;
+    int correct = 0, tp = 0, tn = 0, fp = 0, fn = 0;
+    if (d < D && row < c.nrows) {
+        const float za = lds_ld(c.sZ + row * 16 + 2 * d), zb = lds_ld(c.sZ + row * 16 + 2 * d + 1);
+        const int64_t grow = (int64_t)c.row0 + row;
+        const int y = c.y;
+        const float o0 = 1.0f / (1.0f + expf(-za));
+        const float o1 = 1.0f / (1.0f + expf(-zb));
+        const float mx = fmaxf(o0, o1);
+        const float lse = mx + logf(expf(o0 - mx) + expf(o1 - mx));
+        lossv = lse - (y ? o1 : o0);
+        const int pred = o1 > o0 ? 1 : 0;          // torch.max: first index wins ties
+        correct = pred == y;
+        tp = pred & y; tn = (1 - pred) & (1 - y); fp = pred & (1 - y); fn = (1 - pred) & y;
+        f32x2 ov;
+        if (c.want_grads) {
+            const float g0 = expf(o0 - lse) - (y == 0 ? 1.0f : 0.0f);
+            const float g1 = expf(o1 - lse) - (y == 1 ? 1.0f : 0.0f);
+            ov.x = c.cL * g0 * o0 * (1.0f - o0);
+            ov.y = c.cL * g1 * o1 * (1.0f - o1);
+        } else {
+            ov.x = o0; ov.y = o1;
+        }
+        g_st2(p.dz + ((int64_t)grid_row * p.maxB + grow) * (2 * D) + 2 * d, ov);
+    }
+#pragma unroll
+    for (int off = TB / 2; off >= 1; off >>= 1) lossv += __shfl_xor(lossv, off);
+    const unsigned long long mc = __ballot(correct), mtp = __ballot(tp), mtn = __ballot(tn),
+                             mfp = __ballot(fp), mfn = __ballot(fn);
+    if (row == 0 && d < D) {
+        const int sh = lane & ~(TB - 1);
+        const unsigned long long msk = (TB == 32) ? 0xFFFFFFFFull : 0xFFFFull;
+        const int64_t cell = (int64_t)c.tile * (R * D) + grid_row * D + d;
+        g_st(p.lossp + cell, lossv);
+        int32_t* cp = p.cnt + cell * 5;
+        g_sti(cp + 0, __popcll((mc >> sh) & msk));
+        g_sti(cp + 1, __popcll((mtp >> sh) & msk));
+        g_sti(cp + 2, __popcll((mtn >> sh) & msk));
+        g_sti(cp + 3, __popcll((mfp >> sh) & msk));
+        g_sti(cp + 4, __popcll((mfn >> sh) & msk));
+    }
+    __syncthreads();
+}
+
+template <int RT>
+__global__ __launch_bounds__(NT) void k_genf_fwd(const DevPlan* __restrict__ P, mmn_batch b, float cL, int want_grads) {
+    constexpr int TB = 16 * RT;
+    extern __shared__ __attribute__((aligned(16))) float smem_generic[];
+    const lp smem = (lp)smem_generic;
+    const int ldS = P->ldS, ldH = P->ldH;
+    const GenFastLds GL = gen_fast_lds(TB, ldS, ldH, P->dec_f_floats, P->n_bias, P->dcols, false);
+    const ChainLds& L = GL.c;
+    copy_plan_to_lds(P, smem + L.sPlan);
+    lp sS[2] = {smem + L.sS0, smem + L.sS1};
+    const lp sM = smem + L.sDiff;
+    lp sH[2] = {smem + L.sH0, smem + L.sH1};
+    const lp sX = smem + L.sX;
+    const lp sRed = smem + L.sRed;
+    const lp sBias = smem + GL.sBias;
+    const int tile = blockIdx.x;
+    const int row0 = tile * TB;
+    const int nrows = min(TB, b.batch - row0);
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    // operands that do not depend on the plan copy: request them first
+    copy_pack_to_lds(smem + GL.sW, P->pack + P->dec_f_off, P->dec_f_floats);
+    for (int idx = threadIdx.x; idx < P->n_bias; idx += NT) lds_st(sBias + idx, g_ld(P->biasbuf + idx));
+    __syncthreads();
+    LPlan& p = *(LPlan*)(smem + L.sPlan);
+    const int S = p.S, E = p.E;
+
+    for (int idx = threadIdx.x; idx < TB * ldS; idx += NT) {
+        const int k = idx % ldS;
+        lds_st(sS[0] + idx, k < S ? g_ld(p.m.init_state + k) : 0.f);
+        lds_st(sS[1] + idx, 0.f);
+        lds_st(sM + idx, 0.f);
+    }
+    for (int idx = threadIdx.x; idx < TB * ldH; idx += NT) { lds_st(sH[0] + idx, 0.f); lds_st(sH[1] + idx, 0.f); }
+    for (int idx = threadIdx.x; idx < TB * LDX; idx += NT) lds_st(sX + idx, 0.f);
+    for (int idx = threadIdx.x; idx < 4 * TB * 16; idx += NT) lds_st(smem + L.sZ + idx, 0.f);
+    if (tile == 0 && threadIdx.x == 0) {
+        g_sti(p.exec_flags, 1);
+        for (int e = 0; e < E; ++e) g_sti(p.exec_flags + e + 1, 0);
+        int prev = 0;
+        for (int t = 0; t < b.n_seq; ++t) {
+            if (!slot_present(b, b.seq_data[t])) continue;
+            const int e = b.seq_enc[t];
+            g_sti(p.exec_flags + e + 1, 1);
+            g_sti(p.prev_row + e, prev);
+            prev = e + 1;
+        }
+    }
+    GenDecodeCtx dc;
+    dc.p = &p; dc.sZ = smem + L.sZ; dc.sH0 = sH[0]; dc.sH1 = sH[1]; dc.sW = smem + GL.sW;
+    dc.row0 = row0; dc.nrows = nrows; dc.tile = tile; dc.cL = cL; dc.want_grads = want_grads;
+    {
+        const int row = threadIdx.x & (TB - 1), d = threadIdx.x / TB;
+        const bool ok = d < p.D && row < nrows;
+        dc.y = ok ? (int)*(const MMN_AS1 int64_t*)(b.y + ((int64_t)row0 + row) * p.D + d) : 0;
+    }
+    GenEncRegs<RT> R;
+    int tn = next_exec(b, 0);
+    if (tn < b.n_seq) issue_gen_encoder<RT>(R, p, b, b.seq_enc[tn], b.seq_data[tn], row0, nrows);
+    __syncthreads();
+
+    int cur = 0;
+    genf_decode<RT>(dc, sBias, sS[cur], 0);
+
+    while (tn < b.n_seq) {
+        const int e = b.seq_enc[tn];
+        const auto& enc = p.m.enc[e];
+        const int nl = enc.n_layers, F = enc.n_features, FS = F + S, akind = enc.activation;
+        const bool masked = b.drop_mask[e] != nullptr;
+        const int t_next = next_exec(b, tn + 1);
+        float scacc = 0.f;
+        const clp sC = sS[cur];
+        const lp sN = sS[cur ^ 1];
+        // ---- registers -> LDS images: (masked) x, (masked) state; xin for k_wgrad
+        {
+            float* xin = p.gact + p.xin_off[e] + (int64_t)row0 * FS;
+#pragma unroll
+            for (int k = 0; k < 2 * RT; ++k) {
+                const int idx = threadIdx.x + NT * k;
+                const int row = idx >> 5, c = (idx & 31) << 2;
+                f32x4 xv = R.x[k], sv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xv[j] *= R.mx[k][j];
+                lds_st4(sX + row * LDX + c, xv);
+                if (c < S) {
+                    const f32x4 s4 = lds_ld4(sC + row * ldS + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sv[j] = (c + j < S) ? s4[j] * R.ms[k][j] : 0.f;
+                    if (masked) lds_st4(sM + row * ldS + c, sv);
+                }
+                if (want_grads && row < nrows) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (c + j < F) g_st(xin + (int64_t)row * FS + c + j, xv[j]);
+                        if (c + j < S) g_st(xin + (int64_t)row * FS + F + c + j, sv[j]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const clp sIn = masked ? (clp)sM : sC;
+        auto state_epi = [&](int l) {
+            const clp bias = sBias + p.ebias_off[e][l];
+            return [&, bias](int row, int col, int, float v) {
+                if (col < S) {
+                    const float ns = act_fwd(v + lds_ld(bias + col), akind);
+                    const float dlt = ns - lds_ld(sC + row * ldS + col);
+                    if (row < nrows) scacc += dlt * dlt;              // multimodn.py:174
+                    lds_st(sN + row * ldS + col, ns);
+                }
+            };
+        };
+        auto hid_epi = [&](int l, lp out) {
+            const clp bias = sBias + p.ebias_off[e][l];
+            const int N = enc.layer[l].out_dim;
+            return [&, bias, N, out](int row, int col, int, float v) {
+                if (col < N) lds_st(out + row * ldH + col, act_fwd(v + lds_ld(bias + col), akind));
+            };
+        };
+        {   // layer 0: [state | x] (mlp_encoder.py:40-41)
+            const ASrc A{sIn, ldS, sX, LDX};
+            const PB B = make_pb(p.pack + p.pkf_off[e][0], enc.layer[0].out_dim, S, F);
+            if (nl == 1) layer_regs<RT, TQ>(A, B, R.b0, state_epi(0));
+            else layer_regs<RT, TQ>(A, B, R.b0, hid_epi(0, sH[0]));
+        }
+        __syncthreads();
+        if (nl >= 2) {
+            if (want_grads) store_rows(p.hid + p.hid_off[e][0] + (int64_t)row0 * enc.layer[0].out_dim, sH[0], ldH, nrows, enc.layer[0].out_dim);
+            const ASrc A{sH[0], ldH, sH[0], ldH};
+            const PB B = make_pb(p.pack + p.pkf_off[e][1], enc.layer[1].out_dim, enc.layer[1].in_dim, 0);
+            if (nl == 2) layer_regs<RT, 4>(A, B, R.b1, state_epi(1));
+            else layer_regs<RT, 4>(A, B, R.b1, hid_epi(1, sH[1]));
+            __syncthreads();
+        }
+        if (nl >= 3) {
+            if (want_grads) store_rows(p.hid + p.hid_off[e][1] + (int64_t)row0 * enc.layer[1].out_dim, sH[1], ldH, nrows, enc.layer[1].out_dim);
+            const ASrc A{sH[1], ldH, sH[1], ldH};
+            const PB B = make_pb(p.pack + p.pkf_off[e][2], enc.layer[2].out_dim, enc.layer[2].in_dim, 0);
+            layer_regs<RT, 4>(A, B, R.b2, state_epi(2));
+            __syncthreads();
+        }
+        // the next encoder's inputs travel underneath the decoders of this state
+        if (t_next < b.n_seq) issue_gen_encoder<RT>(R, p, b, b.seq_enc[t_next], b.seq_data[t_next], row0, nrows);
+        scacc = wave_sum(scacc);
+        if (lane == 0) lds_st(sRed + wave, scacc);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            g_st(p.scp + (int64_t)tile * E + e, ((lds_ld(sRed) + lds_ld(sRed + 1)) + lds_ld(sRed + 2)) + lds_ld(sRed + 3));
+        store_rows(p.states + ((int64_t)e * p.maxB + row0) * S, sN, ldS, nrows, S);
+        cur ^= 1;
+        genf_decode<RT>(dc, sBias, sS[cur], e + 1);
+        tn = t_next;
+    }
+}
+
+// act' applied with the layer's OUTPUT read from an LDS tile: sBuf (raw dh) -> sBuf and global dpre (row stride ldg)
+__device__ __forceinline__ void apply_act_grad_l(lp sBuf, int ld, clp hL, int ldh, float* __restrict__ dpre_g, int64_t ldg,
+                                                 int nrows, int rows_pad, int H, int akind) {
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    for (int r = wave; r < rows_pad; r += 4)
+        for (int c = lane; c < H; c += 64) {
+            float dp = 0.f;
+            if (r < nrows) {
+                dp = lds_ld(sBuf + r * ld + c) * act_grad_from_out(lds_ld(hL + r * ldh + c), akind);
+                g_st(dpre_g + (int64_t)r * ldg + c, dp);
+            }
+            lds_st(sBuf + r * ld + c, dp);
+        }
+}
+
+template <int RT> struct GenBwdRegs {
+    f32x4 so[2 * RT], si[2 * RT], ms[2 * RT];  // s_out, s_in, state-column dropout multipliers: row (tid + NT k) >> 5, cols ((..) & 31) << 2
+    f32x4 h0[RT], h1[RT];                      // hidden activations: row (tid + NT k) >> 4, cols ((..) & 15) << 2
+    float dz[RT];                              // dz tile of the grid row: row (tid + NT k) >> 4, col (..) & 15
+    f32x4 da[8];                               // the decoders' hidden activations of the grid row: flat chunk
+    f32x4 bL[8][2], bM[4][2], b0[4][2];        // W^T fragments: the layer contracting over S; a middle layer; the carry
+};
+
+template <int RT>
+__device__ __forceinline__ void issue_gen_bwd(GenBwdRegs<RT>& R, LPlan& p, const mmn_batch& b, int e, int prev_row, int grid_row,
+                                              int row0, int nrows, bool with_encoder) {
+    constexpr int TB = 16 * RT;
+    const int wave = wave_id();
+    const int S = p.S, D2 = 2 * p.D;
+    if (with_encoder) {
+        const auto& enc = p.m.enc[e];
+        const int F = enc.n_features, FS = F + S, nl = enc.n_layers;
+        const float* so = p.states + ((int64_t)e * p.maxB + row0) * S;
+        const float* si = prev_row ? p.states + ((int64_t)(prev_row - 1) * p.maxB + row0) * S : nullptr;
+        const float* mk = b.drop_mask[e] ? b.drop_mask[e] + (int64_t)row0 * FS + F : nullptr;
+#pragma unroll
+        for (int k = 0; k < 2 * RT; ++k) {
+            const int idx = threadIdx.x + NT * k;
+            const int row = idx >> 5, c = (idx & 31) << 2;
+            const bool rok = row < nrows;
+            R.so[k] = ld4_masked(so, (int64_t)row * S + c, c, S, rok);
+            R.si[k] = si ? ld4_masked(si, (int64_t)row * S + c, c, S, rok) : ld4_masked(p.m.init_state, c, c, S, rok);
+            R.ms[k] = mk ? ld4_masked(mk, (int64_t)row * FS + c, c, S, rok) : f32x4{1.f, 1.f, 1.f, 1.f};
+        }
+#pragma unroll
+        for (int k = 0; k < RT; ++k) {
+            const int idx = threadIdx.x + NT * k;
+            const int row = idx >> 4, c = (idx & 15) << 2;
+            const bool rok = row < nrows;
+            const int H0 = enc.layer[0].out_dim, H1 = nl >= 3 ? enc.layer[1].out_dim : 0;
+            R.h0[k] = nl >= 2 ? ld4_masked(p.hid + p.hid_off[e][0] + (int64_t)row0 * H0, (int64_t)row * H0 + c, c, H0, rok)
+                              : f32x4{0.f, 0.f, 0.f, 0.f};
+            R.h1[k] = nl >= 3 ? ld4_masked(p.hid + p.hid_off[e][1] + (int64_t)row0 * H1, (int64_t)row * H1 + c, c, H1, rok)
+                              : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int n0[2] = {16 * wave, 16 * (wave + 4)};
+        const int H0 = enc.layer[0].out_dim;
+        if (nl == 1) {
+            issue_b<8>(R.bL, make_pb(p.pack + p.pkb_off[e][0], S, H0, 0), n0, 0);              // carry contracts over S
+        } else {
+            issue_b<8>(R.bL, make_pb(p.pack + p.pkb_off[e][nl - 1], enc.layer[nl - 1].in_dim, S, 0), n0, 0);
+            if (nl == 3) issue_b<4>(R.bM, make_pb(p.pack + p.pkb_off[e][1], enc.layer[1].in_dim, enc.layer[1].out_dim, 0), n0, 0);
+            issue_b<4>(R.b0, make_pb(p.pack + p.pkb_off[e][0], S, H0, 0), n0, 0);
+        }
+    }
+    // dz tile and the decoders' hidden activations of this grid row (one contiguous chunk per tile)
+#pragma unroll
+    for (int k = 0; k < RT; ++k) {
+        const int idx = threadIdx.x + NT * k;
+        const int row = idx >> 4, n = idx & 15;
+        const bool ok = row < nrows && n < D2;
+        const float v = g_ld(p.dz + ((int64_t)grid_row * p.maxB + row0) * D2 + (ok ? row * D2 + n : 0));
+        R.dz[k] = ok ? v : 0.f;
+    }
+    const float* da = p.gact + p.dh_base + (int64_t)grid_row * p.dh_row_stride + (int64_t)row0 * p.dcols;
+    const int nda = nrows * p.dcols;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx4 = (threadIdx.x + NT * k) * 4;
+        const bool ok = idx4 < nda;
+        const f32x4 v = g_ld4(da + (ok ? idx4 : 0));
+        R.da[k] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// G += d loss / d state through the decoders of one grid row: dz in sDz, activations in sActD [TB x dcols], operands in LDS
+template <int RT>
+__device__ __forceinline__ void genf_decoder_back(LPlan& p, clp sW, lp G, clp sDz, lp sDd, clp sActD, lp sH0, lp sH1, int grid_row,
+                                                  int row0, int nrows) {
+    constexpr int TB = 16 * RT;
+    const int ldS = p.ldS, ldH = p.ldH, S = p.S, D = p.D, dcols = p.dcols;
+    for (int d = 0; d < D; ++d) {
+        const auto& dec = p.m.dec[d];
+        const int nh = dec.n_hidden, hk = dec.hidden_activation;
+        for (int idx = threadIdx.x; idx < TB * 2; idx += NT) {
+            const int row = idx >> 1, c = idx & 1;
+            lds_st(sDd + row * LDZ + c, lds_ld(sDz + row * LDZ + 2 * d + c));
+        }
+        __syncthreads();
+        const ASrc Ad{sDd, LDZ, sDd, LDZ};
+        if (nh == 0) {
+            layer_nt_l<RT>(Ad, sW + (p.pkdb_off[d][0] - p.dec_b_off), S, 2, 0, [&](int row, int col, float v) {
+                if (col < S) lds_st(G + row * ldS + col, lds_ld(G + row * ldS + col) + v);
+            });
+            __syncthreads();
+            continue;
+        }
+        lp cbuf = sH0, nbuf = sH1;
+        {
+            const int Hl = dec.hidden[nh - 1].out_dim;
+            layer_nt_l<RT>(Ad, sW + (p.pkdb_off[d][nh] - p.dec_b_off), Hl, 2, 0, [&](int row, int col, float v) {
+                if (col < Hl) lds_st(cbuf + row * ldH + col, v);
+            });
+            __syncthreads();
+        }
+        for (int l = nh - 1; l >= 0; --l) {
+            const int Hl = dec.hidden[l].out_dim, Kin = dec.hidden[l].in_dim;
+            const int64_t off = (int64_t)grid_row * p.dh_row_stride + (int64_t)row0 * dcols + p.dh_off[d][l];
+            apply_act_grad_l(cbuf, ldH, sActD + p.dh_off[d][l], dcols, p.gdpre + off, dcols, nrows, TB, Hl, hk);
+            __syncthreads();
+            const ASrc A{cbuf, ldH, cbuf, ldH};
+            clp w = sW + (p.pkdb_off[d][l] - p.dec_b_off);
+            if (l == 0) {
+                layer_nt_l<RT>(A, w, Kin, Hl, 0, [&](int row, int col, float v) {
+                    if (col < S) lds_st(G + row * ldS + col, lds_ld(G + row * ldS + col) + v);
+                });
+            } else {
+                layer_nt_l<RT>(A, w, Kin, Hl, 0, [&](int row, int col, float v) {
+                    if (col < Kin) lds_st(nbuf + row * ldH + col, v);
+                });
+                const lp t = cbuf; cbuf = nbuf; nbuf = t;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int RT>
+__global__ __launch_bounds__(NT) void k_genf_bwd(const DevPlan* __restrict__ P, mmn_batch b, float cS) {
+    constexpr int TB = 16 * RT;
+    extern __shared__ __attribute__((aligned(16))) float smem_generic[];
+    const lp smem = (lp)smem_generic;
+    const int ldS = P->ldS, ldH = P->ldH;
+    const GenFastLds GL = gen_fast_lds(TB, ldS, ldH, P->dec_b_floats, P->n_bias, P->dcols, true);
+    const ChainLds& L = GL.c;
+    copy_plan_to_lds(P, smem + L.sPlan);
+    copy_pack_to_lds(smem + GL.sW, P->pack + P->dec_b_off, P->dec_b_floats);
+    __syncthreads();
+    LPlan& p = *(LPlan*)(smem + L.sPlan);
+    const int S = p.S, E = p.E, dcols = p.dcols;
+    lp sG[2] = {smem + L.sS0, smem + L.sS1};
+    const lp sDiff = smem + L.sDiff;
+    lp sH[2] = {smem + L.sH0, smem + L.sH1};
+    const lp sDz = smem + L.sZ;
+    const lp sDd = smem + L.sZ + 2 * TB * 16;              // one decoder's dz pair, [TB x LDZ]
+    const lp sMs = smem + L.sX;                            // state-column dropout multipliers, [TB x LDX]
+    const clp sW = smem + GL.sW;
+    const lp sActD = smem + GL.sActD;
+    const lp sOut = smem + GL.sOut;
+    lp sActE[2] = {smem + GL.sActE, smem + GL.sActE + TB * ldH};
+    const int tile = blockIdx.x;
+    const int row0 = tile * TB;
+    const int nrows = min(TB, b.batch - row0);
+    const int lane = threadIdx.x & 63, wave = wave_id();
+
+    for (int idx = threadIdx.x; idx < TB * ldS; idx += NT) { lds_st(sG[0] + idx, 0.f); lds_st(sG[1] + idx, 0.f); lds_st(sDiff + idx, 0.f); lds_st(sOut + idx, 0.f); }
+    for (int idx = threadIdx.x; idx < TB * ldH; idx += NT) { lds_st(sH[0] + idx, 0.f); lds_st(sH[1] + idx, 0.f); lds_st(sActE[0] + idx, 0.f); lds_st(sActE[1] + idx, 0.f); }
+    for (int idx = threadIdx.x; idx < 4 * TB * 16; idx += NT) lds_st(sDz + idx, 0.f);
+    for (int idx = threadIdx.x; idx < TB * LDX; idx += NT) lds_st(sMs + idx, 0.f);
+    __syncthreads();
+    int cur = 0;
+    GenBwdRegs<RT> R;
+
+    // registers -> LDS: the grid row's dz tile and decoder activations (every step), the encoder's tiles (encoder steps)
+    auto park = [&](bool with_encoder, int nl) {
+        if (with_encoder) {
+#pragma unroll
+            for (int k = 0; k < 2 * RT; ++k) {
+                const int idx = threadIdx.x + NT * k;
+                const int row = idx >> 5, c = (idx & 31) << 2;
+                if (c < S) {                                   // (the state tiles are only round_up(S, 16) + 4 floats wide)
+                    lds_st4(sOut + row * ldS + c, R.so[k]);
+                    f32x4 df;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) df[j] = R.so[k][j] - R.si[k][j];
+                    lds_st4(sDiff + row * ldS + c, df);
+                    lds_st4(sMs + row * LDX + c, R.ms[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < RT; ++k) {
+                const int idx = threadIdx.x + NT * k;
+                const int row = idx >> 4, c = (idx & 15) << 2;
+                if (c + 4 <= ldH) {                            // (hidden tiles: ldH >= round_up(width, 16) + 4)
+                    if (nl >= 2) lds_st4(sActE[0] + row * ldH + c, R.h0[k]);
+                    if (nl >= 3) lds_st4(sActE[1] + row * ldH + c, R.h1[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RT; ++k) {
+            const int idx = threadIdx.x + NT * k;
+            lds_st(sDz + (idx >> 4) * LDZ + (idx & 15), R.dz[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx4 = (threadIdx.x + NT * k) * 4;
+            if (idx4 < TB * dcols) lds_st4(sActD + idx4, R.da[k]);
+        }
+    };
+
+    for (int t = b.n_seq - 1; t >= 0; --t) {
+        const int slot = b.seq_data[t];
+        if (!slot_present(b, slot)) continue;
+        const int e = b.seq_enc[t];
+        int tp = t - 1;
+        while (tp >= 0 && !slot_present(b, b.seq_data[tp])) --tp;
+        const int prev_row = tp >= 0 ? b.seq_enc[tp] + 1 : 0;
+        const auto& enc = p.m.enc[e];
+        const int nl = enc.n_layers, akind = enc.activation;
+        const lp G = sG[cur];
+        const lp Gn = sG[cur ^ 1];
+        issue_gen_bwd<RT>(R, p, b, e, prev_row, e + 1, row0, nrows, true);    // ONE batch of global reads for the whole step
+        park(true, nl);
+        __syncthreads();
+        // G_out = carry + decoder grads of row e+1 + cS * diff
+        genf_decoder_back<RT>(p, sW, G, sDz, sDd, sActD, sH[0], sH[1], e + 1, row0, nrows);
+        for (int r = wave; r < TB; r += 4)
+            for (int c = lane; c < S; c += 64) lds_st(G + r * ldS + c, lds_ld(G + r * ldS + c) + cS * lds_ld(sDiff + r * ldS + c));
+        __syncthreads();
+        // the state layer carries the activation: dpre_last = G .* act'(s_out) = what k_wgrad multiplies (dS[e])
+        apply_act_grad_l(G, ldS, sOut, ldS, p.dS + ((int64_t)e * p.maxB + row0) * S, S, nrows, TB, S, akind);
+        __syncthreads();
+        clp cbuf = G; int ldc = ldS;
+        for (int l = nl - 1; l >= 1; --l) {
+            const int Hl = enc.layer[l].out_dim, Hp = enc.layer[l].in_dim;
+            const lp nbuf = sH[l & 1];
+            const ASrc A{cbuf, ldc, cbuf, ldc};
+            const PB B = make_pb(p.pack + p.pkb_off[e][l], Hp, Hl, 0);                // W_l^T [in x out]
+            auto epi = [&](int row, int col, int, float v) { if (col < Hp) lds_st(nbuf + row * ldH + col, v); };
+            if (l == nl - 1) layer_regs<RT, 8>(A, B, R.bL, epi);
+            else layer_regs<RT, 4>(A, B, R.bM, epi);
+            __syncthreads();
+            apply_act_grad_l(nbuf, ldH, sActE[l - 1], ldH, p.dpre + p.hid_off[e][l - 1] + (int64_t)row0 * Hp, Hp, nrows, TB, Hp, akind);
+            __syncthreads();
+            cbuf = nbuf; ldc = ldH;
+        }
+        {   // carry = (dpre_0 * W_0[:, F:F+S]) .* mask_state - cS * diff ; no grad flows to x
+            const int H0 = enc.layer[0].out_dim;
+            const ASrc A{cbuf, ldc, cbuf, ldc};
+            const PB B = make_pb(p.pack + p.pkb_off[e][0], S, H0, 0);
+            auto epi = [&](int row, int col, int, float v) {
+                if (col < S) lds_st(Gn + row * ldS + col, v * lds_ld(sMs + row * LDX + col) - cS * lds_ld(sDiff + row * ldS + col));
+            };
+            if (nl == 1) layer_regs<RT, 8>(A, B, R.bL, epi);
+            else layer_regs<RT, 4>(A, B, R.b0, epi);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // row 0: decoders on the init state; dS0 = d loss / d tiled init state
+    const lp G = sG[cur];
+    issue_gen_bwd<RT>(R, p, b, 0, 0, 0, row0, nrows, false);
+    park(false, 0);
+    __syncthreads();
+    genf_decoder_back<RT>(p, sW, G, sDz, sDd, sActD, sH[0], sH[1], 0, row0, nrows);
     store_rows(p.dS + ((int64_t)E * p.maxB + row0) * S, G, ldS, nrows, S);
 }
 
@@ -4282,6 +4960,9 @@ struct mmn_plan {
     int grad_blocks;
     int rt_override;
     int generic;             // k_gen_fwd / k_gen_bwd (a MIMIC_MLPEncoder or an MLPDecoder in the model)
+    int dec_lds_rt;          // 0: decoder operands from global memory; 1: in LDS with 16-row tiles only; 2: any tile height
+    int gen_fast;            // k_genf_fwd / k_genf_bwd apply (0, or the largest RT their LDS carve admits)
+    size_t gen_lds_fwd[3], gen_lds_bwd[3];   // by RT: chain carve (+ the LDS copy of the decoders' operands when it fits)
 };
 
 static thread_local int g_last_hip = 0;
@@ -4358,8 +5039,15 @@ struct Layout {
     int64_t xin_off[MMN_MAX_ENCODERS];
     int64_t dh_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN];
     int64_t dh_row_stride, dh_base, gact_floats, gdpre_floats;
+    int dcols;
     int64_t pkdf_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];
     int64_t pkdb_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];
+    int64_t dec_f_off, dec_b_off, dec_f_floats, dec_b_floats;
+    size_t off_biasbuf, off_biassrc;
+    std::vector<const float*> bias_src;
+    int32_t ebias_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
+    int32_t dbias_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];
+    int gen_fast;
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -4395,18 +5083,20 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
         if (L.generic)
             for (int e = 0; e < E; ++e)
                 if (m.enc[e].kind == MMN_ENC_MIMIC) { L.xin_off[e] = go; go += (int64_t)maxB * (m.enc[e].n_features + S); }
+        go = (go + 3) / 4 * 4;                             // 16-byte aligned tile chunks
         L.dh_base = go;
-        int64_t ro = 0;
-        if (L.generic)
+        int64_t ro = 0;                                    // columns: the decoders' hidden layers side by side, so that
+        if (L.generic)                                     // one tile's activations of a grid row are one contiguous chunk
             for (int d = 0; d < D; ++d)
                 for (int l = 0; l < m.dec[d].n_hidden; ++l) {
                     L.dh_off[d][l] = ro;
-                    ro += (int64_t)maxB * m.dec[d].hidden[l].out_dim;
+                    ro += round_up(m.dec[d].hidden[l].out_dim, 4);
                     maxh = maxh > m.dec[d].hidden[l].out_dim ? maxh : m.dec[d].hidden[l].out_dim;
                 }
-        L.dh_row_stride = ro;
-        L.gact_floats = go + ro * R;
-        L.gdpre_floats = ro * R;
+        L.dcols = (int)ro;
+        L.dh_row_stride = ro * maxB;
+        L.gact_floats = go + L.dh_row_stride * R;
+        L.gdpre_floats = L.dh_row_stride * R;
     }
     L.ldH = pick_ld(maxh);
 
@@ -4474,7 +5164,9 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     }
     memset(L.pkdf_off, 0, sizeof(L.pkdf_off));
     memset(L.pkdb_off, 0, sizeof(L.pkdb_off));
-    if (L.generic) {                                       // per-decoder operands of the generic tier
+    L.dec_f_off = L.dec_b_off = po; L.dec_f_floats = L.dec_b_floats = 0;
+    if (L.generic) {                                       // per-decoder operands of the generic tier: all forward
+        L.dec_f_off = po;                                  // operands contiguous, then all backward ones (one LDS copy each)
         for (int d = 0; d < D; ++d) {
             const mmn_decoder& dec = m.dec[d];
             int in = S;
@@ -4482,15 +5174,26 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
                 const mmn_linear& lin = dec.hidden[l];
                 L.pkdf_off[d][l] = po;
                 po += add_pack(lin.w, lin.in_dim, 0, lin.out_dim, lin.in_dim, 0, 0, 0, 0, 0, po);
-                L.pkdb_off[d][l] = po;
-                po += add_pack(lin.w, lin.in_dim, 1, lin.in_dim, lin.out_dim, 0, 0, 0, 0, 0, po);
                 in = lin.out_dim;
             }
             L.pkdf_off[d][dec.n_hidden] = po;              // output Linear [2 x in]
             po += add_pack(dec.w, in, 0, 2, in, 0, 0, 0, 0, 0, po);
+        }
+        L.dec_f_floats = po - L.dec_f_off;
+        L.dec_b_off = po;
+        for (int d = 0; d < D; ++d) {
+            const mmn_decoder& dec = m.dec[d];
+            int in = S;
+            for (int l = 0; l < dec.n_hidden; ++l) {
+                const mmn_linear& lin = dec.hidden[l];
+                L.pkdb_off[d][l] = po;
+                po += add_pack(lin.w, lin.in_dim, 1, lin.in_dim, lin.out_dim, 0, 0, 0, 0, 0, po);
+                in = lin.out_dim;
+            }
             L.pkdb_off[d][dec.n_hidden] = po;              // its transpose [in x 2]
             po += add_pack(dec.w, in, 1, in, 2, 0, 0, 0, 0, 0, po);
         }
+        L.dec_b_floats = po - L.dec_b_off;
     }
     L.pack_floats = po;
     L.pack_elems = L.ptasks.back().start + (int64_t)L.ptasks.back().ntiles * L.ptasks.back().T * 256;
@@ -4594,9 +5297,9 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
                     WTask t{};
                     t.M = odim;
                     if (out_layer) { t.a_kind = A_DZ; t.a_idx = r; t.a_col = 2 * d; }
-                    else { t.a_kind = A_GEN; t.a_gen_off = (int64_t)r * L.dh_row_stride + L.dh_off[d][l]; t.gen_lda = odim; }
+                    else { t.a_kind = A_GEN; t.a_gen_off = (int64_t)r * L.dh_row_stride + L.dh_off[d][l]; t.gen_lda = L.dcols; }
                     if (l == 0) { t.in0_kind = IN_STATE_ROW; t.in0_idx = r; }
-                    else { t.in0_kind = IN_GEN; t.in_gen_off = L.dh_base + (int64_t)r * L.dh_row_stride + L.dh_off[d][l - 1]; t.gen_ldi = idim; }
+                    else { t.in0_kind = IN_GEN; t.in_gen_off = L.dh_base + (int64_t)r * L.dh_row_stride + L.dh_off[d][l - 1]; t.gen_ldi = L.dcols; }
                     t.k0 = idim; t.in1_kind = IN_NONE; t.k1 = 0;
                     t.bias = 1; t.ntot = idim + 1; t.gate = r;
                     t.part_base = nA * ks + (int64_t)r * ks * nB; t.part_stride = nB;
@@ -4715,6 +5418,31 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     L.off_ps = take(sizeof(int32_t) * 3 * (size_t)maxB);      // per-sample regrouping scratch: codes, masks, source rows
     L.off_gact = take(sizeof(float) * (size_t)L.gact_floats);
     L.off_gdpre = take(sizeof(float) * (size_t)L.gdpre_floats);
+    // bias gather table (generic tier only)
+    memset(L.ebias_off, 0, sizeof(L.ebias_off));
+    memset(L.dbias_off, 0, sizeof(L.dbias_off));
+    if (L.generic) {
+        auto add_bias = [&](const float* b, int n) { const int at = (int)L.bias_src.size(); for (int k = 0; k < n; ++k) L.bias_src.push_back(b + k); return at; };
+        for (int e = 0; e < E; ++e)
+            for (int l = 0; l < m.enc[e].n_layers; ++l) L.ebias_off[e][l] = add_bias(m.enc[e].layer[l].b, m.enc[e].layer[l].out_dim);
+        for (int d = 0; d < D; ++d) {
+            for (int l = 0; l < m.dec[d].n_hidden; ++l) L.dbias_off[d][l] = add_bias(m.dec[d].hidden[l].b, m.dec[d].hidden[l].out_dim);
+            L.dbias_off[d][m.dec[d].n_hidden] = add_bias(m.dec[d].b, 2);
+        }
+    }
+    L.off_biasbuf = take(sizeof(float) * L.bias_src.size());
+    L.off_biassrc = take(sizeof(const float*) * L.bias_src.size());
+    // fast form of the generic tier: every encoder a MIMIC_MLPEncoder whose operands fit the register prefetch
+    // (<= 3 layers, hidden widths <= 64, features / state <= 128, layer 0 within TQ k-steps)
+    L.gen_fast = L.generic && S <= 128 && L.dcols <= 256 ? 1 : 0;
+    for (int e = 0; e < E && L.gen_fast; ++e) {
+        const mmn_encoder& enc = m.enc[e];
+        bool ok = enc.kind == MMN_ENC_MIMIC && enc.n_layers <= 3 && enc.n_features <= 128 &&
+                  (round_up(S, 16) + round_up(enc.n_features, 16)) / 16 <= TQ;
+        for (int l = 0; l + 1 < enc.n_layers; ++l) ok = ok && enc.layer[l].out_dim <= 64;
+        if (!ok) L.gen_fast = 0;
+    }
+    if (const char* gf = getenv("MMN_GEN_FAST")) { if (atoi(gf) == 0) L.gen_fast = 0; }
     L.total = o;
 }
 
@@ -4829,9 +5557,16 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     h.gdpre = reinterpret_cast<float*>(ws + L.off_gdpre);
     memcpy(h.xin_off, L.xin_off, sizeof(h.xin_off));
     memcpy(h.dh_off, L.dh_off, sizeof(h.dh_off));
-    h.dh_row_stride = L.dh_row_stride; h.dh_base = L.dh_base;
+    h.dh_row_stride = L.dh_row_stride; h.dh_base = L.dh_base; h.dcols = L.dcols;
     memcpy(h.pkdf_off, L.pkdf_off, sizeof(h.pkdf_off));
     memcpy(h.pkdb_off, L.pkdb_off, sizeof(h.pkdb_off));
+    h.dec_f_off = L.dec_f_off; h.dec_b_off = L.dec_b_off;
+    h.dec_f_floats = (int32_t)L.dec_f_floats; h.dec_b_floats = (int32_t)L.dec_b_floats;
+    h.biasbuf = reinterpret_cast<float*>(ws + L.off_biasbuf);
+    h.bias_src = reinterpret_cast<const float* const*>(ws + L.off_biassrc);
+    h.n_bias = (int32_t)L.bias_src.size();
+    memcpy(h.ebias_off, L.ebias_off, sizeof(h.ebias_off));
+    memcpy(h.dbias_off, L.dbias_off, sizeof(h.dbias_off));
     pl->generic = L.generic;
     pl->dev = reinterpret_cast<DevPlan*>(ws + L.off_plan);
     pl->wg = WgArgs{h.recs, h.dpre, h.dS, h.dz, h.states, h.hid, m->init_state, h.slabs, h.stamps, h.sin, h.maxB, h.S,
@@ -4914,7 +5649,36 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     pl->lds_bytes[0] = 0;
     for (int rt = 1; rt <= 2; ++rt) pl->lds_bytes[rt] = sizeof(float) * (size_t)chain_lds(16 * rt, h.ldS, h.ldH).total;
     if (pl->lds_bytes[1] > 160 * 1024) { delete pl; return MMN_ERR_UNSUPPORTED; }
-
+    {   // generic tier: LDS budgets.  Sequential form: the decoders' operands ride along when both directions fit next to
+        // the 32-row carve (so that the choice does not depend on the batch), else next to the 16-row one with 16-row
+        // tiles only.  Fast form: its own carve (operands + biases + parked activations).
+        const size_t extra_f = sizeof(float) * (size_t)L.dec_f_floats, extra_b = sizeof(float) * (size_t)L.dec_b_floats;
+        const size_t extra = extra_f > extra_b ? extra_f : extra_b;
+        int fit = 0, fast = 0;
+        auto fast_bytes = [&](int rt, bool bwd) {
+            return sizeof(float) * (size_t)gen_fast_lds(16 * rt, h.ldS, h.ldH, (int)(bwd ? L.dec_b_floats : L.dec_f_floats),
+                                                        (int)L.bias_src.size(), L.dcols, bwd).total;
+        };
+        if (L.generic && L.gen_fast) {
+            if (fast_bytes(2, false) <= 160 * 1024 && fast_bytes(2, true) <= 160 * 1024 && L.dcols * 32 <= 8192) fast = 2;
+            else if (fast_bytes(1, false) <= 160 * 1024 && fast_bytes(1, true) <= 160 * 1024) fast = 1;
+        }
+        if (!fast && L.generic && !(getenv("MMN_DEC_LDS") && atoi(getenv("MMN_DEC_LDS")) == 0)) {
+            if (pl->lds_bytes[2] + extra <= 160 * 1024) fit = 2;
+            else if (pl->lds_bytes[1] + extra <= 160 * 1024) fit = 1;
+        }
+        h.dec_lds = (fit || fast) ? 1 : 0;
+        h.gen_fast = fast ? 1 : 0;
+        pl->dec_lds_rt = fast ? fast : fit;
+        pl->gen_fast = fast;
+        for (int rt = 0; rt <= 2; ++rt) {
+            pl->gen_lds_fwd[rt] = fast ? (rt ? fast_bytes(rt, false) : 0) : pl->lds_bytes[rt] + (fit ? extra_f : 0);
+            pl->gen_lds_bwd[rt] = fast ? (rt ? fast_bytes(rt, true) : 0) : pl->lds_bytes[rt] + (fit ? extra_b : 0);
+        }
+        if (getenv("MMN_VERBOSE"))
+            fprintf(stderr, "[mmn] generic=%d fast=%d dec_lds=%d lds fwd=%zu/%zu bwd=%zu/%zu dcols=%d n_bias=%zu\n", L.generic, fast,
+                    h.dec_lds, pl->gen_lds_fwd[1], pl->gen_lds_fwd[2], pl->gen_lds_bwd[1], pl->gen_lds_bwd[2], L.dcols, L.bias_src.size());
+    }
     auto fail = [&](hipError_t e) { g_last_hip = (int)e; delete pl; return MMN_ERR_HIP; };
     hipError_t e;
     if ((e = hipMemcpy(pl->dev, &h, sizeof(h), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
@@ -4923,6 +5687,9 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     if ((e = hipMemcpy(h.recs, L.recs.data(), sizeof(WRec) * L.recs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h.segs, L.segs.data(), sizeof(Seg) * L.segs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h.ptasks, L.ptasks.data(), sizeof(PackTask) * L.ptasks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if (!L.bias_src.empty() &&
+        (e = hipMemcpy(const_cast<const float**>(h.bias_src), L.bias_src.data(), sizeof(const float*) * L.bias_src.size(),
+                       hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemset(h.epoch, 0, sizeof(double) * mmn_epoch_doubles(m))) != hipSuccess) return fail(e);
     if ((e = hipMemset(h.exec_flags, 0, sizeof(int32_t) * (h.R + h.E + MMN_MAX_ENCODERS))) != hipSuccess) return fail(e);
     if ((e = hipMemset(h.pack, 0, sizeof(float) * (size_t)L.pack_floats)) != hipSuccess) return fail(e);
@@ -4932,10 +5699,12 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     if (L.gact_floats && (e = hipMemset(h.gact, 0, sizeof(float) * (size_t)L.gact_floats)) != hipSuccess) return fail(e);
     if (L.gdpre_floats && (e = hipMemset(h.gdpre, 0, sizeof(float) * (size_t)L.gdpre_floats)) != hipSuccess) return fail(e);
     if (L.generic) {
-        const void* gf[4] = {reinterpret_cast<const void*>(k_gen_fwd<1>), reinterpret_cast<const void*>(k_gen_fwd<2>),
-                             reinterpret_cast<const void*>(k_gen_bwd<1>), reinterpret_cast<const void*>(k_gen_bwd<2>)};
+        const void* gf[4] = {pl->gen_fast ? reinterpret_cast<const void*>(k_genf_fwd<1>) : reinterpret_cast<const void*>(k_gen_fwd<1>),
+                             pl->gen_fast ? reinterpret_cast<const void*>(k_genf_fwd<2>) : reinterpret_cast<const void*>(k_gen_fwd<2>),
+                             pl->gen_fast ? reinterpret_cast<const void*>(k_genf_bwd<1>) : reinterpret_cast<const void*>(k_gen_bwd<1>),
+                             pl->gen_fast ? reinterpret_cast<const void*>(k_genf_bwd<2>) : reinterpret_cast<const void*>(k_gen_bwd<2>)};
         for (int k = 0; k < 4; ++k) {
-            const size_t need = pl->lds_bytes[1 + (k & 1)];
+            const size_t need = (k < 2 ? pl->gen_lds_fwd : pl->gen_lds_bwd)[1 + (k & 1)];
             if (need <= 160 * 1024 &&
                 (e = hipFuncSetAttribute(gf[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)need)) != hipSuccess)
                 return fail(e);
@@ -5021,6 +5790,7 @@ static bool use_fb8(const mmn_plan* p, const mmn_batch* b) { return p->fb8_ok &&
 
 static int rt_for(const mmn_plan* p, const mmn_batch* b) {
     if (p->par_ok) return 1;                 // the parallel-phase kernels use 16-row tiles
+    if (p->generic && p->dec_lds_rt == 1) return 1;
     int rt = choose_rt(p, b->batch);
     if (p->lds_bytes[rt] > 160 * 1024) rt = 1;
     return rt;
@@ -5029,6 +5799,7 @@ static int rt_for(const mmn_plan* p, const mmn_batch* b) {
 const char* mmn_chain_kernel_name(mmn_plan* p, const mmn_batch* b, int backward) {
     if (!p || !b) return "";
     if (backward == 2) return use_fb8(p, b) ? "k_fb8" : "";
+    if (p->generic && p->gen_fast) return backward ? "k_genf_bwd" : "k_genf_fwd";
     if (p->generic) return backward ? "k_gen_bwd" : "k_gen_fwd";
     if (use_fast8(p, b)) return backward ? "k_bwd8" : "k_fwd8";
     if (p->par_ok) return backward ? "k_chain_bwd_par" : "k_chain_fwd_par";
@@ -5047,7 +5818,7 @@ int mmn_prepare(mmn_plan* p, const mmn_batch* b, int want_grads, void* stream) {
     }
     // the forward operands are needed by eval steps too, so the repack always runs
     (void)want_grads;
-    const int tblocks = (int)((p->host.n_pack_elems + NT - 1) / NT);
+    const int tblocks = (int)((p->host.n_pack_elems + p->host.n_bias + NT - 1) / NT);
     if (scan_blocks + tblocks == 0) return MMN_OK;
     mmn_batch bb = *b;
     hipLaunchKernelGGL(k_prepare, dim3(scan_blocks + tblocks), dim3(NT), 0, static_cast<hipStream_t>(stream), p->dev, bb,
@@ -5069,9 +5840,12 @@ int mmn_chain_fwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float sc_p
     const float cL = err_penalty / ((float)p->m.n_decoders * (float)(p->m.n_encoders + 1) * (float)b->batch_global);
     mmn_batch bb = *b;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (p->generic) {
-        if (rt == 1) hipLaunchKernelGGL(k_gen_fwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cL, want_grads);
-        else hipLaunchKernelGGL(k_gen_fwd<2>, dim3(tiles), dim3(NT), p->lds_bytes[2], st, p->dev, bb, cL, want_grads);
+    if (p->generic && p->gen_fast) {
+        if (rt == 1) hipLaunchKernelGGL(k_genf_fwd<1>, dim3(tiles), dim3(NT), p->gen_lds_fwd[1], st, p->dev, bb, cL, want_grads);
+        else hipLaunchKernelGGL(k_genf_fwd<2>, dim3(tiles), dim3(NT), p->gen_lds_fwd[2], st, p->dev, bb, cL, want_grads);
+    } else if (p->generic) {
+        if (rt == 1) hipLaunchKernelGGL(k_gen_fwd<1>, dim3(tiles), dim3(NT), p->gen_lds_fwd[1], st, p->dev, bb, cL, want_grads);
+        else hipLaunchKernelGGL(k_gen_fwd<2>, dim3(tiles), dim3(NT), p->gen_lds_fwd[2], st, p->dev, bb, cL, want_grads);
     } else if (use_fast8(p, b)) hipLaunchKernelGGL(k_fwd8, dim3(tiles), dim3(NT8), p->f8_lds_fwd, st, p->pa, bb, cL, want_grads);
     else if (p->par_ok) hipLaunchKernelGGL(k_chain_fwd_par, dim3(tiles), dim3(NT), p->par_lds_fwd, st, p->dev, bb, cL, want_grads);
     else if (rt == 1) hipLaunchKernelGGL(k_chain_fwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cL, want_grads);
@@ -5093,9 +5867,12 @@ int mmn_chain_bwd(mmn_plan* p, const mmn_batch* b, float sc_pen_x001, void* stre
     mmn_batch bb = *b;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float cS = sc_coeff(p, b, sc_pen_x001);
-    if (p->generic) {
-        if (rt == 1) hipLaunchKernelGGL(k_gen_bwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cS);
-        else hipLaunchKernelGGL(k_gen_bwd<2>, dim3(tiles), dim3(NT), p->lds_bytes[2], st, p->dev, bb, cS);
+    if (p->generic && p->gen_fast) {
+        if (rt == 1) hipLaunchKernelGGL(k_genf_bwd<1>, dim3(tiles), dim3(NT), p->gen_lds_bwd[1], st, p->dev, bb, cS);
+        else hipLaunchKernelGGL(k_genf_bwd<2>, dim3(tiles), dim3(NT), p->gen_lds_bwd[2], st, p->dev, bb, cS);
+    } else if (p->generic) {
+        if (rt == 1) hipLaunchKernelGGL(k_gen_bwd<1>, dim3(tiles), dim3(NT), p->gen_lds_bwd[1], st, p->dev, bb, cS);
+        else hipLaunchKernelGGL(k_gen_bwd<2>, dim3(tiles), dim3(NT), p->gen_lds_bwd[2], st, p->dev, bb, cS);
     } else if (use_fast8(p, b)) hipLaunchKernelGGL(k_bwd8, dim3(tiles), dim3(NT8), p->f8_lds_bwd, st, p->pa, bb, cS);
     else if (p->par_ok) hipLaunchKernelGGL(k_chain_bwd_par, dim3(tiles), dim3(NT), p->par_lds_bwd, st, p->dev, bb, cS);
     else if (rt == 1) hipLaunchKernelGGL(k_chain_bwd<1>, dim3(tiles), dim3(NT), p->lds_bytes[1], st, p->dev, bb, cS);

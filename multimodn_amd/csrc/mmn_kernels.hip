@@ -185,7 +185,8 @@ struct DevPlan {
     int64_t xin_off[MMN_MAX_ENCODERS];                           // float offsets into gact (-1: not a MIMIC encoder)
     int64_t dh_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN];        // first COLUMN of (d, l) inside a grid row's [maxB x dcols] block
     int64_t dh_row_stride;                                       // floats per grid row = maxB * dcols (gact and gdpre alike)
-    int32_t dcols, pad7;                                         // hidden widths of all decoders side by side
+    int32_t dcols, dec_maxnh;                                    // hidden widths of all decoders side by side; deepest decoder
+    int32_t dwf_off[MMN_MAX_DECODERS];                           // raw output Linear [2 x in] of decoder d inside biasbuf
     int64_t dh_base;                                             // start of the dhid blocks inside gact
     int64_t pkdf_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];  // forward operand of decoder layer l (last = output Linear)
     int64_t pkdb_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];  // backward operand (W^T)
@@ -1771,6 +1772,45 @@ __global__ __launch_bounds__(NT) void k_gen_bwd(const DevPlan* __restrict__ P, m
     store_rows(p.dS + ((int64_t)E * p.maxB + row0) * S, G, ldS, nrows, S);
 }
 
+// Everything the fast kernels need to know about the model, as a KERNEL ARGUMENT: scalar loads from the kernarg
+// segment that the compiler may hoist and keep in SGPRs.  (Through the LDS copy of the plan every "p.m.dec[d]..."
+// is a dependent ds_read that cannot be hoisted over the LDS stores around it: measured, the descriptor reads alone
+// made one decoder pass cost 9 us for 1.5 us of MFMA work.)  Same member names as DevPlan so that the code reads alike.
+constexpr int GF_MAXE = 8, GF_MAXD = 8, GF_MAXL = 3;
+// One (decoder, column tile) product of a decoder phase, fully resolved on the host: a wave reads its items from an
+// LDS copy of this table (a few 16-byte reads) instead of chasing "dec[d].hidden[ph]..." through scalar loads at every
+// phase (measured: ~1.2 us of dependent descriptor loads per phase against 0.3-1.3 us of MFMA work).
+struct GfItem {
+    int32_t a_col;          // A operand: first column inside the wide activation tile, or -1 = the state tile
+    int32_t T;              // k-steps
+    int32_t w_off;          // this tile's fragments: float offset inside the LDS copy of the decoder operands
+    int32_t bias_off;       // offset of the layer's bias inside the LDS bias copy
+    int32_t out_col;        // hidden layer: first column of the layer's slot in the wide tile; output layer: 2 d
+    int32_t n_valid;        // valid output columns of the layer (N)
+    int32_t col0;           // first column of this tile inside the layer
+    int32_t kind_hk;        // bit 8: output layer; low bits: hidden activation
+};
+constexpr int GF_PHASES = MMN_MAX_DEC_HIDDEN + 1, GF_SLOTS = 4;
+struct GfItemTable { int32_t cnt[GF_PHASES][4]; GfItem item[GF_PHASES][4][GF_SLOTS]; };
+struct GfLinear { int32_t out_dim, in_dim; };
+struct GfEncoder { int32_t n_layers, n_features, activation, pad; GfLinear layer[GF_MAXL]; };
+struct GfDecoder { int32_t n_hidden, hidden_activation; GfLinear hidden[MMN_MAX_DEC_HIDDEN]; };
+struct GfModel { const float* init_state; GfEncoder enc[GF_MAXE]; GfDecoder dec[GF_MAXD]; };
+struct GenArgs {
+    GfModel m;
+    int32_t S, E, D, R, ldS, ldH, maxB, dcols, dec_maxnh, n_bias, dec_f_floats, dec_b_floats;
+    const float* pack; const float* biasbuf;
+    float* states; float* hid; float* dpre; float* dz; float* dS; float* gact; float* gdpre;
+    float* lossp; float* scp; int32_t* cnt; int32_t* exec_flags; int32_t* prev_row; long long* stamps;
+    int64_t dec_f_off, dec_b_off, dh_base, dh_row_stride;
+    int64_t pkf_off[GF_MAXE][GF_MAXL], pkb_off[GF_MAXE][GF_MAXL], hid_off[GF_MAXE][GF_MAXL], xin_off[GF_MAXE];
+    int64_t pkdf_off[GF_MAXD][MMN_MAX_DEC_HIDDEN + 1], pkdb_off[GF_MAXD][MMN_MAX_DEC_HIDDEN + 1];
+    int32_t dh_off[GF_MAXD][MMN_MAX_DEC_HIDDEN];
+    int32_t ebias_off[GF_MAXE][GF_MAXL], dbias_off[GF_MAXD][MMN_MAX_DEC_HIDDEN + 1], dwf_off[GF_MAXD];
+    const GfItemTable* items_f;        // forward decoder phases (device copy inside the workspace)
+};
+typedef const GenArgs GPlan;
+
 // ------------------------------------------------------------------------------------------------
 // Fast form of the generic tier (k_genf_fwd / k_genf_bwd): all encoders MIMIC_MLPEncoder with <= 3
 // layers, hidden widths <= 64, features and state <= 128, and the decoders' operands resident in LDS.
@@ -1785,21 +1825,57 @@ __global__ __launch_bounds__(NT) void k_gen_bwd(const DevPlan* __restrict__ P, m
 //             row and the encoder's W^T fragments are requested together at the top of the step and
 //             parked in LDS; act' then reads LDS
 // ------------------------------------------------------------------------------------------------
-struct GenFastLds { ChainLds c; int sW, sBias, sActD, sOut, sActE, total; };
+struct GenFastLds { ChainLds c; int sW, sBias, sItems, sActD, ldD, sOut, sActE, total; };
 __host__ __device__ inline GenFastLds gen_fast_lds(int TB, int ldS, int ldH, int wfloats, int nbias, int dcols, bool bwd) {
     GenFastLds L;
     L.c = chain_lds(TB, ldS, ldH);
+    // (no LDS copy of the plan here: the descriptor is a kernel argument)
+    L.c.sS0 -= PLAN_FLOATS; L.c.sS1 -= PLAN_FLOATS; L.c.sDiff -= PLAN_FLOATS; L.c.sH0 -= PLAN_FLOATS; L.c.sH1 -= PLAN_FLOATS;
+    L.c.sX -= PLAN_FLOATS; L.c.sZ -= PLAN_FLOATS; L.c.sRed -= PLAN_FLOATS; L.c.total -= PLAN_FLOATS;
     int o = L.c.total;
     L.sW = o; o += round_up(wfloats, 4);
     L.sBias = o; o += round_up(nbias, 4);
-    L.sActD = o; L.sOut = o; L.sActE = o;
+    L.sItems = o; o += (int)(sizeof(GfItemTable) / 4);
+    L.ldD = pick_ld(dcols > 0 ? dcols : 16);               // all decoders' hidden layers side by side: [TB x ldD]
+    L.sActD = o; o += TB * L.ldD;
+    L.sOut = o; L.sActE = o;
     if (bwd) {
-        L.sActD = o; o += TB * round_up(dcols > 0 ? dcols : 4, 4);
         L.sOut = o; o += TB * ldS;
         L.sActE = o; o += 2 * TB * ldH;
     }
     L.total = o;
     return L;
+}
+
+// one wave, one 16-column tile: acc += A[rows x 16 T] * W'[tile]^T, both operands in LDS, next k-step's
+// fragments requested before this one's MFMAs
+template <int RT>
+__device__ __forceinline__ void wave_tile_l(f32x4 (&acc)[RT], clp a, int lda, clp w_tile, int T) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, q = lane >> 4;
+    clp ap = a + i * lda + 4 * q;
+    clp bp = w_tile + lane * 4;
+    f32x4 bb = lds_ld4(bp);
+    f32x4 av[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) av[r] = lds_ld4(ap + r * 16 * lda);
+    for (int t = 0; t < T; ++t) {
+        const int tn = min(t + 1, T - 1);
+        const f32x4 bn = lds_ld4(bp + tn * 256);
+        f32x4 an[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) an[r] = lds_ld4(ap + 16 * tn + r * 16 * lda);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            acc[r] = mfma4(av[r].x, bb.x, acc[r]);
+            acc[r] = mfma4(av[r].y, bb.y, acc[r]);
+            acc[r] = mfma4(av[r].z, bb.z, acc[r]);
+            acc[r] = mfma4(av[r].w, bb.w, acc[r]);
+        }
+        bb = bn;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) av[r] = an[r];
+    }
 }
 
 template <int RT> struct GenEncRegs {
@@ -1820,7 +1896,7 @@ __device__ __forceinline__ f32x4 ld4_masked(const float* __restrict__ base, int6
 }
 
 template <int RT>
-__device__ __forceinline__ void issue_gen_encoder(GenEncRegs<RT>& R, LPlan& p, const mmn_batch& b, int e, int slot, int row0,
+__device__ __forceinline__ void issue_gen_encoder(GenEncRegs<RT>& R, GPlan& p, const mmn_batch& b, int e, int slot, int row0,
                                                   int nrows) {
     const int wave = wave_id();
     const auto& enc = p.m.enc[e];
@@ -1861,38 +1937,68 @@ __device__ __forceinline__ void layer_regs(const ASrc& A, const PB& B, f32x4 (&b
     }
 }
 
-// gen_decode with the biases in LDS and the decoders' operands in LDS
+// All D decoders on one state tile, layer by layer ACROSS the decoders: phase ph evaluates hidden layer ph of every
+// decoder that has one and the output Linear of every decoder with exactly ph hidden layers; the (decoder, column
+// tile) pairs of a phase are dealt to the four waves, one barrier per phase.  Operands and biases in LDS; the hidden
+// activations of all decoders live side by side in sDA [TB x ldD] and leave as ONE contiguous chunk.
+struct GenfCtx {
+    lp sZ; clp sW; clp sItems;
+    int y, row0, nrows, tile;
+    float cL;
+    int want_grads;
+};
+
 template <int RT>
-__device__ __forceinline__ void genf_decode(const GenDecodeCtx& c, clp sBias, clp sS, int grid_row) {
+__device__ __forceinline__ void genf_decode(GPlan& p, const GenfCtx& c, clp sBias, lp sDA, int ldD, clp sS, int grid_row,
+                                            int& stamp_k) {
     constexpr int TB = 16 * RT;
-    LPlan& p = *c.p;
-    const int ldS = p.ldS, ldH = p.ldH, D = p.D, R = p.R, S = p.S;
-    const int lane = threadIdx.x & 63;
-    for (int d = 0; d < D; ++d) {
-        const auto& dec = p.m.dec[d];
-        const int nh = dec.n_hidden, hk = dec.hidden_activation;
-        clp in = sS; int ldi = ldS, K = S;
-        for (int l = 0; l < nh; ++l) {
-            const int N = dec.hidden[l].out_dim;
-            const lp out = (l & 1) ? c.sH1 : c.sH0;
-            const clp bias = sBias + p.dbias_off[d][l];
-            const ASrc A{in, ldi, in, ldi};
-            layer_nt_l<RT>(A, c.sW + (p.pkdf_off[d][l] - p.dec_f_off), N, K, 0, [&](int row, int col, float v) {
-                if (col < N) lds_st(out + row * ldH + col, act_fwd(v + lds_ld(bias + col), hk));
-            });
-            __syncthreads();
-            if (c.want_grads)
-                store_rows_ld(p.gact + p.dh_base + (int64_t)grid_row * p.dh_row_stride + (int64_t)c.row0 * p.dcols + p.dh_off[d][l],
-                              p.dcols, out, ldH, c.nrows, N);
-            in = out; ldi = ldH; K = N;
+    const int stamp_block = 7;
+    const int ldS = p.ldS, D = p.D, R = p.R, S = p.S;
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int i = lane & 15, q = lane >> 4;
+    const MMN_AS3 GfItemTable* tab = (const MMN_AS3 GfItemTable*)c.sItems;
+    for (int ph = 0; ph <= p.dec_maxnh; ++ph) {
+        const int n_it = __builtin_amdgcn_readfirstlane(tab->cnt[ph][wave]);
+        for (int sl = 0; sl < n_it; ++sl) {
+            const MMN_AS3 int32_t* ip = (const MMN_AS3 int32_t*)&tab->item[ph][wave][sl];
+            const int a_col = __builtin_amdgcn_readfirstlane(ip[0]), T = __builtin_amdgcn_readfirstlane(ip[1]);
+            const int w_off = __builtin_amdgcn_readfirstlane(ip[2]), bias_off = __builtin_amdgcn_readfirstlane(ip[3]);
+            const int out_col = __builtin_amdgcn_readfirstlane(ip[4]), N = __builtin_amdgcn_readfirstlane(ip[5]);
+            const int col0 = __builtin_amdgcn_readfirstlane(ip[6]), kh = __builtin_amdgcn_readfirstlane(ip[7]);
+            const bool fin = (kh & 256) != 0;
+            const int hk = kh & 255;
+            clp a = a_col < 0 ? sS : (clp)(sDA + a_col);
+            const int lda = a_col < 0 ? ldS : ldD;
+            f32x4 acc[RT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            wave_tile_l<RT>(acc, a, lda, c.sW + w_off, T);
+            const int col = col0 + i;
+            const float bv = col < N ? lds_ld(sBias + bias_off + col) : 0.f;
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = r * 16 + q * 4 + k;
+                    if (fin) {
+                        if (col < 2) lds_st(c.sZ + row * 16 + out_col + col, acc[r][k] + bv);
+                    } else {                                // padding columns of the slot stay finite (zero)
+                        lds_st(sDA + row * ldD + out_col + col, col < N ? act_fwd(acc[r][k] + bv, hk) : 0.f);
+                    }
+                }
         }
-        const clp bias = sBias + p.dbias_off[d][nh];
-        const ASrc A{in, ldi, in, ldi};
-        layer_nt_l<RT>(A, c.sW + (p.pkdf_off[d][nh] - p.dec_f_off), 2, K, 0, [&](int row, int col, float v) {
-            if (col < 2) lds_st(c.sZ + row * 16 + 2 * d + col, v + lds_ld(bias + col));
-        });
         __syncthreads();
+        STAMP();   // d.ph
     }
+    if (c.want_grads && p.dcols > 0) {                      // one contiguous [nrows x dcols] chunk
+        float* dst = p.gact + p.dh_base + (int64_t)grid_row * p.dh_row_stride + (int64_t)c.row0 * p.dcols;
+        const int c4n = p.dcols >> 2;
+        for (int idx = threadIdx.x; idx < c.nrows * c4n; idx += NT) {
+            const int row = idx / c4n, c4 = idx - row * c4n;
+            g_st4(dst + (int64_t)row * p.dcols + 4 * c4, lds_ld4(sDA + row * ldD + 4 * c4));
+        }
+    }
+    STAMP();   // d.store
     const int t = threadIdx.x;
     const int row = t & (TB - 1), d = t / TB;
     float lossv = 0.f;
@@ -1940,30 +2046,36 @@ __device__ __forceinline__ void genf_decode(const GenDecodeCtx& c, clp sBias, cl
 }
 
 template <int RT>
-__global__ __launch_bounds__(NT) void k_genf_fwd(const DevPlan* __restrict__ P, mmn_batch b, float cL, int want_grads) {
+__global__ __launch_bounds__(NT) void k_genf_fwd(const GenArgs ga, const mmn_batch b, float cL, int want_grads) {
     constexpr int TB = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) float smem_generic[];
     const lp smem = (lp)smem_generic;
+    GPlan& p = ga;
+    const GenArgs* P = &ga;
     const int ldS = P->ldS, ldH = P->ldH;
     const GenFastLds GL = gen_fast_lds(TB, ldS, ldH, P->dec_f_floats, P->n_bias, P->dcols, false);
     const ChainLds& L = GL.c;
-    copy_plan_to_lds(P, smem + L.sPlan);
     lp sS[2] = {smem + L.sS0, smem + L.sS1};
     const lp sM = smem + L.sDiff;
     lp sH[2] = {smem + L.sH0, smem + L.sH1};
     const lp sX = smem + L.sX;
     const lp sRed = smem + L.sRed;
     const lp sBias = smem + GL.sBias;
+    const lp sDA = smem + GL.sActD;
     const int tile = blockIdx.x;
     const int row0 = tile * TB;
     const int nrows = min(TB, b.batch - row0);
     const int lane = threadIdx.x & 63, wave = wave_id();
+    int stamp_k = 0;
+    const int stamp_block = 7;
     // operands that do not depend on the plan copy: request them first
     copy_pack_to_lds(smem + GL.sW, P->pack + P->dec_f_off, P->dec_f_floats);
     for (int idx = threadIdx.x; idx < P->n_bias; idx += NT) lds_st(sBias + idx, g_ld(P->biasbuf + idx));
+    for (int idx = threadIdx.x; idx < (int)(sizeof(GfItemTable) / 4); idx += NT)
+        lds_st(smem + GL.sItems + idx, g_ld(reinterpret_cast<const float*>(P->items_f) + idx));
     __syncthreads();
-    LPlan& p = *(LPlan*)(smem + L.sPlan);
     const int S = p.S, E = p.E;
+    STAMP();   // 0: plan, decoder operands, biases in LDS
 
     for (int idx = threadIdx.x; idx < TB * ldS; idx += NT) {
         const int k = idx % ldS;
@@ -1974,6 +2086,7 @@ __global__ __launch_bounds__(NT) void k_genf_fwd(const DevPlan* __restrict__ P, 
     for (int idx = threadIdx.x; idx < TB * ldH; idx += NT) { lds_st(sH[0] + idx, 0.f); lds_st(sH[1] + idx, 0.f); }
     for (int idx = threadIdx.x; idx < TB * LDX; idx += NT) lds_st(sX + idx, 0.f);
     for (int idx = threadIdx.x; idx < 4 * TB * 16; idx += NT) lds_st(smem + L.sZ + idx, 0.f);
+    for (int idx = threadIdx.x; idx < TB * GL.ldD; idx += NT) lds_st(sDA + idx, 0.f);
     if (tile == 0 && threadIdx.x == 0) {
         g_sti(p.exec_flags, 1);
         for (int e = 0; e < E; ++e) g_sti(p.exec_flags + e + 1, 0);
@@ -1986,8 +2099,8 @@ __global__ __launch_bounds__(NT) void k_genf_fwd(const DevPlan* __restrict__ P, 
             prev = e + 1;
         }
     }
-    GenDecodeCtx dc;
-    dc.p = &p; dc.sZ = smem + L.sZ; dc.sH0 = sH[0]; dc.sH1 = sH[1]; dc.sW = smem + GL.sW;
+    GenfCtx dc;
+    dc.sZ = smem + L.sZ; dc.sW = smem + GL.sW; dc.sItems = smem + GL.sItems;
     dc.row0 = row0; dc.nrows = nrows; dc.tile = tile; dc.cL = cL; dc.want_grads = want_grads;
     {
         const int row = threadIdx.x & (TB - 1), d = threadIdx.x / TB;
@@ -2000,7 +2113,9 @@ __global__ __launch_bounds__(NT) void k_genf_fwd(const DevPlan* __restrict__ P, 
     __syncthreads();
 
     int cur = 0;
-    genf_decode<RT>(dc, sBias, sS[cur], 0);
+    STAMP();   // 1: init done, first encoder requested
+    genf_decode<RT>(p, dc, sBias, sDA, GL.ldD, sS[cur], 0, stamp_k);
+    STAMP();   // 2: decode row 0
 
     while (tn < b.n_seq) {
         const int e = b.seq_enc[tn];
@@ -2038,6 +2153,7 @@ __global__ __launch_bounds__(NT) void k_genf_fwd(const DevPlan* __restrict__ P, 
             }
         }
         __syncthreads();
+        STAMP();   // e.0: x / state images staged (waits for the prefetched x, masks)
         const clp sIn = masked ? (clp)sM : sC;
         auto state_epi = [&](int l) {
             const clp bias = sBias + p.ebias_off[e][l];
@@ -2064,6 +2180,7 @@ __global__ __launch_bounds__(NT) void k_genf_fwd(const DevPlan* __restrict__ P, 
             else layer_regs<RT, TQ>(A, B, R.b0, hid_epi(0, sH[0]));
         }
         __syncthreads();
+        STAMP();   // e.1: layer 0
         if (nl >= 2) {
             if (want_grads) store_rows(p.hid + p.hid_off[e][0] + (int64_t)row0 * enc.layer[0].out_dim, sH[0], ldH, nrows, enc.layer[0].out_dim);
             const ASrc A{sH[0], ldH, sH[0], ldH};
@@ -2079,6 +2196,7 @@ __global__ __launch_bounds__(NT) void k_genf_fwd(const DevPlan* __restrict__ P, 
             layer_regs<RT, 4>(A, B, R.b2, state_epi(2));
             __syncthreads();
         }
+        STAMP();   // e.2: layers 1, 2
         // the next encoder's inputs travel underneath the decoders of this state
         if (t_next < b.n_seq) issue_gen_encoder<RT>(R, p, b, b.seq_enc[t_next], b.seq_data[t_next], row0, nrows);
         scacc = wave_sum(scacc);
@@ -2088,7 +2206,9 @@ __global__ __launch_bounds__(NT) void k_genf_fwd(const DevPlan* __restrict__ P, 
             g_st(p.scp + (int64_t)tile * E + e, ((lds_ld(sRed) + lds_ld(sRed + 1)) + lds_ld(sRed + 2)) + lds_ld(sRed + 3));
         store_rows(p.states + ((int64_t)e * p.maxB + row0) * S, sN, ldS, nrows, S);
         cur ^= 1;
-        genf_decode<RT>(dc, sBias, sS[cur], e + 1);
+        STAMP();   // e.3: next encoder requested, state-change partial, state stored
+        genf_decode<RT>(p, dc, sBias, sDA, GL.ldD, sS[cur], e + 1, stamp_k);
+        STAMP();   // e.4: decode
         tn = t_next;
     }
 }
@@ -2117,7 +2237,7 @@ template <int RT> struct GenBwdRegs {
 };
 
 template <int RT>
-__device__ __forceinline__ void issue_gen_bwd(GenBwdRegs<RT>& R, LPlan& p, const mmn_batch& b, int e, int prev_row, int grid_row,
+__device__ __forceinline__ void issue_gen_bwd(GenBwdRegs<RT>& R, GPlan& p, const mmn_batch& b, int e, int prev_row, int grid_row,
                                               int row0, int nrows, bool with_encoder) {
     constexpr int TB = 16 * RT;
     const int wave = wave_id();
@@ -2180,7 +2300,7 @@ __device__ __forceinline__ void issue_gen_bwd(GenBwdRegs<RT>& R, LPlan& p, const
 
 // G += d loss / d state through the decoders of one grid row: dz in sDz, activations in sActD [TB x dcols], operands in LDS
 template <int RT>
-__device__ __forceinline__ void genf_decoder_back(LPlan& p, clp sW, lp G, clp sDz, lp sDd, clp sActD, lp sH0, lp sH1, int grid_row,
+__device__ __forceinline__ void genf_decoder_back(GPlan& p, clp sW, lp G, clp sDz, lp sDd, clp sActD, lp sH0, lp sH1, int grid_row,
                                                   int row0, int nrows) {
     constexpr int TB = 16 * RT;
     const int ldS = p.ldS, ldH = p.ldH, S = p.S, D = p.D, dcols = p.dcols;
@@ -2231,17 +2351,17 @@ __device__ __forceinline__ void genf_decoder_back(LPlan& p, clp sW, lp G, clp sD
 }
 
 template <int RT>
-__global__ __launch_bounds__(NT) void k_genf_bwd(const DevPlan* __restrict__ P, mmn_batch b, float cS) {
+__global__ __launch_bounds__(NT) void k_genf_bwd(const GenArgs ga, const mmn_batch b, float cS) {
     constexpr int TB = 16 * RT;
     extern __shared__ __attribute__((aligned(16))) float smem_generic[];
     const lp smem = (lp)smem_generic;
+    GPlan& p = ga;
+    const GenArgs* P = &ga;
     const int ldS = P->ldS, ldH = P->ldH;
     const GenFastLds GL = gen_fast_lds(TB, ldS, ldH, P->dec_b_floats, P->n_bias, P->dcols, true);
     const ChainLds& L = GL.c;
-    copy_plan_to_lds(P, smem + L.sPlan);
     copy_pack_to_lds(smem + GL.sW, P->pack + P->dec_b_off, P->dec_b_floats);
     __syncthreads();
-    LPlan& p = *(LPlan*)(smem + L.sPlan);
     const int S = p.S, E = p.E, dcols = p.dcols;
     lp sG[2] = {smem + L.sS0, smem + L.sS1};
     const lp sDiff = smem + L.sDiff;
@@ -4962,6 +5082,7 @@ struct mmn_plan {
     int generic;             // k_gen_fwd / k_gen_bwd (a MIMIC_MLPEncoder or an MLPDecoder in the model)
     int dec_lds_rt;          // 0: decoder operands from global memory; 1: in LDS with 16-row tiles only; 2: any tile height
     int gen_fast;            // k_genf_fwd / k_genf_bwd apply (0, or the largest RT their LDS carve admits)
+    GenArgs ga;              // their kernel-argument descriptor
     size_t gen_lds_fwd[3], gen_lds_bwd[3];   // by RT: chain carve (+ the LDS copy of the decoders' operands when it fits)
 };
 
@@ -5039,11 +5160,13 @@ struct Layout {
     int64_t xin_off[MMN_MAX_ENCODERS];
     int64_t dh_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN];
     int64_t dh_row_stride, dh_base, gact_floats, gdpre_floats;
-    int dcols;
+    int dcols, dec_maxnh;
+    int32_t dwf_off[MMN_MAX_DECODERS];
     int64_t pkdf_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];
     int64_t pkdb_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];
     int64_t dec_f_off, dec_b_off, dec_f_floats, dec_b_floats;
-    size_t off_biasbuf, off_biassrc;
+    size_t off_biasbuf, off_biassrc, off_gfitems;
+    GfItemTable items_f;
     std::vector<const float*> bias_src;
     int32_t ebias_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
     int32_t dbias_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];
@@ -5086,11 +5209,14 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
         go = (go + 3) / 4 * 4;                             // 16-byte aligned tile chunks
         L.dh_base = go;
         int64_t ro = 0;                                    // columns: the decoders' hidden layers side by side, so that
-        if (L.generic)                                     // one tile's activations of a grid row are one contiguous chunk
-            for (int d = 0; d < D; ++d)
-                for (int l = 0; l < m.dec[d].n_hidden; ++l) {
+        L.dec_maxnh = 0;                                   // one tile's activations of a grid row are one contiguous chunk;
+        if (L.generic)                                     // layer-major, every block in its own 16-column slot(s)
+            for (int l = 0; l < MMN_MAX_DEC_HIDDEN; ++l)
+                for (int d = 0; d < D; ++d) {
+                    if (l >= m.dec[d].n_hidden) continue;
+                    L.dec_maxnh = L.dec_maxnh > l + 1 ? L.dec_maxnh : l + 1;
                     L.dh_off[d][l] = ro;
-                    ro += round_up(m.dec[d].hidden[l].out_dim, 4);
+                    ro += round_up(m.dec[d].hidden[l].out_dim, 16);
                     maxh = maxh > m.dec[d].hidden[l].out_dim ? maxh : m.dec[d].hidden[l].out_dim;
                 }
         L.dcols = (int)ro;
@@ -5421,6 +5547,7 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
     // bias gather table (generic tier only)
     memset(L.ebias_off, 0, sizeof(L.ebias_off));
     memset(L.dbias_off, 0, sizeof(L.dbias_off));
+    memset(L.dwf_off, 0, sizeof(L.dwf_off));
     if (L.generic) {
         auto add_bias = [&](const float* b, int n) { const int at = (int)L.bias_src.size(); for (int k = 0; k < n; ++k) L.bias_src.push_back(b + k); return at; };
         for (int e = 0; e < E; ++e)
@@ -5429,12 +5556,16 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
             for (int l = 0; l < m.dec[d].n_hidden; ++l) L.dbias_off[d][l] = add_bias(m.dec[d].hidden[l].b, m.dec[d].hidden[l].out_dim);
             L.dbias_off[d][m.dec[d].n_hidden] = add_bias(m.dec[d].b, 2);
         }
+        for (int d = 0; d < D; ++d) {                      // raw [2 x in] output weights: the K = 2 products of the backward
+            const int in = m.dec[d].n_hidden ? m.dec[d].hidden[m.dec[d].n_hidden - 1].out_dim : S;   // half are plain FMAs
+            L.dwf_off[d] = add_bias(m.dec[d].w, 2 * in);
+        }
     }
     L.off_biasbuf = take(sizeof(float) * L.bias_src.size());
     L.off_biassrc = take(sizeof(const float*) * L.bias_src.size());
     // fast form of the generic tier: every encoder a MIMIC_MLPEncoder whose operands fit the register prefetch
     // (<= 3 layers, hidden widths <= 64, features / state <= 128, layer 0 within TQ k-steps)
-    L.gen_fast = L.generic && S <= 128 && L.dcols <= 256 ? 1 : 0;
+    L.gen_fast = L.generic && S <= 128 && L.dcols <= 256 && E <= GF_MAXE && D <= GF_MAXD ? 1 : 0;
     for (int e = 0; e < E && L.gen_fast; ++e) {
         const mmn_encoder& enc = m.enc[e];
         bool ok = enc.kind == MMN_ENC_MIMIC && enc.n_layers <= 3 && enc.n_features <= 128 &&
@@ -5443,6 +5574,36 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
         if (!ok) L.gen_fast = 0;
     }
     if (const char* gf = getenv("MMN_GEN_FAST")) { if (atoi(gf) == 0) L.gen_fast = 0; }
+    memset(&L.items_f, 0, sizeof(L.items_f));
+    if (L.gen_fast) {                                      // decoder phases, dealt to the four waves (see genf_decode)
+        for (int ph = 0; ph <= L.dec_maxnh && L.gen_fast; ++ph) {
+            int g = 0;
+            for (int d = 0; d < D && L.gen_fast; ++d) {
+                const mmn_decoder& dec = m.dec[d];
+                const int nh = dec.n_hidden;
+                if (ph > nh) continue;
+                const bool fin = ph == nh;
+                const int N = fin ? 2 : dec.hidden[ph].out_dim;
+                const int K = ph == 0 ? S : dec.hidden[ph - 1].out_dim;
+                const int T = (K + 15) / 16, ntl = (N + 15) / 16;
+                for (int tile = 0; tile < ntl; ++tile, ++g) {
+                    const int w = g & 3;
+                    int32_t& n = L.items_f.cnt[ph][w];
+                    if (n >= GF_SLOTS) { L.gen_fast = 0; break; }
+                    GfItem& it = L.items_f.item[ph][w][n++];
+                    it.a_col = ph == 0 ? -1 : (int32_t)L.dh_off[d][ph - 1];
+                    it.T = T;
+                    it.w_off = (int32_t)(L.pkdf_off[d][ph] - L.dec_f_off) + tile * T * 256;
+                    it.bias_off = L.dbias_off[d][ph];
+                    it.out_col = fin ? 2 * d : (int32_t)L.dh_off[d][ph];
+                    it.n_valid = N;
+                    it.col0 = 16 * tile;
+                    it.kind_hk = (fin ? 256 : 0) | (dec.hidden_activation & 255);
+                }
+            }
+        }
+    }
+    L.off_gfitems = take(sizeof(GfItemTable));
     L.total = o;
 }
 
@@ -5557,7 +5718,8 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     h.gdpre = reinterpret_cast<float*>(ws + L.off_gdpre);
     memcpy(h.xin_off, L.xin_off, sizeof(h.xin_off));
     memcpy(h.dh_off, L.dh_off, sizeof(h.dh_off));
-    h.dh_row_stride = L.dh_row_stride; h.dh_base = L.dh_base; h.dcols = L.dcols;
+    h.dh_row_stride = L.dh_row_stride; h.dh_base = L.dh_base; h.dcols = L.dcols; h.dec_maxnh = L.dec_maxnh;
+    memcpy(h.dwf_off, L.dwf_off, sizeof(h.dwf_off));
     memcpy(h.pkdf_off, L.pkdf_off, sizeof(h.pkdf_off));
     memcpy(h.pkdb_off, L.pkdb_off, sizeof(h.pkdb_off));
     h.dec_f_off = L.dec_f_off; h.dec_b_off = L.dec_b_off;
@@ -5675,6 +5837,52 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
             pl->gen_lds_fwd[rt] = fast ? (rt ? fast_bytes(rt, false) : 0) : pl->lds_bytes[rt] + (fit ? extra_f : 0);
             pl->gen_lds_bwd[rt] = fast ? (rt ? fast_bytes(rt, true) : 0) : pl->lds_bytes[rt] + (fit ? extra_b : 0);
         }
+        if (fast) {                                        // kernel-argument descriptor of the fast kernels
+            GenArgs& a = pl->ga;
+            memset(&a, 0, sizeof(a));
+            a.m.init_state = m->init_state;
+            for (int e = 0; e < h.E; ++e) {
+                const mmn_encoder& enc = m->enc[e];
+                a.m.enc[e].n_layers = enc.n_layers; a.m.enc[e].n_features = enc.n_features; a.m.enc[e].activation = enc.activation;
+                for (int l = 0; l < enc.n_layers; ++l) {
+                    a.m.enc[e].layer[l].out_dim = enc.layer[l].out_dim; a.m.enc[e].layer[l].in_dim = enc.layer[l].in_dim;
+                    a.pkf_off[e][l] = L.pkf_off[e][l]; a.pkb_off[e][l] = L.pkb_off[e][l]; a.hid_off[e][l] = L.hid_off[e][l];
+                    a.ebias_off[e][l] = L.ebias_off[e][l];
+                }
+                a.xin_off[e] = L.xin_off[e];
+            }
+            for (int d = 0; d < h.D; ++d) {
+                const mmn_decoder& dec = m->dec[d];
+                a.m.dec[d].n_hidden = dec.n_hidden; a.m.dec[d].hidden_activation = dec.hidden_activation;
+                for (int l = 0; l < dec.n_hidden; ++l) {
+                    a.m.dec[d].hidden[l].out_dim = dec.hidden[l].out_dim; a.m.dec[d].hidden[l].in_dim = dec.hidden[l].in_dim;
+                    a.dh_off[d][l] = (int32_t)L.dh_off[d][l];
+                }
+                for (int l = 0; l <= dec.n_hidden; ++l) {
+                    a.pkdf_off[d][l] = L.pkdf_off[d][l]; a.pkdb_off[d][l] = L.pkdb_off[d][l]; a.dbias_off[d][l] = L.dbias_off[d][l];
+                }
+                a.dwf_off[d] = L.dwf_off[d];
+            }
+            a.S = h.S; a.E = h.E; a.D = h.D; a.R = h.R; a.ldS = h.ldS; a.ldH = h.ldH; a.maxB = h.maxB; a.dcols = L.dcols;
+            a.dec_maxnh = L.dec_maxnh; a.n_bias = (int32_t)L.bias_src.size();
+            a.dec_f_floats = (int32_t)L.dec_f_floats; a.dec_b_floats = (int32_t)L.dec_b_floats;
+            a.pack = h.pack; a.biasbuf = h.biasbuf;
+            a.states = h.states; a.hid = h.hid; a.dpre = h.dpre; a.dz = h.dz; a.dS = h.dS; a.gact = h.gact; a.gdpre = h.gdpre;
+            a.lossp = h.lossp; a.scp = h.scp; a.cnt = h.cnt; a.exec_flags = h.exec_flags; a.prev_row = h.prev_row; a.stamps = h.stamps;
+            a.dec_f_off = L.dec_f_off; a.dec_b_off = L.dec_b_off; a.dh_base = L.dh_base; a.dh_row_stride = L.dh_row_stride;
+            a.items_f = reinterpret_cast<const GfItemTable*>(ws + L.off_gfitems);
+        }
+        if (getenv("MMN_VERBOSE")) {
+            fprintf(stderr, "[mmn] sizeof(GenArgs)=%zu sizeof(mmn_batch)=%zu sizeof(GfItemTable)=%zu\n", sizeof(GenArgs), sizeof(mmn_batch),
+                    sizeof(GfItemTable));
+            for (int ph = 0; ph < GF_PHASES; ++ph)
+                for (int w = 0; w < 4; ++w)
+                    for (int k = 0; k < L.items_f.cnt[ph][w]; ++k) {
+                        const GfItem& it = L.items_f.item[ph][w][k];
+                        fprintf(stderr, "[mmn] item ph=%d wave=%d: a_col=%d T=%d w_off=%d bias=%d out=%d N=%d col0=%d kh=%d\n", ph, w,
+                                it.a_col, it.T, it.w_off, it.bias_off, it.out_col, it.n_valid, it.col0, it.kind_hk);
+                    }
+        }
         if (getenv("MMN_VERBOSE"))
             fprintf(stderr, "[mmn] generic=%d fast=%d dec_lds=%d lds fwd=%zu/%zu bwd=%zu/%zu dcols=%d n_bias=%zu\n", L.generic, fast,
                     h.dec_lds, pl->gen_lds_fwd[1], pl->gen_lds_fwd[2], pl->gen_lds_bwd[1], pl->gen_lds_bwd[2], L.dcols, L.bias_src.size());
@@ -5687,6 +5895,7 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     if ((e = hipMemcpy(h.recs, L.recs.data(), sizeof(WRec) * L.recs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h.segs, L.segs.data(), sizeof(Seg) * L.segs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h.ptasks, L.ptasks.data(), sizeof(PackTask) * L.ptasks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(ws + L.off_gfitems, &L.items_f, sizeof(GfItemTable), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if (!L.bias_src.empty() &&
         (e = hipMemcpy(const_cast<const float**>(h.bias_src), L.bias_src.data(), sizeof(const float*) * L.bias_src.size(),
                        hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
@@ -5841,8 +6050,8 @@ int mmn_chain_fwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float sc_p
     mmn_batch bb = *b;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (p->generic && p->gen_fast) {
-        if (rt == 1) hipLaunchKernelGGL(k_genf_fwd<1>, dim3(tiles), dim3(NT), p->gen_lds_fwd[1], st, p->dev, bb, cL, want_grads);
-        else hipLaunchKernelGGL(k_genf_fwd<2>, dim3(tiles), dim3(NT), p->gen_lds_fwd[2], st, p->dev, bb, cL, want_grads);
+        if (rt == 1) hipLaunchKernelGGL(k_genf_fwd<1>, dim3(tiles), dim3(NT), p->gen_lds_fwd[1], st, p->ga, bb, cL, want_grads);
+        else hipLaunchKernelGGL(k_genf_fwd<2>, dim3(tiles), dim3(NT), p->gen_lds_fwd[2], st, p->ga, bb, cL, want_grads);
     } else if (p->generic) {
         if (rt == 1) hipLaunchKernelGGL(k_gen_fwd<1>, dim3(tiles), dim3(NT), p->gen_lds_fwd[1], st, p->dev, bb, cL, want_grads);
         else hipLaunchKernelGGL(k_gen_fwd<2>, dim3(tiles), dim3(NT), p->gen_lds_fwd[2], st, p->dev, bb, cL, want_grads);
@@ -5868,8 +6077,9 @@ int mmn_chain_bwd(mmn_plan* p, const mmn_batch* b, float sc_pen_x001, void* stre
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float cS = sc_coeff(p, b, sc_pen_x001);
     if (p->generic && p->gen_fast) {
-        if (rt == 1) hipLaunchKernelGGL(k_genf_bwd<1>, dim3(tiles), dim3(NT), p->gen_lds_bwd[1], st, p->dev, bb, cS);
-        else hipLaunchKernelGGL(k_genf_bwd<2>, dim3(tiles), dim3(NT), p->gen_lds_bwd[2], st, p->dev, bb, cS);
+        if (rt == 1) hipLaunchKernelGGL(k_genf_bwd<1>, dim3(tiles), dim3(NT), p->gen_lds_bwd[1], st, p->ga, bb, cS);
+        else hipLaunchKernelGGL(k_genf_bwd<2>, dim3(tiles), dim3(NT), p->gen_lds_bwd[2], st, p->ga, bb, cS);
+
     } else if (p->generic) {
         if (rt == 1) hipLaunchKernelGGL(k_gen_bwd<1>, dim3(tiles), dim3(NT), p->gen_lds_bwd[1], st, p->dev, bb, cS);
         else hipLaunchKernelGGL(k_gen_bwd<2>, dim3(tiles), dim3(NT), p->gen_lds_bwd[2], st, p->dev, bb, cS);

@@ -1792,6 +1792,14 @@ struct GfItem {
 };
 constexpr int GF_PHASES = MMN_MAX_DEC_HIDDEN + 1, GF_SLOTS = 4;
 struct GfItemTable { int32_t cnt[GF_PHASES][4]; GfItem item[GF_PHASES][4][GF_SLOTS]; };
+// backward: phase ph (1 .. deepest-1) = dh of layer ph-1 from dpre of layer ph; top[]: the decoders' K = 2 output
+// products (plain FMAs); gd[]: the decoders whose first hidden layer feeds the state gradient (one product stacked over K)
+struct GfBwdTable {
+    int32_t cnt[GF_PHASES][4]; GfItem item[GF_PHASES][4][GF_SLOTS];
+    int32_t n_top, n_gd, pad0, pad1;
+    int32_t top[GF_MAXD][8];       // d, n_hidden, hidden_activation, width of the last hidden layer (or S), its first column, dwf_off
+    int32_t gd[GF_MAXD][4];        // first column of dpre_0, k-steps, operand offset (tile 0), unused
+};
 struct GfLinear { int32_t out_dim, in_dim; };
 struct GfEncoder { int32_t n_layers, n_features, activation, pad; GfLinear layer[GF_MAXL]; };
 struct GfDecoder { int32_t n_hidden, hidden_activation; GfLinear hidden[MMN_MAX_DEC_HIDDEN]; };
@@ -1808,6 +1816,7 @@ struct GenArgs {
     int32_t dh_off[GF_MAXD][MMN_MAX_DEC_HIDDEN];
     int32_t ebias_off[GF_MAXE][GF_MAXL], dbias_off[GF_MAXD][MMN_MAX_DEC_HIDDEN + 1], dwf_off[GF_MAXD];
     const GfItemTable* items_f;        // forward decoder phases (device copy inside the workspace)
+    const GfBwdTable* items_b;         // backward decoder phases
 };
 typedef const GenArgs GPlan;
 
@@ -1835,7 +1844,7 @@ __host__ __device__ inline GenFastLds gen_fast_lds(int TB, int ldS, int ldH, int
     int o = L.c.total;
     L.sW = o; o += round_up(wfloats, 4);
     L.sBias = o; o += round_up(nbias, 4);
-    L.sItems = o; o += (int)(sizeof(GfItemTable) / 4);
+    L.sItems = o; o += (int)((bwd ? sizeof(GfBwdTable) : sizeof(GfItemTable)) / 4);
     L.ldD = pick_ld(dcols > 0 ? dcols : 16);               // all decoders' hidden layers side by side: [TB x ldD]
     L.sActD = o; o += TB * L.ldD;
     L.sOut = o; L.sActE = o;
@@ -2298,54 +2307,92 @@ __device__ __forceinline__ void issue_gen_bwd(GenBwdRegs<RT>& R, GPlan& p, const
     }
 }
 
-// G += d loss / d state through the decoders of one grid row: dz in sDz, activations in sActD [TB x dcols], operands in LDS
+// G += d loss / d state through the decoders of one grid row, layer by layer ACROSS the decoders (mirror of
+// genf_decode).  sActD [TB x ldD] holds the decoders' hidden activations on entry and their pre-activation
+// gradients on exit: every product's epilogue multiplies by act'(h) in place (each element is touched by one lane).
 template <int RT>
-__device__ __forceinline__ void genf_decoder_back(GPlan& p, clp sW, lp G, clp sDz, lp sDd, clp sActD, lp sH0, lp sH1, int grid_row,
-                                                  int row0, int nrows) {
+__device__ __forceinline__ void genf_decoder_back(GPlan& p, clp sW, clp sBias, clp sItems, lp G, clp sDz, lp sActD, int ldD,
+                                                  int grid_row, int row0, int nrows) {
     constexpr int TB = 16 * RT;
-    const int ldS = p.ldS, ldH = p.ldH, S = p.S, D = p.D, dcols = p.dcols;
-    for (int d = 0; d < D; ++d) {
-        const auto& dec = p.m.dec[d];
-        const int nh = dec.n_hidden, hk = dec.hidden_activation;
-        for (int idx = threadIdx.x; idx < TB * 2; idx += NT) {
-            const int row = idx >> 1, c = idx & 1;
-            lds_st(sDd + row * LDZ + c, lds_ld(sDz + row * LDZ + 2 * d + c));
+    const int ldS = p.ldS, S = p.S;
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int i = lane & 15, q = lane >> 4;
+    const MMN_AS3 GfBwdTable* tab = (const MMN_AS3 GfBwdTable*)sItems;
+    {   // output Linear of every decoder (K = 2): dh = dz0 W[0,:] + dz1 W[1,:], times act'(h) in place; decoders without
+        // hidden layers add straight into G (one thread owns (row, col) for all of them)
+        const int n_top = tab->n_top;
+        const int row = threadIdx.x & (TB - 1), c0 = threadIdx.x / TB, cstep = NT / TB;
+        for (int k = 0; k < n_top; ++k) {
+            const int d = tab->top[k][0], nh = tab->top[k][1], hk = tab->top[k][2], W = tab->top[k][3], colb = tab->top[k][4];
+            clp wf = sBias + tab->top[k][5];
+            const float dz0 = lds_ld(sDz + row * LDZ + 2 * d), dz1 = lds_ld(sDz + row * LDZ + 2 * d + 1);
+            for (int c = c0; c < W; c += cstep) {
+                const float v = fmaf(dz1, lds_ld(wf + W + c), dz0 * lds_ld(wf + c));
+                if (nh == 0) {
+                    lds_st(G + row * ldS + c, lds_ld(G + row * ldS + c) + v);
+                } else {
+                    const lp hp = sActD + row * ldD + colb + c;
+                    lds_st(hp, row < nrows ? v * act_grad_from_out(lds_ld(hp), hk) : 0.f);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int ph = p.dec_maxnh - 1; ph >= 1; --ph) {
+        const int n_it = __builtin_amdgcn_readfirstlane(tab->cnt[ph][wave]);
+        for (int sl = 0; sl < n_it; ++sl) {
+            const MMN_AS3 int32_t* ip = (const MMN_AS3 int32_t*)&tab->item[ph][wave][sl];
+            const int a_col = __builtin_amdgcn_readfirstlane(ip[0]), T = __builtin_amdgcn_readfirstlane(ip[1]);
+            const int w_off = __builtin_amdgcn_readfirstlane(ip[2]);
+            const int out_col = __builtin_amdgcn_readfirstlane(ip[4]), N = __builtin_amdgcn_readfirstlane(ip[5]);
+            const int col0 = __builtin_amdgcn_readfirstlane(ip[6]), hk = __builtin_amdgcn_readfirstlane(ip[7]) & 255;
+            f32x4 acc[RT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            wave_tile_l<RT>(acc, sActD + a_col, ldD, sW + w_off, T);
+            const int col = col0 + i;
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = r * 16 + q * 4 + k;
+                    const lp hp = sActD + row * ldD + out_col + col;
+                    lds_st(hp, (col < N && row < nrows) ? acc[r][k] * act_grad_from_out(lds_ld(hp), hk) : 0.f);
+                }
         }
         __syncthreads();
-        const ASrc Ad{sDd, LDZ, sDd, LDZ};
-        if (nh == 0) {
-            layer_nt_l<RT>(Ad, sW + (p.pkdb_off[d][0] - p.dec_b_off), S, 2, 0, [&](int row, int col, float v) {
-                if (col < S) lds_st(G + row * ldS + col, lds_ld(G + row * ldS + col) + v);
-            });
-            __syncthreads();
-            continue;
-        }
-        lp cbuf = sH0, nbuf = sH1;
-        {
-            const int Hl = dec.hidden[nh - 1].out_dim;
-            layer_nt_l<RT>(Ad, sW + (p.pkdb_off[d][nh] - p.dec_b_off), Hl, 2, 0, [&](int row, int col, float v) {
-                if (col < Hl) lds_st(cbuf + row * ldH + col, v);
-            });
-            __syncthreads();
-        }
-        for (int l = nh - 1; l >= 0; --l) {
-            const int Hl = dec.hidden[l].out_dim, Kin = dec.hidden[l].in_dim;
-            const int64_t off = (int64_t)grid_row * p.dh_row_stride + (int64_t)row0 * dcols + p.dh_off[d][l];
-            apply_act_grad_l(cbuf, ldH, sActD + p.dh_off[d][l], dcols, p.gdpre + off, dcols, nrows, TB, Hl, hk);
-            __syncthreads();
-            const ASrc A{cbuf, ldH, cbuf, ldH};
-            clp w = sW + (p.pkdb_off[d][l] - p.dec_b_off);
-            if (l == 0) {
-                layer_nt_l<RT>(A, w, Kin, Hl, 0, [&](int row, int col, float v) {
-                    if (col < S) lds_st(G + row * ldS + col, lds_ld(G + row * ldS + col) + v);
-                });
-            } else {
-                layer_nt_l<RT>(A, w, Kin, Hl, 0, [&](int row, int col, float v) {
-                    if (col < Kin) lds_st(nbuf + row * ldH + col, v);
-                });
-                const lp t = cbuf; cbuf = nbuf; nbuf = t;
+    }
+    {   // G += [dpre_0 of every decoder] * [W_0^T of every decoder]: one product per state column tile, stacked over K
+        const int n_gd = tab->n_gd;
+        const int ntl = (S + 15) >> 4;
+        for (int tile = wave; tile < ntl && n_gd > 0; tile += 4) {
+            f32x4 acc[RT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < n_gd; ++k) {
+                const int a_col = __builtin_amdgcn_readfirstlane(tab->gd[k][0]), T = __builtin_amdgcn_readfirstlane(tab->gd[k][1]);
+                const int w_off = __builtin_amdgcn_readfirstlane(tab->gd[k][2]);
+                wave_tile_l<RT>(acc, sActD + a_col, ldD, sW + w_off + tile * T * 256, T);
             }
-            __syncthreads();
+            const int col = 16 * tile + i;
+            if (col < S) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const lp gp = G + (r * 16 + q * 4 + k) * ldS + col;
+                        lds_st(gp, lds_ld(gp) + acc[r][k]);
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    if (p.dcols > 0) {                                     // all dpre of this grid row: one contiguous [nrows x dcols] chunk
+        float* dst = p.gdpre + (int64_t)grid_row * p.dh_row_stride + (int64_t)row0 * p.dcols;
+        const int c4n = p.dcols >> 2;
+        for (int idx = threadIdx.x; idx < nrows * c4n; idx += NT) {
+            const int row = idx / c4n, c4 = idx - row * c4n;
+            g_st4(dst + (int64_t)row * p.dcols + 4 * c4, lds_ld4(sActD + row * ldD + 4 * c4));
         }
     }
 }
@@ -2361,13 +2408,18 @@ __global__ __launch_bounds__(NT) void k_genf_bwd(const GenArgs ga, const mmn_bat
     const GenFastLds GL = gen_fast_lds(TB, ldS, ldH, P->dec_b_floats, P->n_bias, P->dcols, true);
     const ChainLds& L = GL.c;
     copy_pack_to_lds(smem + GL.sW, P->pack + P->dec_b_off, P->dec_b_floats);
+    for (int idx = threadIdx.x; idx < P->n_bias; idx += NT) lds_st(smem + GL.sBias + idx, g_ld(P->biasbuf + idx));
+    for (int idx = threadIdx.x; idx < (int)(sizeof(GfBwdTable) / 4); idx += NT)
+        lds_st(smem + GL.sItems + idx, g_ld(reinterpret_cast<const float*>(P->items_b) + idx));
     __syncthreads();
-    const int S = p.S, E = p.E, dcols = p.dcols;
+    const int S = p.S, E = p.E, dcols = p.dcols, dc4 = dcols >> 2;
     lp sG[2] = {smem + L.sS0, smem + L.sS1};
     const lp sDiff = smem + L.sDiff;
     lp sH[2] = {smem + L.sH0, smem + L.sH1};
     const lp sDz = smem + L.sZ;
-    const lp sDd = smem + L.sZ + 2 * TB * 16;              // one decoder's dz pair, [TB x LDZ]
+    const clp sBias = smem + GL.sBias;                     // (the raw output Linears of the decoders live behind the biases)
+    const clp sItems = smem + GL.sItems;
+    const int ldD = GL.ldD;
     const lp sMs = smem + L.sX;                            // state-column dropout multipliers, [TB x LDX]
     const clp sW = smem + GL.sW;
     const lp sActD = smem + GL.sActD;
@@ -2419,8 +2471,11 @@ __global__ __launch_bounds__(NT) void k_genf_bwd(const GenArgs ga, const mmn_bat
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int idx4 = (threadIdx.x + NT * k) * 4;
-            if (idx4 < TB * dcols) lds_st4(sActD + idx4, R.da[k]);
+            const int i4 = threadIdx.x + NT * k;           // 16-byte chunk of the [TB x dcols] tile
+            if (i4 < TB * dc4) {
+                const int row = i4 / dc4, c4 = i4 - row * dc4;
+                lds_st4(sActD + row * ldD + 4 * c4, R.da[k]);
+            }
         }
     };
 
@@ -2439,7 +2494,7 @@ __global__ __launch_bounds__(NT) void k_genf_bwd(const GenArgs ga, const mmn_bat
         park(true, nl);
         __syncthreads();
         // G_out = carry + decoder grads of row e+1 + cS * diff
-        genf_decoder_back<RT>(p, sW, G, sDz, sDd, sActD, sH[0], sH[1], e + 1, row0, nrows);
+        genf_decoder_back<RT>(p, sW, sBias, sItems, G, sDz, sActD, ldD, e + 1, row0, nrows);
         for (int r = wave; r < TB; r += 4)
             for (int c = lane; c < S; c += 64) lds_st(G + r * ldS + c, lds_ld(G + r * ldS + c) + cS * lds_ld(sDiff + r * ldS + c));
         __syncthreads();
@@ -2452,12 +2507,14 @@ __global__ __launch_bounds__(NT) void k_genf_bwd(const GenArgs ga, const mmn_bat
             const lp nbuf = sH[l & 1];
             const ASrc A{cbuf, ldc, cbuf, ldc};
             const PB B = make_pb(p.pack + p.pkb_off[e][l], Hp, Hl, 0);                // W_l^T [in x out]
-            auto epi = [&](int row, int col, int, float v) { if (col < Hp) lds_st(nbuf + row * ldH + col, v); };
+            const clp hl = sActE[l - 1];
+            auto epi = [&](int row, int col, int, float v) {       // dpre_{l-1} = dh .* act'(h_{l-1}), in the epilogue
+                if (col < Hp) lds_st(nbuf + row * ldH + col, row < nrows ? v * act_grad_from_out(lds_ld(hl + row * ldH + col), akind) : 0.f);
+            };
             if (l == nl - 1) layer_regs<RT, 8>(A, B, R.bL, epi);
             else layer_regs<RT, 4>(A, B, R.bM, epi);
             __syncthreads();
-            apply_act_grad_l(nbuf, ldH, sActE[l - 1], ldH, p.dpre + p.hid_off[e][l - 1] + (int64_t)row0 * Hp, Hp, nrows, TB, Hp, akind);
-            __syncthreads();
+            store_rows(p.dpre + p.hid_off[e][l - 1] + (int64_t)row0 * Hp, nbuf, ldH, nrows, Hp);
             cbuf = nbuf; ldc = ldH;
         }
         {   // carry = (dpre_0 * W_0[:, F:F+S]) .* mask_state - cS * diff ; no grad flows to x
@@ -2478,7 +2535,7 @@ __global__ __launch_bounds__(NT) void k_genf_bwd(const GenArgs ga, const mmn_bat
     issue_gen_bwd<RT>(R, p, b, 0, 0, 0, row0, nrows, false);
     park(false, 0);
     __syncthreads();
-    genf_decoder_back<RT>(p, sW, G, sDz, sDd, sActD, sH[0], sH[1], 0, row0, nrows);
+    genf_decoder_back<RT>(p, sW, sBias, sItems, G, sDz, sActD, ldD, 0, row0, nrows);
     store_rows(p.dS + ((int64_t)E * p.maxB + row0) * S, G, ldS, nrows, S);
 }
 
@@ -5165,8 +5222,9 @@ struct Layout {
     int64_t pkdf_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];
     int64_t pkdb_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];
     int64_t dec_f_off, dec_b_off, dec_f_floats, dec_b_floats;
-    size_t off_biasbuf, off_biassrc, off_gfitems;
+    size_t off_biasbuf, off_biassrc, off_gfitems, off_gfitems_b;
     GfItemTable items_f;
+    GfBwdTable items_b;
     std::vector<const float*> bias_src;
     int32_t ebias_off[MMN_MAX_ENCODERS][MMN_MAX_LAYERS];
     int32_t dbias_off[MMN_MAX_DECODERS][MMN_MAX_DEC_HIDDEN + 1];
@@ -5603,7 +5661,50 @@ void build_layout(const mmn_model& m, int maxB, Layout& L) {
             }
         }
     }
+    memset(&L.items_b, 0, sizeof(L.items_b));
+    if (L.gen_fast) {
+        GfBwdTable& tb = L.items_b;
+        for (int d = 0; d < D; ++d) {                      // every decoder's output Linear
+            const mmn_decoder& dec = m.dec[d];
+            const int nh = dec.n_hidden;
+            int32_t* t = tb.top[tb.n_top++];
+            t[0] = d; t[1] = nh; t[2] = dec.hidden_activation;
+            t[3] = nh ? dec.hidden[nh - 1].out_dim : S;
+            t[4] = nh ? (int32_t)L.dh_off[d][nh - 1] : 0;
+            t[5] = L.dwf_off[d];
+            if (nh) {
+                int32_t* gdv = tb.gd[tb.n_gd++];
+                gdv[0] = (int32_t)L.dh_off[d][0];
+                gdv[1] = (dec.hidden[0].out_dim + 15) / 16;
+                gdv[2] = (int32_t)(L.pkdb_off[d][0] - L.dec_b_off);
+            }
+        }
+        for (int ph = L.dec_maxnh - 1; ph >= 1 && L.gen_fast; --ph) {
+            int g = 0;
+            for (int d = 0; d < D && L.gen_fast; ++d) {
+                const mmn_decoder& dec = m.dec[d];
+                if (dec.n_hidden <= ph) continue;
+                const int N = dec.hidden[ph - 1].out_dim, K = dec.hidden[ph].out_dim;
+                const int T = (K + 15) / 16, ntl = (N + 15) / 16;
+                for (int tile = 0; tile < ntl; ++tile, ++g) {
+                    const int w = g & 3;
+                    int32_t& n = tb.cnt[ph][w];
+                    if (n >= GF_SLOTS) { L.gen_fast = 0; break; }
+                    GfItem& it = tb.item[ph][w][n++];
+                    it.a_col = (int32_t)L.dh_off[d][ph];
+                    it.T = T;
+                    it.w_off = (int32_t)(L.pkdb_off[d][ph] - L.dec_b_off) + tile * T * 256;
+                    it.bias_off = 0;
+                    it.out_col = (int32_t)L.dh_off[d][ph - 1];
+                    it.n_valid = N;
+                    it.col0 = 16 * tile;
+                    it.kind_hk = dec.hidden_activation & 255;
+                }
+            }
+        }
+    }
     L.off_gfitems = take(sizeof(GfItemTable));
+    L.off_gfitems_b = take(sizeof(GfBwdTable));
     L.total = o;
 }
 
@@ -5871,6 +5972,7 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
             a.lossp = h.lossp; a.scp = h.scp; a.cnt = h.cnt; a.exec_flags = h.exec_flags; a.prev_row = h.prev_row; a.stamps = h.stamps;
             a.dec_f_off = L.dec_f_off; a.dec_b_off = L.dec_b_off; a.dh_base = L.dh_base; a.dh_row_stride = L.dh_row_stride;
             a.items_f = reinterpret_cast<const GfItemTable*>(ws + L.off_gfitems);
+            a.items_b = reinterpret_cast<const GfBwdTable*>(ws + L.off_gfitems_b);
         }
         if (getenv("MMN_VERBOSE")) {
             fprintf(stderr, "[mmn] sizeof(GenArgs)=%zu sizeof(mmn_batch)=%zu sizeof(GfItemTable)=%zu\n", sizeof(GenArgs), sizeof(mmn_batch),
@@ -5896,6 +5998,7 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
     if ((e = hipMemcpy(h.segs, L.segs.data(), sizeof(Seg) * L.segs.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(h.ptasks, L.ptasks.data(), sizeof(PackTask) * L.ptasks.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(ws + L.off_gfitems, &L.items_f, sizeof(GfItemTable), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(ws + L.off_gfitems_b, &L.items_b, sizeof(GfBwdTable), hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if (!L.bias_src.empty() &&
         (e = hipMemcpy(const_cast<const float**>(h.bias_src), L.bias_src.data(), sizeof(const float*) * L.bias_src.size(),
                        hipMemcpyHostToDevice)) != hipSuccess) return fail(e);

@@ -44,15 +44,32 @@ def _worker(rank, world, port, name, out_dir):
         if len(b) > 2:
             item.append(torch.from_numpy(b[2][lo:hi]))
         loader.append(tuple(item))
+    # MIMIC family: every rank feeds ITS rows of the dropout masks the reference drew for the global batch
+    step = {"i": 0}
+
+    class CountingLoader(list):
+        def __iter__(self):
+            for item in list.__iter__(self):
+                yield item
+                step["i"] += 1
+
+    def provide(e, batch, width):
+        m = g.step_masks(step["i"]).get(e)
+        if m is None:
+            return None
+        n = m.shape[0]
+        return torch.from_numpy(m[rank * n // world:(rank + 1) * n // world])
+
+    model.dropout_mask_provider = provide
     for _ in range(g.epochs):
-        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+        model.train_epoch(CountingLoader(loader), opt, torch.nn.CrossEntropyLoss(), hist)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=np.stack(hist.loss["train"]),
              acc=np.stack(hist.accuracy["train"]), sc=np.stack(hist.state_change_loss),
              **{"p/" + k: v.numpy() for k, v in model.state_dict().items()})
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["seq_perm", "nan_skip"])
+@pytest.mark.parametrize("name", ["seq_perm", "nan_skip", "mimic_drop"])
 def test_two_rank_dp_equals_single_process(name, tmp_path):
     g = Golden(name)
     mp.spawn(_worker, args=(2, _free_port(), name, str(tmp_path)), nprocs=2, join=True)
@@ -94,8 +111,24 @@ def _gpu_worker(rank, world, port, name, policy, out_dir):
         if len(b) > 2:
             item.append(torch.from_numpy(b[2][lo:hi]))
         loader.append(tuple(item))
+    step = {"i": 0}
+
+    class CountingLoader(list):
+        def __iter__(self):
+            for item in list.__iter__(self):
+                yield item
+                step["i"] += 1
+
+    def provide(e, batch, width):                         # MIMIC family: this rank's rows of the reference's masks
+        m = g.step_masks(step["i"]).get(e)
+        if m is None:
+            return None
+        n = m.shape[0]
+        return torch.from_numpy(m[rank * n // world:(rank + 1) * n // world])
+
+    model.dropout_mask_provider = provide
     for _ in range(g.epochs):
-        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+        model.train_epoch(CountingLoader(loader), opt, torch.nn.CrossEntropyLoss(), hist)
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=np.stack(hist.loss["train"]),
              acc=np.stack(hist.accuracy["train"]), sc=np.stack(hist.state_change_loss),
@@ -104,7 +137,8 @@ def _gpu_worker(rank, world, port, name, policy, out_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,policy", [("seq_perm", "host"), ("nan_skip", "host"), ("nan_skip", "device"), ("c2_split", "device")])
+@pytest.mark.parametrize("name,policy", [("seq_perm", "host"), ("nan_skip", "host"), ("nan_skip", "device"), ("c2_split", "device"),
+                                         ("mimic_drop", "device"), ("mimic_mixed", "host")])
 def test_two_rank_dp_on_one_gpu_equals_reference_golden(name, policy, tmp_path):
     g = Golden(name)
     mp.spawn(_gpu_worker, args=(2, _free_port(), name, policy, str(tmp_path)), nprocs=2, join=True)

@@ -42,10 +42,14 @@ def run_step(model, batch, masks=None, batch_global=None, nan_policy="host"):
     return stats, grads, executed
 
 
+@pytest.mark.parametrize("form", ["fast", "sequential"])
 @pytest.mark.parametrize("rt", ["1", "2"])
 @pytest.mark.parametrize("name", MIMIC_GOLDEN_NAMES)
-def test_first_step_matches_reference_golden(lib, name, rt, monkeypatch):
+def test_first_step_matches_reference_golden(lib, name, rt, form, monkeypatch):
+    """Both forms of the generic tier (k_genf_* where the model is eligible, k_gen_* otherwise or when forced) and
+    both tile heights."""
     monkeypatch.setenv("MMN_RT", rt)
+    monkeypatch.setenv("MMN_GEN_FAST", "1" if form == "fast" else "0")
     g = Golden(name)
     model = build_torch_model(g.spec, g.init_params(), "cuda", lib)
     stats, grads, _ = run_step(model, g.batch(0), g.step_masks(0))
@@ -152,6 +156,24 @@ def test_full_size_against_fp64_oracle(lib, B):
     stats, grads, _ = run_step(model, batch, masks)
     ref = O.forward_backward(params, spec, batch[0], batch[1], drop_masks=masks, dtype=np.float64)
     check_against(stats, grads, ref, tol_grad=5e-5)
+
+
+def test_kernel_names_and_forms(lib, monkeypatch):
+    """Which kernels run: the fast form for an all-MIMIC model within its limits, the sequential form otherwise."""
+    import ctypes as C
+    fast = build_torch_model(mimic_c3_spec(), O.init_params(mimic_c3_spec(), 0), "cuda", lib)
+    eng = fast._get_engine(64)
+    b = eng.make_batch([torch.zeros(64, 64, device="cuda") for _ in range(4)], torch.zeros(64, 3, dtype=torch.int64, device="cuda"),
+                       [(k, k) for k in range(4)])
+    assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 0) == b"k_genf_fwd"
+    assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 1) == b"k_genf_bwd"
+    assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 2) == b""
+    g = Golden("mimic_mixed")                               # one MLPEncoder among the MIMIC ones: sequential form
+    mixed = build_torch_model(g.spec, g.init_params(), "cuda", lib)
+    eng2 = mixed._get_engine(16)
+    xs, y, _ = [torch.from_numpy(x).cuda() for x in g.batch(0)[0]], torch.from_numpy(g.batch(0)[1]).cuda(), None
+    b2 = eng2.make_batch(xs, y, [(k, k) for k in range(3)])
+    assert eng2.lib.mmn_chain_kernel_name(eng2._plan, C.byref(b2), 0) == b"k_gen_fwd"
 
 
 def test_shard_sum_equals_full_batch(lib):

@@ -467,15 +467,17 @@ def main():
     achieved = fl[dominant] * B / (avg_us[dominant] * 1e-6) / 1e12
     traffic = None
     try:                                                      # HBM bytes per launch from the committed PMC passes
-        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_final_pmc_traffic.json")))
-        if args.workload == "c3" and B == WORKLOADS["c3"]["B"]:      # the passes were made on this workload
+        pmc_file = {"c3": "r01_final_pmc_traffic.json", "mimic": "r01_mimic_pmc_traffic.json"}.get(args.workload)
+        if pmc_file and B == wl["B"]:                        # the passes were made on this workload at this batch
+            pmc = json.load(open(os.path.join(REPO, "profiles", pmc_file)))
             traffic = pmc["kernels"].get(dominant, {}).get("hbm_bytes_per_launch")
     except Exception:
         traffic = None
     roofline = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "traffic_note": "HBM bytes per launch of the dominant kernel = (2*FETCH_SIZE + WRITE_SIZE)*1024 from "
-                                "profiles/r01_final_pmc_traffic.json (separate rocprofv3 --pmc passes)",
+                                "profiles/r01_final_pmc_traffic.json (mimic workload: r01_mimic_pmc_traffic.json), "
+                                "separate rocprofv3 --pmc passes",
                 "avg_launch_us": avg_us, "flops_per_sample": fl,
                 "algorithmic_flops_per_launch": fl[dominant] * B,
                 "step_frac_of_fp32_roof": value / world * sum(fl.values()) / (FP32_MFMA_PEAK_TFLOPS * 1e12),

@@ -1300,8 +1300,22 @@ __device__ __forceinline__ void dec_layer(LPlan& p, clp sW, int64_t pk_off, int6
     }
 }
 
+// (eight independent 16-byte requests per thread in flight, then their stores: a plain load -> store loop waits
+//  for every load in turn, ~16 dependent round trips for the decoders' 66 KB at the MIMIC shape)
 __device__ __forceinline__ void copy_pack_to_lds(lp dst, const float* __restrict__ src, int nfloats) {
-    for (int idx = threadIdx.x * 4; idx < nfloats; idx += NT * 4) lds_st4(dst + idx, g_ld4(src + idx));
+    for (int base = threadIdx.x * 4; base < nfloats; base += NT * 4 * 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = base + k * NT * 4;
+            v[k] = g_ld4(src + (idx < nfloats ? idx : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = base + k * NT * 4;
+            if (idx < nfloats) lds_st4(dst + idx, v[k]);
+        }
+    }
 }
 
 // LDS tile [nrows x ncols] -> global rows of stride ld_dst
@@ -1892,15 +1906,22 @@ template <int RT> struct GenEncRegs {
     f32x4 b0[TQ][2], b1[4][2], b2[4][2];       // this wave's weight fragments of the (up to) three layers
 };
 
-// unconditional 4-float read from a clamped address, zeroed by select (no branch around the loads)
+// Unconditional 4-float read from a clamped (always valid) address.  RAW values: nothing at the request site may
+// depend on the loaded data (a select on it makes hipcc wait for the load right there, and the prefetch is gone -
+// measured: every "prefetched" tile was waited for at its request); out-of-range lanes are zeroed by sel4 at the
+// point of USE.
 __device__ __forceinline__ f32x4 ld4_masked(const float* __restrict__ base, int64_t off, int c, int limit, bool row_ok) {
     f32x4 v;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const bool ok = row_ok && (c + j) < limit;
-        const float t = g_ld(base + (ok ? off + j : 0));
-        v[j] = ok ? t : 0.f;
+        v[j] = g_ld(base + (ok ? off + j : 0));
     }
+    return v;
+}
+__device__ __forceinline__ f32x4 sel4(f32x4 v, int c, int limit, bool row_ok) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (row_ok && (c + j) < limit) ? v[j] : 0.f;
     return v;
 }
 
@@ -2077,6 +2098,8 @@ __global__ __launch_bounds__(NT) void k_genf_fwd(const GenArgs ga, const mmn_bat
     const int lane = threadIdx.x & 63, wave = wave_id();
     int stamp_k = 0;
     const int stamp_block = 7;
+    // the NaN flags ONCE, as a wave-uniform mask: a per-use global load is a dependent round trip at every encoder step
+    const unsigned pm = present_mask(b);
     // operands that do not depend on the plan copy: request them first
     copy_pack_to_lds(smem + GL.sW, P->pack + P->dec_f_off, P->dec_f_floats);
     for (int idx = threadIdx.x; idx < P->n_bias; idx += NT) lds_st(sBias + idx, g_ld(P->biasbuf + idx));
@@ -2101,7 +2124,7 @@ __global__ __launch_bounds__(NT) void k_genf_fwd(const GenArgs ga, const mmn_bat
         for (int e = 0; e < E; ++e) g_sti(p.exec_flags + e + 1, 0);
         int prev = 0;
         for (int t = 0; t < b.n_seq; ++t) {
-            if (!slot_present(b, b.seq_data[t])) continue;
+            if (!slot_present(pm, b.seq_data[t])) continue;
             const int e = b.seq_enc[t];
             g_sti(p.exec_flags + e + 1, 1);
             g_sti(p.prev_row + e, prev);
@@ -2117,7 +2140,7 @@ __global__ __launch_bounds__(NT) void k_genf_fwd(const GenArgs ga, const mmn_bat
         dc.y = ok ? (int)*(const MMN_AS1 int64_t*)(b.y + ((int64_t)row0 + row) * p.D + d) : 0;
     }
     GenEncRegs<RT> R;
-    int tn = next_exec(b, 0);
+    int tn = next_exec(b, pm, 0);
     if (tn < b.n_seq) issue_gen_encoder<RT>(R, p, b, b.seq_enc[tn], b.seq_data[tn], row0, nrows);
     __syncthreads();
 
@@ -2131,7 +2154,7 @@ __global__ __launch_bounds__(NT) void k_genf_fwd(const GenArgs ga, const mmn_bat
         const auto& enc = p.m.enc[e];
         const int nl = enc.n_layers, F = enc.n_features, FS = F + S, akind = enc.activation;
         const bool masked = b.drop_mask[e] != nullptr;
-        const int t_next = next_exec(b, tn + 1);
+        const int t_next = next_exec(b, pm, tn + 1);
         float scacc = 0.f;
         const clp sC = sS[cur];
         const lp sN = sS[cur ^ 1];
@@ -2142,14 +2165,18 @@ __global__ __launch_bounds__(NT) void k_genf_fwd(const GenArgs ga, const mmn_bat
             for (int k = 0; k < 2 * RT; ++k) {
                 const int idx = threadIdx.x + NT * k;
                 const int row = idx >> 5, c = (idx & 31) << 2;
-                f32x4 xv = R.x[k], sv = {0.f, 0.f, 0.f, 0.f};
+                const bool rok = row < nrows;
+                f32x4 xv = sel4(R.x[k], c, F, rok), sv = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
+                const f32x4 mxv = masked ? sel4(R.mx[k], c, F, rok) : one4;
+                const f32x4 msv = masked ? sel4(R.ms[k], c, S, rok) : one4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xv[j] *= R.mx[k][j];
+                for (int j = 0; j < 4; ++j) xv[j] *= mxv[j];
                 lds_st4(sX + row * LDX + c, xv);
                 if (c < S) {
                     const f32x4 s4 = lds_ld4(sC + row * ldS + c);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) sv[j] = (c + j < S) ? s4[j] * R.ms[k][j] : 0.f;
+                    for (int j = 0; j < 4; ++j) sv[j] = (c + j < S) ? s4[j] * msv[j] : 0.f;
                     if (masked) lds_st4(sM + row * ldS + c, sv);
                 }
                 if (want_grads && row < nrows) {
@@ -2245,11 +2272,29 @@ template <int RT> struct GenBwdRegs {
     f32x4 bL[8][2], bM[4][2], b0[4][2];        // W^T fragments: the layer contracting over S; a middle layer; the carry
 };
 
+// W^T fragments of one encoder's backward products (consumed late in a step: requested right after the previous
+// step's last use of the registers)
+template <int RT>
+__device__ __forceinline__ void issue_gen_bwd_weights(GenBwdRegs<RT>& R, GPlan& p, int e) {
+    const int wave = wave_id();
+    const auto& enc = p.m.enc[e];
+    const int S = p.S, nl = enc.n_layers;
+    const int n0[2] = {16 * wave, 16 * (wave + 4)};
+    const int H0 = enc.layer[0].out_dim;
+    if (nl == 1) {
+        issue_b<8>(R.bL, make_pb(p.pack + p.pkb_off[e][0], S, H0, 0), n0, 0);              // carry contracts over S
+    } else {
+        issue_b<8>(R.bL, make_pb(p.pack + p.pkb_off[e][nl - 1], enc.layer[nl - 1].in_dim, S, 0), n0, 0);
+        if (nl == 3) issue_b<4>(R.bM, make_pb(p.pack + p.pkb_off[e][1], enc.layer[1].in_dim, enc.layer[1].out_dim, 0), n0, 0);
+        issue_b<4>(R.b0, make_pb(p.pack + p.pkb_off[e][0], S, H0, 0), n0, 0);
+    }
+}
+
+// activation tiles of one step (consumed first: requested a whole step ahead, right after the previous step parked its own)
 template <int RT>
 __device__ __forceinline__ void issue_gen_bwd(GenBwdRegs<RT>& R, GPlan& p, const mmn_batch& b, int e, int prev_row, int grid_row,
                                               int row0, int nrows, bool with_encoder) {
     constexpr int TB = 16 * RT;
-    const int wave = wave_id();
     const int S = p.S, D2 = 2 * p.D;
     if (with_encoder) {
         const auto& enc = p.m.enc[e];
@@ -2277,15 +2322,6 @@ __device__ __forceinline__ void issue_gen_bwd(GenBwdRegs<RT>& R, GPlan& p, const
             R.h1[k] = nl >= 3 ? ld4_masked(p.hid + p.hid_off[e][1] + (int64_t)row0 * H1, (int64_t)row * H1 + c, c, H1, rok)
                               : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const int n0[2] = {16 * wave, 16 * (wave + 4)};
-        const int H0 = enc.layer[0].out_dim;
-        if (nl == 1) {
-            issue_b<8>(R.bL, make_pb(p.pack + p.pkb_off[e][0], S, H0, 0), n0, 0);              // carry contracts over S
-        } else {
-            issue_b<8>(R.bL, make_pb(p.pack + p.pkb_off[e][nl - 1], enc.layer[nl - 1].in_dim, S, 0), n0, 0);
-            if (nl == 3) issue_b<4>(R.bM, make_pb(p.pack + p.pkb_off[e][1], enc.layer[1].in_dim, enc.layer[1].out_dim, 0), n0, 0);
-            issue_b<4>(R.b0, make_pb(p.pack + p.pkb_off[e][0], S, H0, 0), n0, 0);
-        }
     }
     // dz tile and the decoders' hidden activations of this grid row (one contiguous chunk per tile)
 #pragma unroll
@@ -2293,17 +2329,14 @@ __device__ __forceinline__ void issue_gen_bwd(GenBwdRegs<RT>& R, GPlan& p, const
         const int idx = threadIdx.x + NT * k;
         const int row = idx >> 4, n = idx & 15;
         const bool ok = row < nrows && n < D2;
-        const float v = g_ld(p.dz + ((int64_t)grid_row * p.maxB + row0) * D2 + (ok ? row * D2 + n : 0));
-        R.dz[k] = ok ? v : 0.f;
+        R.dz[k] = g_ld(p.dz + ((int64_t)grid_row * p.maxB + row0) * D2 + (ok ? row * D2 + n : 0));    // raw: zeroed when parked
     }
     const float* da = p.gact + p.dh_base + (int64_t)grid_row * p.dh_row_stride + (int64_t)row0 * p.dcols;
     const int nda = nrows * p.dcols;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int idx4 = (threadIdx.x + NT * k) * 4;
-        const bool ok = idx4 < nda;
-        const f32x4 v = g_ld4(da + (ok ? idx4 : 0));
-        R.da[k] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        R.da[k] = g_ld4(da + (idx4 < nda ? idx4 : 0));      // raw: zeroed when parked
     }
 }
 
@@ -2437,21 +2470,27 @@ __global__ __launch_bounds__(NT) void k_genf_bwd(const GenArgs ga, const mmn_bat
     __syncthreads();
     int cur = 0;
     GenBwdRegs<RT> R;
+    const unsigned pm = present_mask(b);                   // the NaN flags once (see k_genf_fwd)
+    int stamp_k = 0;
+    const int stamp_block = 7;
+    STAMP();   // 0: operands, biases, item table in LDS; tiles zeroed
 
     // registers -> LDS: the grid row's dz tile and decoder activations (every step), the encoder's tiles (encoder steps)
-    auto park = [&](bool with_encoder, int nl) {
+    auto park = [&](bool with_encoder, int nl, int h0w, int h1w) {
         if (with_encoder) {
 #pragma unroll
             for (int k = 0; k < 2 * RT; ++k) {
                 const int idx = threadIdx.x + NT * k;
                 const int row = idx >> 5, c = (idx & 31) << 2;
                 if (c < S) {                                   // (the state tiles are only round_up(S, 16) + 4 floats wide)
-                    lds_st4(sOut + row * ldS + c, R.so[k]);
+                    const bool rok = row < nrows;
+                    const f32x4 sov = sel4(R.so[k], c, S, rok), siv = sel4(R.si[k], c, S, rok);
+                    lds_st4(sOut + row * ldS + c, sov);
                     f32x4 df;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) df[j] = R.so[k][j] - R.si[k][j];
+                    for (int j = 0; j < 4; ++j) df[j] = sov[j] - siv[j];
                     lds_st4(sDiff + row * ldS + c, df);
-                    lds_st4(sMs + row * LDX + c, R.ms[k]);
+                    lds_st4(sMs + row * LDX + c, sel4(R.ms[k], c, S, rok));
                 }
             }
 #pragma unroll
@@ -2459,42 +2498,60 @@ __global__ __launch_bounds__(NT) void k_genf_bwd(const GenArgs ga, const mmn_bat
                 const int idx = threadIdx.x + NT * k;
                 const int row = idx >> 4, c = (idx & 15) << 2;
                 if (c + 4 <= ldH) {                            // (hidden tiles: ldH >= round_up(width, 16) + 4)
-                    if (nl >= 2) lds_st4(sActE[0] + row * ldH + c, R.h0[k]);
-                    if (nl >= 3) lds_st4(sActE[1] + row * ldH + c, R.h1[k]);
+                    if (nl >= 2) lds_st4(sActE[0] + row * ldH + c, sel4(R.h0[k], c, h0w, row < nrows));
+                    if (nl >= 3) lds_st4(sActE[1] + row * ldH + c, sel4(R.h1[k], c, h1w, row < nrows));
                 }
             }
         }
 #pragma unroll
         for (int k = 0; k < RT; ++k) {
             const int idx = threadIdx.x + NT * k;
-            lds_st(sDz + (idx >> 4) * LDZ + (idx & 15), R.dz[k]);
+            lds_st(sDz + (idx >> 4) * LDZ + (idx & 15), ((idx >> 4) < nrows && (idx & 15) < 2 * p.D) ? R.dz[k] : 0.f);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int i4 = threadIdx.x + NT * k;           // 16-byte chunk of the [TB x dcols] tile
             if (i4 < TB * dc4) {
                 const int row = i4 / dc4, c4 = i4 - row * dc4;
-                lds_st4(sActD + row * ldD + 4 * c4, R.da[k]);
+                lds_st4(sActD + row * ldD + 4 * c4, row < nrows ? R.da[k] : f32x4{0.f, 0.f, 0.f, 0.f});
             }
         }
     };
 
-    for (int t = b.n_seq - 1; t >= 0; --t) {
-        const int slot = b.seq_data[t];
-        if (!slot_present(b, slot)) continue;
+    // previous executed position before t (or -1)
+    auto prev_exec = [&](int t) { int u = t - 1; while (u >= 0 && !slot_present(pm, b.seq_data[u])) --u; return u; };
+    int t = prev_exec(b.n_seq);
+    if (t >= 0) {                                          // the first step's requests (every later step's travel a step ahead)
+        const int tp0 = prev_exec(t);
+        issue_gen_bwd<RT>(R, p, b, b.seq_enc[t], tp0 >= 0 ? b.seq_enc[tp0] + 1 : 0, b.seq_enc[t] + 1, row0, nrows, true);
+    } else {
+        issue_gen_bwd<RT>(R, p, b, 0, 0, 0, row0, nrows, false);
+    }
+    for (; t >= 0;) {
         const int e = b.seq_enc[t];
-        int tp = t - 1;
-        while (tp >= 0 && !slot_present(b, b.seq_data[tp])) --tp;
+        const int tp = prev_exec(t);
         const int prev_row = tp >= 0 ? b.seq_enc[tp] + 1 : 0;
         const auto& enc = p.m.enc[e];
         const int nl = enc.n_layers, akind = enc.activation;
         const lp G = sG[cur];
         const lp Gn = sG[cur ^ 1];
-        issue_gen_bwd<RT>(R, p, b, e, prev_row, e + 1, row0, nrows, true);    // ONE batch of global reads for the whole step
-        park(true, nl);
+        park(true, nl, enc.layer[0].out_dim, nl >= 3 ? enc.layer[1].out_dim : 0);
         __syncthreads();
+        // The NEXT step's activation tiles and THIS step's W^T fragments travel underneath the decoder pass below
+        // (vmcnt retires in order and hipcc waits with vmcnt(0): whatever is requested last must be consumed last,
+        // so the fragments are requested here and not a step ahead - measured: requested at the end of the previous
+        // step they made the park above wait a full round trip)
+        issue_gen_bwd_weights<RT>(R, p, e);
+        if (tp >= 0) {
+            const int tpp = prev_exec(tp);
+            issue_gen_bwd<RT>(R, p, b, b.seq_enc[tp], tpp >= 0 ? b.seq_enc[tpp] + 1 : 0, b.seq_enc[tp] + 1, row0, nrows, true);
+        } else {
+            issue_gen_bwd<RT>(R, p, b, 0, 0, 0, row0, nrows, false);
+        }
+        STAMP();   // e.0: the step's global reads have arrived and are parked in LDS
         // G_out = carry + decoder grads of row e+1 + cS * diff
         genf_decoder_back<RT>(p, sW, sBias, sItems, G, sDz, sActD, ldD, e + 1, row0, nrows);
+        STAMP();   // e.1: decoders
         for (int r = wave; r < TB; r += 4)
             for (int c = lane; c < S; c += 64) lds_st(G + r * ldS + c, lds_ld(G + r * ldS + c) + cS * lds_ld(sDiff + r * ldS + c));
         __syncthreads();
@@ -2528,12 +2585,13 @@ __global__ __launch_bounds__(NT) void k_genf_bwd(const GenArgs ga, const mmn_bat
             else layer_regs<RT, 4>(A, B, R.b0, epi);
         }
         __syncthreads();
+        STAMP();   // e.2: encoder
         cur ^= 1;
+        t = tp;
     }
     // row 0: decoders on the init state; dS0 = d loss / d tiled init state
     const lp G = sG[cur];
-    issue_gen_bwd<RT>(R, p, b, 0, 0, 0, row0, nrows, false);
-    park(false, 0);
+    park(false, 0, 0, 0);
     __syncthreads();
     genf_decoder_back<RT>(p, sW, sBias, sItems, G, sDz, sActD, ldD, 0, row0, nrows);
     store_rows(p.dS + ((int64_t)E * p.maxB + row0) * S, G, ldS, nrows, S);

@@ -13,6 +13,10 @@
 //     k_fwd8 + k_bwd8  the same math as two 8-wave kernels (E <= 8; also the forward-only path)
 //     k_chain_*_par    4-wave parallel-phase kernels (dims that fit LDS)
 //     k_chain_fwd/bwd  sequential form, any shape, 16- or 32-row tiles
+//     k_genf_fwd/bwd   generic tier, fast form: MIMIC_MLPEncoder (state enters the FIRST layer, activation on
+//                      every layer, dropout multipliers from mmn_batch.drop_mask) + MLPDecoder heads; decoder
+//                      operands / biases / item tables in LDS, descriptor as kernel argument
+//     k_gen_fwd/bwd    generic tier, sequential form: any mix of encoder / decoder kinds and shapes
 //   k_wgrad            grouped split-K "A^T B" GEMM: weight, bias and init-state grads as
 //                      flat-gradient-shaped partial slabs
 //   k_reduce           fixed-order slab reduction -> grads (+ Adam on the element just summed, :204);
@@ -21,15 +25,17 @@
 //                      (data parallel: after the all-reduce, together with the epoch accumulation)
 //   k_ps_code / k_ps_layout / k_ps_gather   per-sample mode: regrouping of the rows into tiles of one
 //                      executed sequence (mmn_regroup)
-// File order: plan structs and device helpers; k_prepare; sequential chain kernels; 4-wave parallel
-// kernels; 8-wave kernels (k_fwd8, k_bwd8, k_fb8); k_wgrad; k_ps_*; k_adam; k_reduce; host side
-// (layout, plan, C ABI).
+// File order: plan structs and device helpers; k_prepare; sequential chain kernels; generic tier
+// (sequential form, fast form); 4-wave parallel kernels; 8-wave kernels (k_fwd8, k_bwd8, k_fb8); k_wgrad;
+// k_ps_*; k_adam; k_reduce; host side (layout, plan, C ABI).
 //
 // Data layout in HBM (all fp32 row-major, B = batch rows):
 //   states[e][B][S]     output state of encoder e          hid[e][l][B][H_l]  hidden activations
 //   dz[r][B][2D]        d loss / d decoder logits, row r   dS[e][B][S]        d loss / d state_e (+dS0)
 //   dpre[e][l][B][H_l]  d loss / d hidden pre-activation   slabs              split-K partial grads
 //   sin[e][B][S]        per-sample mode: state that fed encoder e
+//   gact / gdpre        generic tier: xin[e][B][F+S] = the (masked) cat[x, state] of a MIMIC encoder; per grid row
+//                       the decoders' hidden activations / pre-activation gradients side by side, [B][dcols]
 //   pack                weights in fragment order: [col tile][k-step][lane][4] (zero padded)
 //
 // Tiling.  A workgroup owns 16 batch rows (32 in the sequential tier's RT = 2 form); the state tiles

@@ -242,3 +242,73 @@ def test_unsupported_combinations_are_refused(lib):
     with pytest.raises((lib.hip.MmnError, lib.UnsupportedModelError)):
         eng = model._get_engine(32)
         model._run_step_per_sample(eng, xs, torch.zeros(32, 1, dtype=torch.int64), None)
+
+
+import collections
+SWEEP_FORMS = collections.Counter()
+
+
+@pytest.mark.parametrize("seed", list(range(48)))
+def test_random_models_against_oracle(lib, seed):
+    """Seeded sweep over generic-tier models: encoder kinds (all MIMIC in two thirds of the cases, so that the fast
+    form runs with 1, 2 and 3 layers, narrow and 64-wide hidden layers, up to 8 encoders / 8 decoders), decoder kinds
+    and depths, dropout on some encoders, a NaN-skipped modality, a permuted encoder sequence, ragged batches."""
+    rng = np.random.default_rng(5000 + seed)
+    all_mimic = seed % 3 != 0
+    E = int(rng.integers(1, 9))
+    S = int(rng.choice([4, 8, 16, 24, 48, 64, 100, 128]))
+    D = int(rng.integers(1, 9 if all_mimic else 5))
+    B = int(rng.choice([1, 7, 16, 33, 100, 257]))
+    hid_choices = [(), (8,), (16, 16), (32,), (5, 5), (32, 32), (7,), (24, 8), (64, 64), (64,)]
+    encs = []
+    for _ in range(E):
+        H = hid_choices[int(rng.integers(0, len(hid_choices)))]
+        kind = "mimic" if (all_mimic or rng.random() < 0.6) else "mlp"
+        act = int(rng.choice([O.ACT_RELU, O.ACT_SIGMOID])) if (H or kind == "mimic") else O.ACT_IDENTITY
+        F = int(rng.choice([1, 3, 4, 6, 16, 33, 64, 100]))
+        if kind == "mimic" and (F + 15) // 16 + (S + 15) // 16 > 12:
+            F = 16                                            # keep some all-MIMIC models inside the fast form's layer-0 limit
+        drop = float(rng.choice([0.0, 0.2, 0.5])) if kind == "mimic" else 0.0
+        encs.append(O.EncoderSpec(F, H, act, kind=kind, dropout=drop))
+    dec_h = [(), (8,), (16, 16), (32, 32), (5,), (12, 7, 9)]
+    decs = []
+    for _ in range(D):
+        if rng.random() < 0.25:
+            decs.append(O.DecoderSpec("class"))
+        else:
+            decs.append(O.DecoderSpec("mlp", dec_h[int(rng.integers(0, len(dec_h)))], int(rng.choice([O.ACT_RELU, O.ACT_SIGMOID]))))
+    spec = O.ModelSpec(S, encs, D, float(rng.choice([0.7, 1.0])), float(rng.choice([0.0, 0.3, 1.0])), decoders=decs)
+    params = O.init_params(spec, seed)
+    xs, y = O.synthetic_batches(spec, B, B, seed=seed + 5)[0]
+    order = rng.permutation(E)
+    xs_o = [xs[e].copy() for e in order]
+    if E > 1 and rng.random() < 0.3:
+        xs_o[int(rng.integers(0, E))][int(rng.integers(0, B)), 0] = np.nan      # that modality is skipped for the batch
+    batch = (xs_o, y, np.tile(order.astype(np.int64), (B, 1)))
+    masks = {e: ((rng.random((B, enc.n_features + S)) >= enc.dropout) / (1 - enc.dropout)).astype(np.float32)
+             for e, enc in enumerate(encs) if enc.dropout > 0}
+    model = build_torch_model(spec, params, "cuda", lib)
+    stats, grads, _ = run_step(model, batch, masks)
+    import ctypes as C
+    eng = model._get_engine(B)
+    probe = eng.make_batch([torch.zeros(B, e.n_features, device="cuda") for e in encs],
+                           torch.zeros(B, D, dtype=torch.int64, device="cuda"), [(k, k) for k in range(E)])
+    SWEEP_FORMS[eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(probe), 0).decode()] += 1
+    ref = O.forward_backward(params, spec, batch[0], batch[1], batch[2], drop_masks=masks)
+    assert rel_err(stats["loss"], ref.loss) < 1e-5
+    assert rel_err(stats["err_loss"], ref.err_loss) < 1e-5
+    for k in ("n_correct", "tp", "tn", "fp", "fn"):
+        assert np.array_equal(stats[k].astype(np.int64), getattr(ref, k)), k
+    for n, g in ref.grads.items():
+        if g is None:
+            assert grads[n] is None, n
+            continue
+        got = grads[n].reshape(g.shape)
+        assert np.abs(got - g).max() <= 3e-5 * np.abs(g).max() + 2e-8, (n, np.abs(got - g).max(), np.abs(g).max())
+
+
+def test_sweep_ran_both_forms():
+    """The sweep above must have exercised both forms of the generic tier (it runs before this test)."""
+    if sum(SWEEP_FORMS.values()) < 48:
+        pytest.skip("sweep not run in this session")
+    assert SWEEP_FORMS["k_genf_fwd"] >= 8 and SWEEP_FORMS["k_gen_fwd"] >= 8, dict(SWEEP_FORMS)

@@ -509,14 +509,27 @@ __global__ __launch_bounds__(NT) void k_prepare(const DevPlan* __restrict__ P, m
         const int64_t total = (int64_t)b.batch * f4;
         const bool vec = ((ld & 3) == 0) && ((F & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
         bool bad = false;
-        for (int64_t idx = (int64_t)part * NT + threadIdx.x; idx < total; idx += (int64_t)blocks_per_slot * NT) {
-            const int64_t r = idx / f4;
-            const int c = (int)(idx - r * f4) << 2;
-            const float* q = x + r * ld + c;
-            if (vec) {
-                const f32x4 v = g_ld4(q);
-                bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
-            } else {
+        const int64_t stride = (int64_t)blocks_per_slot * NT;
+        if (vec) {
+            // four independent 16-byte reads per thread in flight (a load -> test loop waits for every read in turn:
+            // at the MIMIC shape that was four dependent HBM round trips per thread)
+            for (int64_t idx = (int64_t)part * NT + threadIdx.x; idx < total; idx += 4 * stride) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t id = idx + u * stride;
+                    const int64_t ic = id < total ? id : idx;                 // clamp: re-reads a valid element
+                    const int64_t r = ic / f4;
+                    v[u] = g_ld4(x + r * ld + ((int)(ic - r * f4) << 2));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bad |= (v[u].x != v[u].x) | (v[u].y != v[u].y) | (v[u].z != v[u].z) | (v[u].w != v[u].w);
+            }
+        } else {
+            for (int64_t idx = (int64_t)part * NT + threadIdx.x; idx < total; idx += stride) {
+                const int64_t r = idx / f4;
+                const int c = (int)(idx - r * f4) << 2;
+                const float* q = x + r * ld + c;
                 for (int k = 0; k < 4 && c + k < F; ++k) { const float v = g_ld(q + k); bad |= (v != v); }
             }
         }
@@ -3958,8 +3971,8 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = g_ld(px + ((ok && c + j < F) ? j : 0));
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xr[k][j] = (ok && c + j < F) ? v[j] : 0.f;
+            xr[k] = v;                                     // RAW: a select here would make hipcc wait for the x tile before
+                                                           // the requests below are even issued; zeroed at the LDS store
         }
         issue_t<8>(h0q, a.pack + pe.pkf[l0], (pe.in[l0] + 15) >> 4, (pe.out[l0] + 15) >> 4, half, 0);
         hb0 = g_ld(pe.bias[l0] + min(16 * half + i, pe.out[l0] - 1));
@@ -4015,7 +4028,12 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int idx = lane + 64 * k;
-            if (idx < 8 * f4) lds_st4(sXg + (8 * half + idx / f4) * ldX + ((idx % f4) << 2), xr[k]);
+            const int row = 8 * half + idx / f4, c = (idx % f4) << 2;
+            const bool ok = idx < 8 * f4 && row < nrows && c < F;
+            f32x4 v = xr[k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (ok && c + j < F) ? v[j] : 0.f;
+            if (idx < 8 * f4) lds_st4(sXg + row * ldX + c, v);
         }
     }
     for (int r = wave; r < TB; r += 8)
@@ -4107,9 +4125,7 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
         for (int j = 0; j < 8; ++j) {                      // clamped address + select: no branch around a load
             const int k = 16 * j + 4 * q;
             const bool ok = rowok && k < S && j < T0;
-            const f32x4 v = g_ld4(w + (ok ? k : 0));
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            wd[j] = ok ? v : z;
+            wd[j] = g_ld4(w + (ok ? k : 0));               // RAW (see xr); zeroed where they are first used
         }
     }
     __syncthreads();
@@ -4174,6 +4190,15 @@ __global__ __launch_bounds__(NT8) void k_fb8(const ParArgs a, const mmn_batch b,
         if (X.row(wave)) {
             const clp sS = St + wave * TB * ldS;
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            {                                              // the decoder fragments were requested raw at kernel start
+                const bool rowok = i < 2 * D;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool ok = rowok && (16 * j + 4 * q) < S && j < T0;
+                    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                    wd[j] = ok ? wd[j] : zero4;
+                }
+            }
             consume_t<8>(z, sS, ldS, 0, wd, 0, T0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) lds_st(sZ + (wave * TB + q * 4 + k) * 16 + i, z[k]);

@@ -8,7 +8,7 @@ from collections import defaultdict
 out, tag = sys.argv[1], sys.argv[2]
 res = defaultdict(dict)
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    files = glob.glob(os.path.join(out, f"pmc_{counter}", "**", "*counter_collection.csv"), recursive=True)
+    files = glob.glob(os.path.join(out, f"pmc_{counter}", "**", f"{tag}_counter_collection.csv"), recursive=True)   # this tag's pass only
     acc, cnt = defaultdict(float), defaultdict(int)
     for f in files:
         for row in csv.DictReader(open(f)):

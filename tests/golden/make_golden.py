@@ -260,6 +260,39 @@ def spec_of(cfg):
     return O.ModelSpec(cfg["S"], encs, cfg["D"], cfg["pen"][0], cfg["pen"][1], decoders=decs)
 
 
+def checkpoint_round_trip(ref, cfg, spec):
+    """SURVEY 8f #4.  (a) The checkpoint the MIMIC pipelines write (mimic_multi_task_pipeline.py:150-154:
+    torch.save({'epoch', 'model_state_dict', 'auc_bac_val_cum'})) from the reference's TRAINED model becomes a
+    fixture (tests/golden/ref_checkpoint_mimic_drop.pt: tensors only, no code); tests load it into the build.
+    (b) The other direction, checked here because only this container has the reference: a multimodn_amd model
+    (CPU, no engine needed for state_dict) saves the same kind of checkpoint, the reference's model loads it with
+    load_state_dict(strict=True) and its eval-mode forward reproduces the oracle on those weights."""
+    import io
+    import multimodn_amd as mm
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from helpers import build_torch_model
+    model = ref["model"]
+    torch.save({"epoch": cfg["epochs"], "model_state_dict": model.state_dict(), "auc_bac_val_cum": 1.25},
+               os.path.join(HERE, "ref_checkpoint_mimic_drop.pt"))
+    params = O.init_params(spec, 123)
+    ours = build_torch_model(spec, params, "cpu", mm)
+    buf = io.BytesIO()
+    torch.save({"epoch": 1, "model_state_dict": ours.state_dict()}, buf)
+    buf.seek(0)
+    model.load_state_dict(torch.load(buf)["model_state_dict"], strict=True)
+    model.eval()
+    b0 = ref["batches"][0]
+    with torch.no_grad():
+        state = model.init_state(len(b0[1]))
+        for e, enc in enumerate(model.encoders):
+            state = enc(state, torch.from_numpy(b0[0][e]))
+        out = torch.stack([dec(state) for dec in model.decoders], 1).numpy()
+    r = O.forward_backward(params, spec, b0[0], b0[1], want_grads=False, keep_states=True)
+    want = O.decoder_outputs(params, spec, r.states[spec.E])
+    assert rel(out, want) < 2e-6, rel(out, want)
+    print("checkpoint round trip: build -> reference ok (rel err %.1e); reference -> fixture written" % rel(out, want))
+
+
 def rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-12)) if a.size else 0.0
@@ -360,6 +393,8 @@ def main():
         if "predict" in ev:
             b0 = ref["batches"][0]
             assert np.array_equal(O.predict(fin, spec, b0[0], b0[2] if len(b0) > 2 else None), ev["predict"]), name
+        if name == "mimic_drop":
+            checkpoint_round_trip(ref, cfg, spec)
         worst[name] = w
         print(f"{name:14s} steps={n_steps:3d} oracle-vs-reference rel err: " +
               " ".join(f"{k}={v:.2e}" for k, v in w.items()))

@@ -87,6 +87,28 @@ def test_mimic_family_host_logic_reproduces_golden_history(name):
     assert rel_err(th.loss["test"][0], z["eval/test_loss"]) < 2e-6
 
 
+def test_reference_written_checkpoint_loads():
+    """the checkpoint the MIMIC pipelines write (mimic_multi_task_pipeline.py:150-154), produced by
+    the REFERENCE's trained model (tests/golden/ref_checkpoint_mimic_drop.pt, tensors only), loads into the build with
+    strict key matching and evaluates to the reference's test() numbers.  The other direction (a build checkpoint
+    loading into the reference) is asserted in tests/golden/make_golden.py, the only place that has the reference."""
+    import os
+    from helpers import GOLDEN
+    g = Golden("mimic_drop")
+    ck = torch.load(os.path.join(GOLDEN, "ref_checkpoint_mimic_drop.pt"))
+    assert set(ck) == {"epoch", "model_state_dict", "auc_bac_val_cum"} and ck["epoch"] == g.epochs
+    model = build_torch_model(g.spec, g.init_params(), "cpu", mm)
+    missing = model.load_state_dict(ck["model_state_dict"], strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    for n, w in g.final_params().items():
+        assert np.array_equal(model.state_dict()[n].numpy(), w), n
+    model._engine_factory = OracleEngine
+    th = mm.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
+    model.test(make_loader(g), torch.nn.CrossEntropyLoss(), th, tag="test")
+    assert rel_err(th.loss["test"][0], g.z["eval/test_loss"]) < 2e-6
+    assert np.array_equal(th.accuracy["test"][0], g.z["eval/test_accuracy"])
+
+
 def test_mimic_plugin_forward_contract():
     """The plugins' own forward (module-level contract) equals the oracle's restatement of the reference modules."""
     torch.manual_seed(0)

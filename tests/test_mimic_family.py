@@ -121,6 +121,21 @@ def test_eval_entry_points_match_reference(lib, name):
         assert (pred != z["eval/predict"]).mean() < 0.01               # a class can flip only on a rounding-level tie
 
 
+def test_reference_written_checkpoint_evaluates_on_hip(lib):
+    """SURVEY 8f #4 on the GPU: load the reference-written checkpoint fixture, run test() on the HIP path."""
+    import os
+    from helpers import GOLDEN
+    g = Golden("mimic_drop")
+    model = build_torch_model(g.spec, g.init_params(), "cuda", lib)
+    ck = torch.load(os.path.join(GOLDEN, "ref_checkpoint_mimic_drop.pt"), map_location="cuda")
+    model.load_state_dict(ck["model_state_dict"], strict=True)
+    loader = [tuple([[torch.from_numpy(x) for x in b[0]], torch.from_numpy(b[1])]) for b in g.batches()]
+    hist = lib.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
+    model.test(loader, torch.nn.CrossEntropyLoss(), hist, tag="test")
+    assert rel_err(hist.loss["test"][0], g.z["eval/test_loss"]) < 1e-5
+    assert rel_err(torch.stack(model.get_states(loader)).cpu().numpy(), g.z["eval/states"]) < 1e-5
+
+
 @pytest.mark.parametrize("B", [1, 15, 17, 33, 257])
 def test_ragged_batches_match_oracle(lib, B):
     spec = O.ModelSpec(20, [O.EncoderSpec(7, (9, 6), O.ACT_RELU, kind="mimic", dropout=0.3),

@@ -20,7 +20,9 @@ def hipcc_path() -> str:
 def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
-    newest = max(os.path.getmtime(p) for p in (SRC, os.path.join(INC, "mmn_hip.h")))
+    csrc = os.path.dirname(SRC)                           # mmn_kernels.hip includes the *.inc files next to it
+    sources = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc"))]
+    newest = max(os.path.getmtime(p) for p in sources + [os.path.join(INC, "mmn_hip.h")])
     return os.path.getmtime(OUT) < newest
 
 

@@ -9,6 +9,9 @@ NaN scan + forward and reverse chain (one fused kernel) + weight grads + reducti
 step fused in [N>1: reduction, ONE RCCL all-reduce of grads+stats, loss/epoch accumulation, then
 Adam as its own launch].
 
+Other workloads (never what the driver reads): --workload c1|c2 (Titanic-shaped), c5 (per-sample missing modalities),
+mimic (the MIMIC pipelines' own modules, MIMIC_MLPEncoder + MLPDecoder, on the generic kernels k_genf_fwd / k_genf_bwd).
+
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MMN_VERSION 102            /* 0.1.2: MIMIC_MLPEncoder / MLPDecoder (mmn_encoder.kind, mmn_decoder.hidden, mmn_batch.drop_mask) */
+#define MMN_VERSION 103            /* 0.1.3: + mmn_draw_dropout; 0.1.2: MIMIC_MLPEncoder / MLPDecoder (mmn_encoder.kind, mmn_decoder.hidden, mmn_batch.drop_mask) */
 #define MMN_MAX_ENCODERS 16
 #define MMN_MAX_DECODERS 8
 #define MMN_MAX_LAYERS 8           /* hidden layers + the state-update Linear */
@@ -146,8 +146,8 @@ typedef struct mmn_batch {
     /* MIMIC_MLPEncoder dropout (mlp_encoder.py:34,41), indexed by ENCODER id: drop_mask[e] = device
      * [batch x (n_features_e + S)] multipliers (0 or 1/(1-p), row stride n_features_e + S) applied to
      * cat([x, state]) before the first Linear of encoder e, forward and backward.  NULL = no dropout
-     * for that encoder this step (eval mode, p = 0, or an MLPEncoder).  The caller draws them (the
-     * reference draws them from torch's generator; multimodn_amd does the same on the device). */
+     * for that encoder this step (eval mode, p = 0, or an MLPEncoder).  The caller provides them: from its own generator,
+     * or with mmn_draw_dropout below (what multimodn_amd does; tests hand in the reference's recorded draws). */
     const float* drop_mask[MMN_MAX_ENCODERS];
 } mmn_batch;
 
@@ -293,6 +293,19 @@ int mmn_adam_step_accumulate(mmn_plan* p, const mmn_adam* d, float err_penalty, 
 int mmn_train_step_adam(mmn_plan* p, const mmn_batch* b, float err_penalty, float state_change_penalty_x001,
                         int accumulate_epoch, const mmn_adam* adam, void* stream);
 int mmn_reduce_adam(mmn_plan* p, const mmn_batch* b, const mmn_adam* adam, void* stream);
+
+/* nn.Dropout of the MIMIC_MLPEncoders (mlp_encoder.py:34,41) as ONE launch (k_dropout): draws the multipliers of every
+ * MIMIC encoder of b's sequence whose drop_p[e] > 0 into `buf` (device, 16-byte aligned, mmn_dropout_floats(p, b->batch)
+ * floats: encoder after encoder in encoder-id order, [batch x (n_features_e + S)] each) and points b->drop_mask[e] at
+ * them (host fields of *b).  Counter-based generator: Philox4x32-10, key = seed, counter = (index of the 4-float group
+ * inside buf, draw index); a multiplier is 1/(1-p) if u >= p else 0, u = (32 random bits >> 8) * 2^-24.  The draw index
+ * lives in the plan's workspace and advances by one per launch ON THE DEVICE (the last workgroup to finish bumps it),
+ * so a captured launch draws fresh multipliers at every hipGraph replay; mmn_dropout_reset restarts it at 0 (call it
+ * when the seed changes).  drop_p: host array of n_encoders probabilities (entries of non-MIMIC encoders are ignored). */
+size_t mmn_dropout_floats(mmn_plan* p, int batch);
+int mmn_draw_dropout(mmn_plan* p, mmn_batch* b, const float* drop_p, uint64_t seed, float* buf, size_t buf_floats,
+                     void* stream);
+int mmn_dropout_reset(mmn_plan* p, void* stream);
 
 /* Epoch accumulators (device, inside the workspace): reset at epoch start, read at epoch end.
  * mmn_epoch_read synchronises the stream.  Layout of `out` (doubles): err_sum[R*D], sc_sum[E],

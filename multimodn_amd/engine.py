@@ -196,6 +196,10 @@ class HipChainEngine:
         # (encoder id, mask width F + S, p) of the MIMIC encoders whose nn.Dropout is active in training
         self.dropout_encoders = [(e, enc.n_features + self.S, float(enc.dropout))
                                  for e, enc in enumerate(model.encoders) if isinstance(enc, MIMIC_MLPEncoder) and enc.dropout > 0]
+        self._drop_p = (C.c_float * hip.MAX_ENCODERS)(*[float(getattr(enc, "dropout", 0.0)) if isinstance(enc, MIMIC_MLPEncoder)
+                                                          else 0.0 for enc in model.encoders])
+        self._drop_buf = None
+        self._drop_seed = None
 
     def __del__(self):
         try:
@@ -245,9 +249,9 @@ class HipChainEngine:
 
     def draw_dropout_masks(self, b: hip.Batch, provider=None) -> List[torch.Tensor]:
         """Training-mode nn.Dropout of the MIMIC encoders (mlp_encoder.py:34,41): one [batch, F_e + S]
-        multiplier tensor (0 or 1/(1-p)) per encoder that runs this step, drawn on the device from
-        torch's generator like the reference's modules draw theirs (torch.manual_seed governs both),
-        and handed to the kernels through mmn_batch.drop_mask.  `provider(e, batch, width)` (tests:
+        multiplier tensor (0 or 1/(1-p)) per encoder that runs this step, drawn on the device by ONE
+        HIP launch (k_dropout, seeded with torch.initial_seed(): torch.manual_seed governs it as it governs
+        the reference's modules) and handed to the kernels through mmn_batch.drop_mask.  `provider(e, batch, width)` (tests:
         the masks the reference drew) replaces the draw.  Returns the tensors: keep them alive until
         the step's launches have run."""
         running = {b.seq_enc[t] for t in range(b.n_seq)}
@@ -255,33 +259,43 @@ class HipChainEngine:
         if not todo:
             return []
         B = int(b.batch)
-        if provider is None and len({p for _, _, p in todo}) == 1:
-            # one draw for all encoders (2 launches per step instead of 2 per encoder); encoder e's mask is a
-            # contiguous [B, width_e] slice of the flat buffer
-            p = todo[0][2]
-            flat = torch.empty(B * sum(w for _, w, _ in todo), dtype=torch.float32, device=self.device)
-            flat.bernoulli_(1.0 - p).div_(1.0 - p)
-            keep, off = [], 0
-            for e, w, _ in todo:
-                mk = flat[off:off + B * w].view(B, w)
-                b.drop_mask[e] = mk.data_ptr()
-                keep.append(mk)
-                off += B * w
-            return keep
+        if provider is None:
+            # one k_dropout launch (Philox4x32-10 keyed by torch's seed; include/mmn_hip.h, mmn_draw_dropout): the draw
+            # index advances on the device, so a captured step draws fresh multipliers at every graph replay
+            need = int(self.lib.mmn_dropout_floats(self._plan, self.max_batch))
+            if self._drop_buf is None or self._drop_buf.numel() < need:
+                self._drop_buf = torch.empty(need, dtype=torch.float32, device=self.device)
+            seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+            if seed != self._drop_seed:                        # torch.manual_seed(...) restarts the sequence
+                self.reset_dropout()
+                self._drop_seed = seed
+            hip.check(self.lib.mmn_draw_dropout(self._plan, C.byref(b), self._drop_p, seed, self._drop_buf.data_ptr(),
+                                                self._drop_buf.numel(), self._stream()), "mmn_draw_dropout")
+            views, off = [], 0
+            for e, enc in enumerate(self.model.encoders):      # the library's layout: MIMIC encoders in id order
+                if not isinstance(enc, MIMIC_MLPEncoder):
+                    continue
+                w = enc.n_features + self.S
+                n = (B * w + 3) // 4 * 4
+                if enc.dropout > 0 and e in running:
+                    views.append(self._drop_buf[off:off + B * w].view(B, w))
+                    off += n
+            return views
         keep = []
         for e, width, p in todo:
-            if provider is not None:
-                mk = provider(e, B, width)
-                if mk is None:
-                    continue
-                mk = mk.to(self.device, torch.float32).contiguous()
-            else:
-                mk = torch.empty((B, width), dtype=torch.float32, device=self.device).bernoulli_(1.0 - p).div_(1.0 - p)
+            mk = provider(e, B, width)
+            if mk is None:
+                continue
+            mk = mk.to(self.device, torch.float32).contiguous()
             if tuple(mk.shape) != (B, width):
                 raise ValueError(f"dropout mask of encoder {e}: expected {(B, width)}, got {tuple(mk.shape)}")
             b.drop_mask[e] = mk.data_ptr()
             keep.append(mk)
         return keep
+
+    def reset_dropout(self) -> None:
+        """Restart the dropout generator's draw index (same seed -> same multipliers again)."""
+        hip.check(self.lib.mmn_dropout_reset(self._plan, self._stream()), "mmn_dropout_reset")
 
     def local_step(self, b: hip.Batch, err_penalty: float, sc_penalty_x001: float, accumulate: bool = False,
                    optimizer=None) -> bool:

@@ -17,7 +17,7 @@ MAX_LAYERS = 8
 MAX_DIM = 256
 ADAM_MAX_SEG = 512
 ERR_UNSUPPORTED = -2
-VERSION = 102
+VERSION = 103
 MAX_DEC_HIDDEN = 3
 ENC_MLP, ENC_MIMIC = 0, 1
 
@@ -33,6 +33,7 @@ ABI_SYMBOLS = (
     "mmn_nan_scan", "mmn_chain_kernel_name", "mmn_chain_fwd",
     "mmn_chain_bwd", "mmn_chain_fwd_bwd", "mmn_wgrad", "mmn_reduce", "mmn_epoch_accumulate", "mmn_train_step",
     "mmn_eval_step", "mmn_adam_blocks", "mmn_adam_step", "mmn_adam_step_accumulate", "mmn_train_step_adam", "mmn_reduce_adam", "mmn_regroup_rows", "mmn_regroup", "mmn_epoch_reset", "mmn_epoch_read", "mmn_debug_buffer",
+    "mmn_dropout_floats", "mmn_draw_dropout", "mmn_dropout_reset",
 )
 
 
@@ -156,6 +157,12 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_epoch_read.argtypes = [vp, C.POINTER(C.c_double), vp]
     lib.mmn_debug_buffer.restype = vp
     lib.mmn_debug_buffer.argtypes = [vp, i32, i32]
+    lib.mmn_dropout_floats.restype = C.c_size_t
+    lib.mmn_dropout_floats.argtypes = [vp, i32]
+    lib.mmn_draw_dropout.restype = i32
+    lib.mmn_draw_dropout.argtypes = [vp, C.POINTER(Batch), C.POINTER(C.c_float), C.c_uint64, vp, C.c_size_t, vp]
+    lib.mmn_dropout_reset.restype = i32
+    lib.mmn_dropout_reset.argtypes = [vp, vp]
     if lib.mmn_version() != VERSION:
         raise MmnError(f"{p}: ABI version {lib.mmn_version()} != expected {VERSION}; rebuild")
     if path is None:

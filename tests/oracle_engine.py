@@ -81,6 +81,9 @@ class OracleEngine:
                 b.masks[e] = mk.numpy()
         return list(b.masks.values())
 
+    def reset_dropout(self):
+        pass
+
     def per_sample_batch(self, xs, y, seq):
         b = _Batch()
         b.xs = [x.numpy() for x in xs]

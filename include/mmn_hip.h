@@ -294,13 +294,14 @@ int mmn_train_step_adam(mmn_plan* p, const mmn_batch* b, float err_penalty, floa
                         int accumulate_epoch, const mmn_adam* adam, void* stream);
 int mmn_reduce_adam(mmn_plan* p, const mmn_batch* b, const mmn_adam* adam, void* stream);
 
-/* nn.Dropout of the MIMIC_MLPEncoders (mlp_encoder.py:34,41) as one launch (k_dropout + a one-thread counter bump): draws the multipliers of every
+/* nn.Dropout of the MIMIC_MLPEncoders (mlp_encoder.py:34,41) as ONE launch (k_dropout): draws the multipliers of every
  * MIMIC encoder of b's sequence whose drop_p[e] > 0 into `buf` (device, 16-byte aligned, mmn_dropout_floats(p, b->batch)
  * floats: encoder after encoder in encoder-id order, [batch x (n_features_e + S)] each) and points b->drop_mask[e] at
  * them (host fields of *b).  Counter-based generator: Philox4x32-10, key = seed, counter = (index of the 4-float group
  * inside buf, draw index); a multiplier is 1/(1-p) if u >= p else 0, u = (32 random bits >> 8) * 2^-24.  The draw index
- * lives in the plan's workspace and advances by one per call ON THE DEVICE (a one-thread launch right behind k_dropout),
- * so a captured call draws fresh multipliers at every hipGraph replay; mmn_dropout_reset restarts it at 0 (call it
+ * lives in the plan's workspace and advances by one per call ON THE DEVICE (in the k_prepare launch of the step that
+ * follows - mmn_prepare / mmn_train_step* / mmn_eval_step - or in a one-thread launch when another draw comes first),
+ * so a captured draw + step pair draws fresh multipliers at every hipGraph replay; mmn_dropout_reset restarts it at 0 (call it
  * when the seed changes).  drop_p: host array of n_encoders probabilities (entries of non-MIMIC encoders are ignored). */
 size_t mmn_dropout_floats(mmn_plan* p, int batch);
 int mmn_draw_dropout(mmn_plan* p, mmn_batch* b, const float* drop_p, uint64_t seed, float* buf, size_t buf_floats,

@@ -309,6 +309,8 @@ def test_device_dropout_draw(lib):
     want = [expected_masks(123, d, sizes, ps)[0].reshape(B, 192) for d in (1, 2, 3)]     # draw 0 was the warm-up
     for a, w in zip(seen, want):
         assert np.array_equal(a, w)
+    del graph, views                                         # release the capture's private pool before the engine goes
+    torch.cuda.synchronize()
 
 
 def test_unsupported_combinations_are_refused(lib):

@@ -20,6 +20,15 @@
  *   - return value: 0 = ok, <0 = error (mmn_error_string()).  Nothing throws.
  *   - arithmetic: fp32 in, fp32 accumulate (v_mfma_f32_16x16x4_f32 = exact fp32 FMA chains);
  *     int64 targets; deterministic (no float atomics: fixed-order two-stage reductions).
+ *
+ * Environment (diagnostics and tests only; read ONCE per mmn_plan_create, never needed in production):
+ *   MMN_FUSED=0 / MMN_FAST8=0 / MMN_PAR=0   step down the kernel tiers (fused 8-wave -> 8-wave pair -> 4-wave parallel ->
+ *                                           sequential); MMN_RT=1|2 forces 16- / 32-row tiles of the sequential tiers
+ *   MMN_GENERIC=1                           run MLPEncoder / ClassDecoder models on the generic tier's kernels too
+ *   MMN_GEN_FAST=0 / MMN_DEC_LDS=0          generic tier: sequential form only / decoder operands from global memory
+ *   MMN_WGRAD_ROWS=n                        rows per k_wgrad row-range split (default 512)
+ *   MMN_STAMPS=1                            phase timestamps of one workgroup (mmn_debug_buffer kind 3; tools/stamps*.py)
+ *   MMN_VERBOSE=1                           plan summary on stderr
  */
 #ifndef MMN_HIP_H
 #define MMN_HIP_H

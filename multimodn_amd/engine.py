@@ -475,6 +475,10 @@ class HipChainEngine:
         eval_step (decoder d at columns 2d, 2d+1).  After a TRAINING step this buffer holds dz."""
         return self.debug_tensor(1, row, self.max_batch, 2 * self.D)[:batch]
 
+    def executed_flags(self) -> torch.Tensor:
+        """int32 [E+1] device view: 1 where the last step produced the state row (row 0 always 1).  No sync."""
+        return self.debug_tensor(4, 0, 1, self.E + 1).view(torch.int32).flatten()
+
     def executed_rows(self) -> List[bool]:
         """Which state rows the last step produced (synchronises; the device NaN policy needs it)."""
         return [bool(v) for v in self.debug_tensor(4, 0, 1, self.E + 1).view(torch.int32).flatten().tolist()]

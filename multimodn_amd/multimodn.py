@@ -388,8 +388,12 @@ class MultiModN(nn.Module):
         n_batches = len(test_loader)
         eng = None
         keep = None
+        # Nothing in the batch loop waits for the GPU: targets, last-row outputs and (device NaN policy) the "row
+        # exists" flags of every step stay on the device as small clones and are sorted out once after the loop
+        # (a per-step .to("cpu") / flag readback made this loop ~3 ms per batch against ~45 us of kernels).
         outputs_epoch: List[Tensor] = []
         targets_epoch: List[Tensor] = []
+        last_ran: List = []                                  # per step: bool (host policy) or a device flag tensor
         for batch in test_loader:
             data, target, encoder_sequence = (list(batch) + [None])[:3]
             if eng is None:
@@ -405,16 +409,16 @@ class MultiModN(nn.Module):
                 for j in range(len(self.encoders)):
                     has_last |= ((codes >> (4 * j)) & 15) == last + 1
                 rows_l = torch.nonzero(has_last).flatten()       # samples whose LAST encoder ran (multimodn.py:354-357)
-                targets_epoch.append(keep[1].detach()[rows_l].to("cpu"))
+                targets_epoch.append(keep[1].detach()[rows_l])
                 bp = int(keep[2][1].shape[0])
                 outputs_epoch.append(eng.decoder_outputs(last + 1, bp)[where[rows_l]].clone())
                 continue
             executed, keep = self._run_step(eng, data, target, encoder_sequence, train=False)
-            if executed is None:                               # device NaN policy: ask the GPU which rows exist
-                executed = eng.executed_rows()[1:]
-            targets_epoch.append(keep[1].detach().to("cpu"))
-            if executed[last]:                                  # multimodn.py:354-357: only the LAST encoder's row
-                outputs_epoch.append(eng.decoder_outputs(last + 1, int(keep[1].shape[0])).clone())
+            targets_epoch.append(keep[1].detach().clone())      # (a staged host batch's device copy is recycled)
+            outputs_epoch.append(eng.decoder_outputs(last + 1, int(keep[1].shape[0])).clone())
+            # multimodn.py:354-357: only batches whose LAST encoder ran contribute outputs; under the device NaN
+            # policy that is known on the GPU only: keep this step's flag word for later
+            last_ran.append(executed[last] if executed is not None else eng.executed_flags()[last + 1:last + 2].clone())
         if eng is None:
             return None
         arrays = self._epoch_arrays(eng, n_batches)
@@ -429,14 +433,23 @@ class MultiModN(nn.Module):
                 getattr(history, name).setdefault(tag, []).append(arrays[name])
         # per-decoder report on the state after the last encoder (multimodn.py:410-419)
         results: List = [[]] * len(self.decoders)
+        if last_ran and not self.per_sample:                   # one readback for all the steps' flags
+            dev_flags = [f for f in last_ran if isinstance(f, Tensor)]
+            if dev_flags:
+                host_flags = iter(torch.cat(dev_flags).cpu().tolist())
+                last_ran = [bool(next(host_flags)) if isinstance(f, Tensor) else f for f in last_ran]
+            outputs_epoch = [o for o, ran in zip(outputs_epoch, last_ran) if ran]
         if outputs_epoch:
-            out = torch.cat(outputs_epoch, dim=0).to("cpu")            # [N, 2D]
-            tgt = torch.cat(targets_epoch, dim=0)
+            out = torch.cat(outputs_epoch, dim=0)                      # [N, 2D], on the model's device
+            tgt = torch.cat(targets_epoch, dim=0).to(out.device)
             for d in range(len(self.decoders)):
                 o = out[:, 2 * d:2 * d + 2]
                 o = torch.div(o, torch.sum(o, dim=1).reshape(-1, 1))   # class probabilities sum to 1 (:415)
                 _, pred = torch.max(o, dim=1)
-                results[d] = get_performance_metrics(tgt[:, d], pred, o[:, 1])
+                # the report (sort + cumulative sums over N scores) runs where the scores are; like the reference's
+                # torchmetrics values the results are handed back as CPU tensors
+                res = get_performance_metrics(tgt[:, d], pred, o[:, 1])
+                results[d] = tuple(v.cpu() if isinstance(v, Tensor) else v for v in res)
         return results
 
     def predict(self, x: List[Tensor], encoder_sequence: Optional[np.ndarray] = None) -> np.ndarray:
@@ -508,7 +521,15 @@ class MultiModN(nn.Module):
             b = eng.make_batch(xs, y, exec_pairs, batch_global=n, device_nan_flags=executed is None)
             eng.eval_step(b, accumulate=False)
             if executed is None:
-                executed = eng.executed_rows()[1:]
+                # device NaN policy: which encoders ran is known on the GPU only; pick the last executed one's state
+                # with device-side selects instead of reading the flags back every batch
+                flags = eng.executed_flags()
+                state = self.init_state(n).detach().to(self.device)
+                for _, e in pairs:
+                    state = torch.where(flags[e + 1] != 0, eng.state_rows(e, n), state)
+                batch_states.append(state.clone())
+                del xs, y
+                continue
             last = None
             for _, e in pairs:
                 if executed[e]:

@@ -162,6 +162,9 @@ class OracleEngine:
         o = O.decoder_outputs(params, self.spec, r.states[row][:batch])
         return torch.from_numpy(np.ascontiguousarray(o.reshape(o.shape[0], -1)))
 
+    def executed_flags(self):
+        return torch.tensor([1] + [int(v) for v in self._last[1].executed], dtype=torch.int32)
+
     def executed_rows(self):
         return [True] + [bool(v) for v in self._last[1].executed]
 

@@ -200,6 +200,7 @@ class HipChainEngine:
                                                           else 0.0 for enc in model.encoders])
         self._drop_buf = None
         self._drop_seed = None
+        self._step_graphs: Dict[tuple, list] = {}             # replayable_train_step: key -> [sightings, graph, keep-alive]
 
     def __del__(self):
         try:
@@ -322,6 +323,56 @@ class HipChainEngine:
         hip.check(self.lib.mmn_train_step(self._plan, C.byref(b), err_penalty, sc_penalty_x001,
                                           1 if accumulate else 0, self._stream()), "mmn_train_step")
         return False
+
+    # ------------------------------------------------------------------ whole steps as replayable hipGraphs
+    MAX_STEP_GRAPHS = 64
+
+    def replayable_train_step(self, xs, y, pairs, batch_global, err_penalty: float, sc_penalty_x001: float, optimizer,
+                              draw_dropout: bool) -> bool:
+        """One training step (device NaN policy, Adam fused) for a batch whose device buffers this engine has seen
+        before: the step - k_dropout, k_prepare, chain, k_wgrad, k_reduce+Adam - is captured into a hipGraph on its
+        second sighting and replayed from then on (ONE host submission instead of 4-5 launches; at the reference
+        pipelines' batch sizes of 16-32 rows the step is host-bound otherwise).  Loaders hand the same device buffers
+        back every epoch (DeviceResidentLoader views, the staging ring of host batches), so this pays from the second
+        epoch on.  Everything a replay must see fresh lives in device memory (Adam step counters, epoch accumulators,
+        NaN flags, the dropout draw index); what is baked into the graph is in the key (buffers, sequence,
+        hyper-parameters, dropout seed).  Returns False when the step cannot be cached: the caller runs it eagerly."""
+        d = optimizer.fused_descriptor(self) if hasattr(optimizer, "fused_descriptor") else None
+        if d is None or torch.cuda.is_current_stream_capturing():
+            return False
+        seed = (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF) if draw_dropout else 0
+        if draw_dropout and seed != self._drop_seed:            # a new seed restarts the draw index: do that eagerly
+            return False
+        key = (tuple(x.data_ptr() for x in xs), tuple(int(x.stride(0)) for x in xs), y.data_ptr(), int(y.shape[0]),
+               tuple(pairs), int(batch_global), float(err_penalty), float(sc_penalty_x001), seed,
+               d.lr, d.beta1, d.beta2, d.eps, d.weight_decay, d.maximize)
+        ent = self._step_graphs.get(key)
+        if ent is None:
+            if len(self._step_graphs) >= self.MAX_STEP_GRAPHS:
+                return False
+            self._step_graphs[key] = [1, None, None]            # first sighting: the caller's eager step is the warm-up
+            return False
+        if ent[1] is None:
+            if ent[0] < 0:                                      # capture failed earlier for this key
+                return False
+            try:
+                b = self.make_batch(xs, y, pairs, batch_global=batch_global, device_nan_flags=True)
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream())
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(graph, stream=side):
+                        keep = self.draw_dropout_masks(b) if draw_dropout else None
+                        hip.check(self.lib.mmn_train_step_adam(self._plan, C.byref(b), err_penalty, sc_penalty_x001, 1,
+                                                               C.byref(d), side.cuda_stream), "mmn_train_step_adam")
+                torch.cuda.current_stream().wait_stream(side)
+                ent[1], ent[2] = graph, (xs, y, b, keep, side)
+            except Exception:
+                ent[0] = -1
+                return False
+        ent[1].replay()
+        optimizer.mark_fused_step()
+        return True
 
     # ------------------------------------------------------------------ per-sample mode (BASELINE configs[4])
     def per_sample_batch(self, xs: Sequence[torch.Tensor], y: torch.Tensor, seq: Optional[torch.Tensor]):

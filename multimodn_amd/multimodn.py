@@ -124,6 +124,11 @@ class MultiModN(nn.Module):
         # tests: callable (encoder id, batch, width) -> [batch, width] multipliers replacing the device draw
         # of the MIMIC encoders' dropout masks (parity runs feed the masks the reference drew)
         self.dropout_mask_provider = None
+        #: single GPU, nan_policy "device", multimodn_amd.optim.Adam, batches of at most REPLAY_MAX_ROWS rows (the
+        #: reference pipelines train with 16-32): a step whose device buffers were seen before is captured into a
+        #: hipGraph once and replayed afterwards (engine.replayable_train_step)
+        self.replay_steps = True
+        self.REPLAY_MAX_ROWS = 256
 
     # nn.Module pickling: the engine holds raw device handles and is rebuilt on demand
     def __getstate__(self):
@@ -218,9 +223,17 @@ class MultiModN(nn.Module):
         pairs = self.get_encoder_iterable(encoder_sequence, self.shuffle_mode, train=train)
         xs, y, exec_pairs, executed = self._ingest(data, target, pairs)
         B = int(y.shape[0])
+        dp = self._dp_group is not None
+        # (replaying pays where the step is host-bound - measured: 50 -> 39 us/step at 32 rows, break-even at 512,
+        #  a replayed single-step graph is ~7 us SLOWER than four eager launches once the GPU is the bottleneck)
+        if (train and not dp and executed is None and getattr(self, "replay_steps", True) and B <= getattr(self, "REPLAY_MAX_ROWS", 256)
+                and self.dropout_mask_provider is None
+                and hasattr(eng, "replayable_train_step")
+                and eng.replayable_train_step(xs, y, exec_pairs, batch_global or B, float(self.err_penalty),
+                                              float(self.state_change_penalty), optimizer, bool(eng.dropout_encoders))):
+            return executed, (xs, y, None)
         b = eng.make_batch(xs, y, exec_pairs, batch_global=batch_global or B * self._dp_world,
                            device_nan_flags=executed is None)
-        dp = self._dp_group is not None
         if dp and executed is None and exec_pairs:
             # device NaN policy under data parallel: the skip decision belongs to the GLOBAL batch
             # (multimodn.py:168 looks at the whole batch): OR the per-slot flags over the ranks first

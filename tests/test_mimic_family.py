@@ -121,6 +121,43 @@ def test_eval_entry_points_match_reference(lib, name):
         assert (pred != z["eval/predict"]).mean() < 0.01               # a class can flip only on a rounding-level tie
 
 
+@pytest.mark.parametrize("family", ["classic", "mimic"])
+def test_replayed_steps_equal_eager_steps(lib, family):
+    """train_epoch with nan_policy "device" + multimodn_amd.optim.Adam captures a step into a hipGraph the second time
+    it sees the same device buffers and replays it afterwards (engine.replayable_train_step).  Four epochs over the
+    same device-resident batches, with replay on and off: History and trained weights must be identical bit for bit
+    (deterministic kernels; Adam counters, epoch sums and the dropout draw index live on the device)."""
+    if family == "mimic":
+        spec = O.ModelSpec(32, [O.EncoderSpec(12, (16, 16), O.ACT_RELU, kind="mimic", dropout=0.2) for _ in range(3)], 2, 1.0, 0.3,
+                           decoders=[O.DecoderSpec("mlp", (16,)) for _ in range(2)])
+    else:
+        spec = O.ModelSpec(32, [O.EncoderSpec(12, (16, 16), O.ACT_RELU) for _ in range(3)], 2, 1.0, 0.3)
+    params = O.init_params(spec, 2)
+    batches = O.synthetic_batches(spec, 5 * 48, 48, seed=9)
+    loader = [([torch.from_numpy(x).cuda() for x in xs], torch.from_numpy(y).cuda()) for xs, y in batches]
+    runs = {}
+    for replay in (True, False):
+        torch.manual_seed(77)
+        model = build_torch_model(spec, params, "cuda", lib)
+        model.nan_policy = "device"
+        model.replay_steps = replay
+        opt = lib.optim.Adam(list(model.parameters()), 1e-2)
+        hist = lib.MultiModNHistory(["a", "b"])
+        for _ in range(4):
+            model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+        torch.cuda.synchronize()
+        n_graphs = sum(1 for v in model._engine._step_graphs.values() if v[1] is not None)
+        assert n_graphs == (5 if replay else 0)
+        runs[replay] = (np.stack(hist.loss["train"]), np.stack(hist.state_change_loss),
+                        {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()},
+                        {k: v["step"].item() for k, v in list(opt.state.items())[:1]})
+    assert np.array_equal(runs[True][0], runs[False][0]) and np.array_equal(runs[True][1], runs[False][1])
+    for k in runs[True][2]:
+        assert np.array_equal(runs[True][2][k], runs[False][2][k]), k
+    assert list(runs[True][3].values()) == list(runs[False][3].values()) == [20.0]
+    assert runs[True][0][-1].mean() < runs[True][0][0].mean()
+
+
 def test_mimic_pipeline_shape_runs_end_to_end(lib):
     """examples/mimic_like_pipeline.py = the body of the reference's MIMIC multi-task pipeline with the import swapped
     (stock DataLoader over Subsets of a PartitionDataset, MIMIC_MLPEncoder / MLPDecoder, dropout live in training,

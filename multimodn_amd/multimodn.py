@@ -114,9 +114,12 @@ class MultiModN(nn.Module):
         self._dp_group = None
         self._dp_world = 1
         self._stager: Optional[_HostStager] = None
-        #: "host": decide NaN-skips on the host like the reference (exact grad=None semantics);
-        #: "device": keep the decision on the GPU (no sync; skipped encoders get zero grads)
-        self.nan_policy = "host"
+        #: "host": decide NaN-skips on the host like the reference (exact grad=None semantics, one readback per step);
+        #: "device": keep the decision on the GPU (no sync; a skipped encoder's .grad reads zeros instead of None);
+        #: "auto" (default): "device" whenever the result is the reference's anyway - forward-only entry points, and
+        #: training with multimodn_amd.optim.Adam, which leaves a skipped encoder's parameters, moments and step counts
+        #: untouched exactly as torch does for grad None - and "host" for every other optimizer
+        self.nan_policy = "auto"
         #: build-defined extension (BASELINE.json configs[4]): every SAMPLE may miss modalities (NaN
         #: rows) and carry its own encoder order; the batch result is the mean over the samples of the
         #: reference's batch-size-1 result (the only case the reference defines, multimodn.py:168,518-523)
@@ -171,10 +174,12 @@ class MultiModN(nn.Module):
         return pairs
 
     # ------------------------------------------------------------------------------------------
-    def _ingest(self, data: Sequence[Tensor], target, pairs):
+    def _ingest(self, data: Sequence[Tensor], target, pairs, optimizer=None, train: bool = False):
         """Host half of multimodn.py:132-135,168: move the batch to the device, decide NaN skips.
         Returns (xs_dev, y_dev, executed_pairs, executed_mask or None)."""
-        use_device_policy = self.nan_policy == "device"
+        policy = getattr(self, "nan_policy", "auto")
+        use_device_policy = policy == "device" or (
+            policy == "auto" and (not train or hasattr(optimizer, "fused_descriptor")))
         present: Optional[List[bool]] = None
         if not isinstance(target, Tensor):
             target = torch.as_tensor(np.asarray(target))
@@ -221,7 +226,7 @@ class MultiModN(nn.Module):
     def _run_step(self, eng, data, target, encoder_sequence, train: bool, batch_global: Optional[int] = None,
                   optimizer=None):
         pairs = self.get_encoder_iterable(encoder_sequence, self.shuffle_mode, train=train)
-        xs, y, exec_pairs, executed = self._ingest(data, target, pairs)
+        xs, y, exec_pairs, executed = self._ingest(data, target, pairs, optimizer, train)
         B = int(y.shape[0])
         dp = self._dp_group is not None
         # (replaying pays where the step is host-bound - measured: 50 -> 39 us/step at 32 rows, break-even at 512,

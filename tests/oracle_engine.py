@@ -154,12 +154,17 @@ class OracleEngine:
             self.accumulate(1.0, 0.0)
 
     # what a step leaves behind (HipChainEngine.state_rows / decoder_outputs / executed_rows)
+    def _state(self, row, batch):
+        """Row of a skipped encoder: the HIP engine's buffer holds stale data there (callers mask it); zeros here."""
+        st = self._last[1].states
+        return st[row][:batch] if row in st else np.zeros((batch, self.S), np.float32)
+
     def state_rows(self, e, batch):
-        return torch.from_numpy(np.ascontiguousarray(self._last[1].states[e + 1][:batch]))
+        return torch.from_numpy(np.ascontiguousarray(self._state(e + 1, batch)))
 
     def decoder_outputs(self, row, batch):
         params, r = self._last
-        o = O.decoder_outputs(params, self.spec, r.states[row][:batch])
+        o = O.decoder_outputs(params, self.spec, self._state(row, batch))
         return torch.from_numpy(np.ascontiguousarray(o.reshape(o.shape[0], -1)))
 
     def executed_flags(self):

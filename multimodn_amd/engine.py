@@ -348,8 +348,8 @@ class HipChainEngine:
                d.lr, d.beta1, d.beta2, d.eps, d.weight_decay, d.maximize)
         ent = self._step_graphs.get(key)
         if ent is None:
-            if len(self._step_graphs) >= self.MAX_STEP_GRAPHS:
-                return False
+            if len(self._step_graphs) >= self.MAX_STEP_GRAPHS:  # e.g. an LR scheduler changed the baked hyper-parameters:
+                self._step_graphs.clear()                       # start over with the current ones
             self._step_graphs[key] = [1, None, None]            # first sighting: the caller's eager step is the warm-up
             return False
         if ent[1] is None:

@@ -266,7 +266,7 @@ class HipChainEngine:
             need = int(self.lib.mmn_dropout_floats(self._plan, self.max_batch))
             if self._drop_buf is None or self._drop_buf.numel() < need:
                 self._drop_buf = torch.empty(need, dtype=torch.float32, device=self.device)
-            seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+            seed = (int(torch.initial_seed()) ^ (int(getattr(self, "dropout_salt", 0)) * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
             if seed != self._drop_seed:                        # torch.manual_seed(...) restarts the sequence
                 self.reset_dropout()
                 self._drop_seed = seed
@@ -340,7 +340,8 @@ class HipChainEngine:
         d = optimizer.fused_descriptor(self) if hasattr(optimizer, "fused_descriptor") else None
         if d is None or torch.cuda.is_current_stream_capturing():
             return False
-        seed = (int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF) if draw_dropout else 0
+        seed = ((int(torch.initial_seed()) ^ (int(getattr(self, "dropout_salt", 0)) * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF) \
+            if draw_dropout else 0
         if draw_dropout and seed != self._drop_seed:            # a new seed restarts the draw index: do that eagerly
             return False
         key = (tuple(x.data_ptr() for x in xs), tuple(int(x.stride(0)) for x in xs), y.data_ptr(), int(y.shape[0]),

@@ -139,6 +139,7 @@ class MultiModN(nn.Module):
         state["_engine"] = None
         state["_dp_group"] = None
         state["_dp_world"] = 1
+        state["_dp_rank"] = 0
         state["_stager"] = None
         return state
 
@@ -151,11 +152,15 @@ class MultiModN(nn.Module):
             raise RuntimeError("torch.distributed is not initialised")
         self._dp_group = process_group if process_group is not None else dist.group.WORLD
         self._dp_world = dist.get_world_size(self._dp_group)
+        self._dp_rank = dist.get_rank(self._dp_group)
 
     def _get_engine(self, batch: int):
         if self._engine is None:
             self._engine = self._engine_factory(self, max(int(batch), 1))
         self._engine.ensure(int(batch))
+        # data parallel: every rank draws ITS rows' dropout multipliers from its own stream (same torch seed on all
+        # ranks is the usual discipline; identical multipliers on different rows would correlate the shards)
+        self._engine.dropout_salt = int(getattr(self, "_dp_rank", 0)) if self._dp_group is not None else 0
         return self._engine
 
     def get_encoder_iterable(self, encoder_sequence, shuffle_mode: bool, train: bool) -> List[Tuple[int, int]]:

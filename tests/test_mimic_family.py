@@ -121,6 +121,35 @@ def test_eval_entry_points_match_reference(lib, name):
         assert (pred != z["eval/predict"]).mean() < 0.01               # a class can flip only on a rounding-level tie
 
 
+def test_replayed_steps_with_host_batches(lib):
+    """The same with HOST batches (a stock DataLoader's tensors): they are staged through a ring of three device
+    buffers, whose addresses repeat every third batch with NEW content - a replayed step must read the fresh copy."""
+    spec = O.ModelSpec(32, [O.EncoderSpec(6, (5, 5), O.ACT_RELU)], 1, 0.7, 0.3)
+    params = O.init_params(spec, 3)
+    batches = O.synthetic_batches(spec, 7 * 32, 32, seed=10)
+    loader = [([torch.from_numpy(x) for x in xs], torch.from_numpy(y)) for xs, y in batches]      # CPU tensors
+    runs = {}
+    for replay in (True, False):
+        model = build_torch_model(spec, params, "cuda", lib)
+        model.replay_steps = replay                          # nan_policy "auto" + the HIP Adam: device-side decision
+        opt = lib.optim.Adam(list(model.parameters()), 1e-2)
+        hist = lib.MultiModNHistory(["a"])
+        for _ in range(3):
+            model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+        torch.cuda.synchronize()
+        if replay:
+            assert any(v[1] is not None for v in model._engine._step_graphs.values())
+        runs[replay] = (np.stack(hist.loss["train"]), {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()})
+    assert np.array_equal(runs[True][0], runs[False][0])
+    for k in runs[True][1]:
+        assert np.array_equal(runs[True][1][k], runs[False][1][k]), k
+    ref_p = {k: v.copy() for k, v in params.items()}
+    oopt = O.Adam(1e-2)
+    for _ in range(3):
+        ep = O.train_epoch(ref_p, spec, batches, oopt)
+    assert rel_err(runs[True][0][-1], ep.loss) < 1e-5          # and it is the oracle's trajectory
+
+
 @pytest.mark.parametrize("family", ["classic", "mimic"])
 def test_replayed_steps_equal_eager_steps(lib, family):
     """train_epoch with nan_policy "device" + multimodn_amd.optim.Adam captures a step into a hipGraph the second time

@@ -4,15 +4,16 @@
 Workload (N=1): BASELINE.json configs[2], the configuration the metric is quoted on:
 synthetic MIMIC-shaped tabular data, 4 modalities x 64 features, 3 binary tasks, state_dim 128,
 encoder hidden (32, 32) relu, batch 4096 per GPU, Adam lr 1e-3, err_penalty 1, state_change 0.3.
-A "step" = one full training step of one mini-batch whose inputs are already resident in HBM:
-NaN scan + forward and reverse chain (one fused kernel) + weight grads + reduction with the Adam
-step fused in [N>1: reduction, ONE RCCL all-reduce of grads+stats, loss/epoch accumulation, then
-Adam as its own launch].
+A "step" = one full training step of one mini-batch whose inputs are already resident in HBM, driven
+through the package's own batch loop (MultiModN._train_steps = the body of train_epoch): forward and
+reverse chain (one fused kernel) + weight grads + reduction with the Adam step, the refresh of the
+chain kernels' weight copies and the NaN scan of the NEXT batch fused in [N>1: reduction + pre-scan,
+ONE RCCL all-reduce of grads + stats + NaN flags, then loss/epoch accumulation + Adam in one launch].
 
 Other workloads (never what the driver reads): --workload c1|c2 (Titanic-shaped), c5 (per-sample missing modalities),
 mimic (the MIMIC pipelines' own modules, MIMIC_MLPEncoder + MLPDecoder, on the generic kernels k_genf_fwd / k_genf_bwd).
 
-Launch:  python bench.py [--gpus N --steps K --warmup W]
+Launch:  python bench.py [--gpus N --steps K --warmup W]      (N>1 without a launcher: it starts its own N ranks)
          N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -26,7 +27,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 import numpy as np
-import torch
+
+torch = None                       # imported in main() / where needed: the launcher parent (--gpus N without a launcher)
+                                   # never loads it, let alone touches a GPU
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix) = vector peak
 HBM_PEAK_GBS = 8000.0
@@ -70,6 +73,7 @@ def oracle_spec(O, w):
 def build_model(mm, w, device):
     """The workload's model on the product surface: MLPEncoder / LogisticDecoder / MultiModN with
     torch's default initialisation under a fixed seed (the same weights on every rank)."""
+    import torch
     torch.manual_seed(0)
     if w.get("family") == "mimic":      # mimic_multi_task_pipeline.py:118-119
         enc = [mm.MIMIC_MLPEncoder(w["S"], f, tuple(w["H"]), dropout=w["dropout"]) for f in w["F"]]
@@ -148,6 +152,7 @@ def cpu_match(O, mm, w, device, batch_size, steps=3):
     `steps` training steps (same initial weights, same batches, Adam) at the workload's full size;
     reported are the largest relative difference of the (E+1) x D loss grid over the steps and of
     the trained weights (relative to each tensor's max).  Target: <= 1e-5 on the loss."""
+    import torch
     model = build_model(mm, w, device)
     spec = oracle_spec(O, w)
     params = {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
@@ -208,6 +213,32 @@ def cpu_baseline(O, spec, batch_size, budget_s=15.0):
             "sample": f"{n} training steps of batch {batch_size} (numpy fp32 oracle: fwd+bwd+Adam), {el:.1f} s"}
 
 
+def spawn_ranks(n_gpus: int) -> int:
+    """`python bench.py --gpus N` started WITHOUT a launcher: this process never touches the GPU (no torch import, no
+    HIP call); it starts N fresh worker processes - one rank per GPU, rendezvous on 127.0.0.1 - waits for them and
+    passes rank 0's JSON line through.  (Under `python -m torch.distributed.run` the ranks already exist and this
+    is never reached.)"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", MMN_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p_ in procs[1:]:
+        rc = rc or p_.wait()
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,10 +249,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="rows per GPU per step (default: the workload's batch)")
     ap.add_argument("--resident-batches", type=int, default=8)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
-    ap.add_argument("--graph", action="store_true", help="force hipGraph replay also for N>1")
     ap.add_argument("--graph-steps", type=int, default=8, help="consecutive steps captured into one hipGraph")
     ap.add_argument("--optimizer", choices=("hip", "torch"), default="hip",
-                    help="hip: multimodn_amd.optim.Adam (one k_adam launch); torch: torch.optim.Adam(fused, capturable)")
+                    help="hip: multimodn_amd.optim.Adam (fused into the step's last launch); torch: torch.optim.Adam(fused, capturable)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default, what the driver's scaling run uses): every GPU gets the workload's batch; "
                          "strong: the workload's batch is split over the GPUs (SURVEY 8e: the mode whose loss curve "
@@ -229,20 +259,28 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="testing aid: take the data-parallel code path (process group, all-reduce, separate Adam) "
                          "even with one rank")
-    ap.add_argument("--no-fused-adam", action="store_true", help="keep optimizer.step() a separate k_adam launch")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="nccl = RCCL over xGMI (the product); gloo: testing aid, the reduce buffer travels through the host")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="testing aid: every rank uses GPU 0 (RCCL refuses two ranks per device: combine with --dist-backend gloo)")
     ap.add_argument("--preroll", type=float, default=0.5, help="seconds of untimed load before the warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-public-path", action="store_true", help="skip the train_epoch-over-DeviceResidentLoader leg")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:          # plain `python bench.py --gpus N`: be our own launcher
+        raise SystemExit(spawn_ranks(args.gpus))
+
+    global torch
+    import torch
     import multimodn_amd as mm
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -251,7 +289,11 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:                  # --force-dist without a launcher
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
+        assert dist.get_world_size() == world, (dist.get_world_size(), world)
 
     wl = WORKLOADS[args.workload]
     n_enc = len(wl["F"])
@@ -260,116 +302,60 @@ def main():
         B = max(1, B // max(world, 1))                       # rows per GPU; the global batch stays the workload's
     model = build_model(mm, wl, dev)
     model.nan_policy = "device"
+    model.replay_steps = not args.no_graph
+    model.REPLAY_GROUP = max(1, args.graph_steps)
+    per_sample = bool(wl.get("per_sample"))
+    model.per_sample = per_sample
     if dp:
         model.enable_data_parallel()
     eng = model._get_engine(B)
     if args.optimizer == "hip":
-        # optimizer.step() as one k_adam launch over the flat parameter / gradient buffers
+        # optimizer.step() inside the step's last launch (single GPU) / in the launch behind the all-reduce
         opt = mm.optim.Adam(list(model.parameters()), wl["lr"])
     else:
         # torch's multi-tensor fused Adam (one block per 64K-element chunk per tensor: 15 us for the
         # 31 tensors, plus a foreach add for the step counters)
         opt = torch.optim.Adam(list(model.parameters()), wl["lr"], fused=True, capturable=True)
+    crit = torch.nn.CrossEntropyLoss()
 
     # synthetic data resident in HBM (weak scaling: every rank its own B rows per step)
     host = synthetic_batches(wl, B * args.resident_batches, B, seed=100 + rank)
     resident = []
     for xs, y in host:
         resident.append(([torch.from_numpy(x).to(dev) for x in xs], torch.from_numpy(y).to(dev)))
-    pairs = [(i, i) for i in range(n_enc)]
-    per_sample = bool(wl.get("per_sample"))
-    seqs = None
     if per_sample:
         # modality e is missing (NaN row) with probability 0.45 if y_0 = 1 else 0.15
         # (mean 0.3); every sample carries its own random permutation of the encoders
         rng = np.random.default_rng(1 + rank)
-        seqs = []
+        with_seq = []
         for xs, y in resident:
             p_miss = torch.where(y[:, :1] == 1, 0.45, 0.15).cpu().numpy()
             miss = torch.from_numpy(rng.random((B, n_enc)) < p_miss).to(dev)
             for e in range(n_enc):
                 xs[e][miss[:, e]] = float("nan")
-            seqs.append(torch.from_numpy(np.stack([rng.permutation(n_enc) for _ in range(B)]).astype(np.int64)).to(dev))
-        args.no_graph = True                                 # the regrouping uses torch ops that size-sync
-        batches, _keep_ps = [], []
-        for (xs, y), sq in zip(resident, seqs):              # (only for the per-kernel timing section below)
-            bb, kk = eng.per_sample_batch(xs, y, sq)
-            bb.batch_global = B * world
-            batches.append(bb); _keep_ps.append(kk)
-    else:
-        batches = [eng.make_batch(xs, y, pairs, batch_global=B * world, device_nan_flags=True) for xs, y in resident]
+            sq = torch.from_numpy(np.stack([rng.permutation(n_enc) for _ in range(B)]).astype(np.int64)).to(dev)
+            with_seq.append((xs, y, sq))
+        resident = with_seq
     alpha, beta = float(model.err_penalty), float(model.state_change_penalty)
 
-    fuse_opt = opt if (not dp and args.optimizer == "hip" and not args.no_fused_adam) else None
+    def steps_list(n, first=0):
+        """n consecutive mini-batches in the batch format train_epoch unpacks, cycling through the resident ones."""
+        return [resident[(first + i) % len(resident)] for i in range(n)]
 
-    def step(i):
-        if per_sample:                                       # regroup THIS batch's rows, then the usual step
-            xs, y = resident[i % len(resident)]
-            b, keep = eng.per_sample_batch(xs, y, seqs[i % len(seqs)])
-            b.batch_global = B * world
-            step.keep = keep
-        else:
-            b = batches[i % len(batches)]
-        if eng.dropout_encoders:                             # train-mode nn.Dropout: this step's multipliers, drawn on the device
-            step.masks = eng.draw_dropout_masks(b)
-        # single GPU: Adam rides in the last launch (k_reduce) of the step; N > 1: all-reduce first
-        eng.local_step(b, alpha, beta, accumulate=not dp, optimizer=fuse_opt)
-        if dp:
-            dist.all_reduce(eng.reduce_buf)                  # ONE collective per step: grads + stats
-            if args.optimizer == "hip":
-                eng.accumulate_and_step(alpha, beta, opt)    # epoch accumulation + Adam: one launch
-            else:
-                eng.accumulate(alpha, beta)
-        opt.step()                                           # no-op when the step was fused
+    class _Sized(list):
+        pass
 
-    eng.assign_grads(None)
-    eng.epoch_reset()
-    use_graph = (not args.no_graph) and (not dp or args.graph)
-    graphs = None
-    group = 1
-    for i in range(3):                                        # eager warm-up (also initialises Adam state)
-        step(i)
-    torch.cuda.synchronize()
-    if use_graph:
-        # One hipGraph holds `group` consecutive steps (each step = its own batch: prepare, fused
-        # forward+backward chain, wgrad, reduce(+Adam)); replaying it costs one host submission for
-        # `group` steps, which keeps the host ahead of a ~85 us step.
-        group = max(1, min(args.graph_steps, len(batches)))
-        while len(batches) % group:
-            group -= 1
-        try:
-            graphs = []
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for i0 in range(0, len(batches), group):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=side):
-                        for i in range(i0, i0 + group):
-                            step(i)
-                    graphs.append(g)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-        except Exception as exc:                              # pragma: no cover - depends on the box
-            print(f"[bench] hipGraph capture failed ({exc!r}); running eagerly", file=sys.stderr)
-            graphs = None
-    if graphs is None:
-        group = 1
-
-    def run_range(i0, n):
-        """Steps i0 .. i0+n-1, in order."""
-        if graphs is None:
-            for i in range(i0, i0 + n):
-                step(i)
+    def run_steps(n, first=0):
+        """n training steps through the package's own batch loop: MultiModN.train_epoch's body (look-ahead ingest,
+        pre-scan, hipGraph groups, data-parallel protocol), without the History bookkeeping of an epoch's end."""
+        if n <= 0:
             return
-        i = i0
-        while i < i0 + n:
-            if i % group == 0 and i + group <= i0 + n:
-                graphs[(i // group) % len(graphs)].replay()
-                i += group
-            else:                                             # ragged head / tail: eager single steps
-                step(i)
-                i += 1
+        if per_sample:
+            model.train_epoch(_Sized(steps_list(n, first)), opt, crit)
+        else:
+            model._train_steps(_Sized(steps_list(n, first)), opt)
+
+    group = 1 if (dp or args.no_graph or per_sample or args.optimizer != "hip") else max(1, args.graph_steps)
 
     def barrier():
         if world > 1:
@@ -379,45 +365,78 @@ def main():
     # Untimed pre-roll, before the W warm-up steps the contract asks for: the GPU leaves its idle power
     # state only after tens of milliseconds of load; without this the first timed steps of a short run
     # execute at a fraction of the clock (measured: 76 us/step steady, up to 400 us/step averaged over a
-    # cold 200-step region).
+    # cold 200-step region).  It runs the very step lists that are timed below, so their hipGraph groups are
+    # captured here (second sighting) and the timed region only replays.
+    run_steps(args.warmup)
+    run_steps(args.steps, args.warmup)
+    torch.cuda.synchronize()
     t_ramp = time.perf_counter()
     while True:
         go = time.perf_counter() - t_ramp < args.preroll
         if dp:                                               # every rank must run the same number of collectives:
-            flag = torch.tensor([1 if go else 0], device=dev)    # rank 0's clock decides
+            flag = torch.tensor([1 if go else 0], device=dev if args.dist_backend == "nccl" else "cpu")    # rank 0's clock decides
             dist.broadcast(flag, src=0)
             go = bool(flag.item())
         if not go:
             break
-        run_range(0, group * 8)
+        run_steps(args.steps, args.warmup)
         torch.cuda.synchronize()
-    run_range(0, args.warmup)
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    start = -(-args.warmup // group) * group              # timed steps start on a graph boundary
-    run_range(start, args.steps)
+    run_steps(args.steps, args.warmup)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
+    replayed = bool(getattr(eng, "_graph_hits", 0))
 
     # distribution of the step time: HIP events around groups of `group` steps
     dist_us = None
     if world == 1 and not dp:
         samples = []
+        n_ev = max(group, 8)
+        run_steps(n_ev)
+        run_steps(n_ev)
         for rep_i in range(40):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            run_range(start + rep_i * group, group)
+            run_steps(n_ev)
             e1.record()
             torch.cuda.synchronize()
-            samples.append(e0.elapsed_time(e1) * 1e3 / group)
+            samples.append(e0.elapsed_time(e1) * 1e3 / n_ev)
         dist_us = {"median": float(np.median(samples)), "p10": float(np.percentile(samples, 10)),
-                   "p90": float(np.percentile(samples, 90)), "groups": len(samples), "steps_per_group": group}
+                   "p90": float(np.percentile(samples, 90)), "groups": len(samples), "steps_per_group": n_ev}
+
+    # ---- the public entry point itself: MultiModN.train_epoch over a DeviceResidentLoader, History
+    #      appended every epoch.  Same step code as `value`; what it adds is the epoch's end (one readback of the epoch
+    #      accumulators, the History arrays).
+    public = None
+    if world == 1 and not dp and not per_sample and not args.no_public_path:
+        nb_pub = 64
+        rows = []
+        for i in range(nb_pub):
+            rows.append(resident[i % len(resident)])
+        ds = ([torch.cat([r[0][k] for r in rows], 0) for k in range(n_enc)], torch.cat([r[1] for r in rows], 0))
+        loader = mm.DeviceResidentLoader(ds, batch_size=B, device=dev)
+        hist = mm.MultiModNHistory([f"t{d}" for d in range(wl["D"])])
+        for _ in range(3):                                   # eager sighting, capture, first replay
+            model.train_epoch(loader, opt, crit, hist)
+        torch.cuda.synchronize()
+        n_ep = 4
+        t_p = time.perf_counter()
+        for _ in range(n_ep):
+            model.train_epoch(loader, opt, crit, hist)
+        torch.cuda.synchronize()
+        el_p = time.perf_counter() - t_p
+        public = {"entry_point": "MultiModN.train_epoch(DeviceResidentLoader, multimodn_amd.optim.Adam, CrossEntropyLoss, History)",
+                  "value": B * nb_pub * n_ep / el_p, "unit": "samples/s", "us_per_step": el_p / (nb_pub * n_ep) * 1e6,
+                  "epochs": n_ep, "steps_per_epoch": nb_pub, "ratio_to_value": (B * nb_pub * n_ep / el_p) / value}
+        del loader, ds
 
     # ---- per-kernel durations with HIP events on the launch stream.  Each kernel of the step is
     # launched REP times back to back between one event pair (same stream the step uses), so the
@@ -425,25 +444,40 @@ def main():
     # rocprofv3 --kernel-trace averages of the same command are committed under profiles/.
     lib, plan, C = eng.lib, eng._plan, __import__("ctypes")
     stream = torch.cuda.current_stream().cuda_stream
+    pairs = [(i, i) for i in range(n_enc)]
+    eng.begin_sequence()
+    if per_sample:
+        batches, _keep_ps = [], []
+        for xs, y, sq in resident:
+            bb, kk = eng.per_sample_batch(xs, y, sq)
+            bb.batch_global = B * world
+            batches.append(bb); _keep_ps.append(kk)
+    else:
+        batches = [eng.make_batch(xs, y, pairs, batch_global=B * world, device_nan_flags=True) for xs, y in resident]
+    plan = eng._plan                                          # (per-sample batches may have re-planned)
     b0 = batches[0]
     fwd_name = lib.mmn_chain_kernel_name(plan, C.byref(b0), 0).decode()
     bwd_name = lib.mmn_chain_kernel_name(plan, C.byref(b0), 1).decode()
     fused_name = lib.mmn_chain_kernel_name(plan, C.byref(b0), 2).decode()
-    kern = {"k_prepare": lambda b: lib.mmn_prepare(plan, C.byref(b), 1, stream)}
+    # k_prepare (NaN scan + repack of the weights) is NOT part of a steady-state step any more: the scan of batch t+1
+    # rides in step t's k_reduce, the repack is replaced by the Adam tail's scatter.  Timed here as what the first step
+    # of an epoch still pays.
+    kern = {"k_prepare(first step of an epoch only)": lambda b: lib.mmn_prepare(plan, C.byref(b), 1, stream)}
     if fused_name:        # forward + backward chain in one launch (what mmn_train_step uses)
         kern[fused_name] = lambda b: lib.mmn_chain_fwd_bwd(plan, C.byref(b), alpha, beta, stream)
     else:
         kern[fwd_name] = lambda b: lib.mmn_chain_fwd(plan, C.byref(b), alpha, beta, 1, stream)
         kern[bwd_name] = lambda b: lib.mmn_chain_bwd(plan, C.byref(b), beta, stream)
     kern["k_wgrad"] = lambda b: lib.mmn_wgrad(plan, C.byref(b), stream)
+    fuse_opt = opt if (not dp and args.optimizer == "hip") else None
     if args.optimizer == "hip":
-        adam_desc = opt.descriptor(opt._runs[0][0], opt.param_groups[0])   # the launch opt.step() makes
-    if fuse_opt is not None:
-        kern["k_reduce"] = lambda b: lib.mmn_reduce_adam(plan, C.byref(b), C.byref(adam_desc), stream)   # + Adam
+        adam_desc = opt.fused_descriptor(eng)
+    if fuse_opt is not None and adam_desc is not None:
+        kern["k_reduce"] = lambda b: lib.mmn_reduce_adam(plan, C.byref(b), C.byref(adam_desc), stream)   # + Adam + scatter
     else:
         kern["k_reduce"] = lambda b: lib.mmn_reduce(plan, C.byref(b), stream)
-        if args.optimizer == "hip":
-            kern["k_adam"] = lambda b: lib.mmn_adam_step(C.byref(adam_desc), stream)
+        if args.optimizer == "hip" and adam_desc is not None:
+            kern["k_adam_accumulate"] = lambda b: lib.mmn_adam_step_accumulate(plan, C.byref(adam_desc), alpha, beta, stream)
     REP, ROUNDS = 20, 5
     avg_us = {}
     for name, fn in kern.items():
@@ -451,7 +485,7 @@ def main():
         for rnd in range(ROUNDS):
             b = batches[rnd % len(batches)]
             if eng.dropout_encoders:
-                step.masks = eng.draw_dropout_masks(b)
+                _m = eng.draw_dropout_masks(b)
             eng.local_step(b, alpha, beta, accumulate=False)        # valid inputs for every kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -468,37 +502,48 @@ def main():
         fl = {fwd_name: flp["k_chain_fwd"], bwd_name: flp["k_chain_bwd"], "k_wgrad": flp["k_wgrad"]}
     dominant = max(fl, key=lambda k: avg_us[k])
     achieved = fl[dominant] * B / (avg_us[dominant] * 1e-6) / 1e12
-    traffic = None
-    try:                                                      # HBM bytes per launch from the committed PMC passes
-        pmc_file = {"c3": "r01_final_pmc_traffic.json", "mimic": "r01_mimic_pmc_traffic.json"}.get(args.workload)
-        if pmc_file and B == wl["B"]:                        # the passes were made on this workload at this batch
-            pmc = json.load(open(os.path.join(REPO, "profiles", pmc_file)))
+    traffic, mfma_busy = None, None
+    try:                                                      # HBM bytes per launch / matrix-pipe busy % from the committed PMC passes
+        tag = {"c3": "r02_final", "mimic": "r02_mimic"}.get(args.workload)
+        if tag and B == wl["B"]:                             # the passes were made on this workload at this batch
+            pmc = json.load(open(os.path.join(REPO, "profiles", f"{tag}_pmc_traffic.json")))
             traffic = pmc["kernels"].get(dominant, {}).get("hbm_bytes_per_launch")
+            util = json.load(open(os.path.join(REPO, "profiles", f"{tag}_pmc_util.json")))
+            mfma_busy = util["kernels"].get(dominant, {}).get("mfma_busy_pct")
     except Exception:
-        traffic = None
+        pass
     roofline = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                "traffic_note": "HBM bytes per launch of the dominant kernel = (2*FETCH_SIZE + WRITE_SIZE)*1024 from "
-                                "profiles/r01_final_pmc_traffic.json (mimic workload: r01_mimic_pmc_traffic.json), "
-                                "separate rocprofv3 --pmc passes",
+                "mfma_busy_pct_pmc": mfma_busy,
+                "traffic_note": "HBM bytes per launch of the dominant kernel = (2*FETCH_SIZE + WRITE_SIZE)*1024 and its "
+                                "SQ_VALU_MFMA_BUSY_CYCLES share from profiles/r02_final_pmc_traffic.json / _pmc_util.json "
+                                "(mimic workload: r02_mimic_*), separate rocprofv3 --pmc passes",
                 "avg_launch_us": avg_us, "flops_per_sample": fl,
                 "algorithmic_flops_per_launch": fl[dominant] * B,
                 "step_frac_of_fp32_roof": value / world * sum(fl.values()) / (FP32_MFMA_PEAK_TFLOPS * 1e12),
                 "hbm_frac_of_peak": (traffic / (avg_us[dominant] * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None}
 
+    if args.optimizer != "hip":
+        opt_text = "torch.optim.Adam(fused, capturable)"
+    elif dp:
+        opt_text = "multimodn_amd.optim.Adam in the launch behind the all-reduce (k_adam_accumulate)"
+    else:
+        opt_text = "multimodn_amd.optim.Adam fused into k_reduce"
     out = {
         "metric": "samples/sec/GPU (MIMIC 4-enc/3-dec, state_dim=128) + CPU-match Δloss",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["text"] if B == wl["B"] else wl["text"] + f" [rows per GPU: {B}]",
-                   "optimizer": ("multimodn_amd.optim.Adam fused into k_reduce" if fuse_opt is not None else
-                                 "multimodn_amd.optim.Adam (k_adam)") if args.optimizer == "hip" else "torch.optim.Adam(fused, capturable)",
+                   "optimizer": opt_text,
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                   "launch": f"hipGraph replay ({group} steps per graph)" if graphs is not None else "eager",
+                   "step_path": "MultiModN._train_steps (the batch loop of MultiModN.train_epoch)",
+                   "launch": f"hipGraph replay ({group} steps per graph)" if replayed else "eager",
+                   "collectives_per_step": 1 if dp else 0,
                    "samples_per_sec_per_gpu": value / world},
         "roofline": roofline,
         "step_us_hip_events": dist_us,
+        "public_path": public,
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         from oracle import multimodn_oracle as O      # the CPU oracle: imported for this leg ONLY, never measured as `value`

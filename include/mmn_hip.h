@@ -40,11 +40,13 @@
 extern "C" {
 #endif
 
-#define MMN_VERSION 103            /* 0.1.3: + mmn_draw_dropout; 0.1.2: MIMIC_MLPEncoder / MLPDecoder (mmn_encoder.kind, mmn_decoder.hidden, mmn_batch.drop_mask) */
+#define MMN_VERSION 104            /* 0.1.4: mmn_train_step_ex (pre-scan of the next batch, flag sets in the stats block), mmn_pack_invalidate;
+                                      0.1.3: + mmn_draw_dropout; 0.1.2: MIMIC_MLPEncoder / MLPDecoder (mmn_encoder.kind, mmn_decoder.hidden, mmn_batch.drop_mask) */
 #define MMN_MAX_ENCODERS 16
 #define MMN_MAX_DECODERS 8
 #define MMN_MAX_LAYERS 8           /* hidden layers + the state-update Linear */
-#define MMN_MAX_DIM 256            /* state_size and every hidden width; n_features is unbounded */
+#define MMN_MAX_DIM 128            /* state_size and every hidden width (what the LDS carve of the chain kernels admits; wider
+                                      models get MMN_ERR_UNSUPPORTED); n_features is unbounded */
 #define MMN_MAX_DEC_HIDDEN 3       /* hidden layers of an MLPDecoder */
 
 /* activation of MLPEncoder hidden layers (multimodn/encoders/mlp_encoder.py:56,75-76) */
@@ -126,6 +128,8 @@ typedef struct mmn_model {
  * slot seq_data[t] to encoder seq_enc[t].  nan_flags (optional, device, one int per DATA SLOT, as
  * written by mmn_nan_scan): nonzero = that slot's batch contained a NaN, skip its encoder
  * (multimodn.py:168-169).  NULL = the caller already removed skipped slots from the sequence.
+ * flags_ready != 0: nan_flags already hold this batch's decision (an earlier step pre-scanned it, see
+ * mmn_step_opts.next; with data parallel the flag sets have been through the all-reduce): the step does not scan.
  * batch_global: divisor of every batch mean; > batch for a data-parallel shard. */
 typedef struct mmn_batch {
     const float* x[MMN_MAX_ENCODERS];
@@ -135,7 +139,7 @@ typedef struct mmn_batch {
     int32_t batch;
     int32_t batch_global;
     int32_t n_seq;
-    int32_t reserved;
+    int32_t flags_ready;
     int32_t seq_data[MMN_MAX_ENCODERS];
     int32_t seq_enc[MMN_MAX_ENCODERS];
     /* Per-sample mode (BASELINE.json configs[4]: per-sample missing modalities and per-sample
@@ -168,7 +172,11 @@ typedef struct mmn_batch {
  *   then R                   rows executed this step: batch rows if the state row was produced
  *                            (n_samples_epoch increments, multimodn.py:121,171)
  *   then 4                   loss, global_err_loss, global_state_change, reserved
- *                            (multimodn.py:194-202; filled by mmn_epoch_accumulate) */
+ *                            (multimodn.py:194-202; filled by mmn_epoch_accumulate)
+ *   then 2 * MMN_MAX_ENCODERS   the two NaN-flag sets (mmn_nan_flags_set): one word per data slot, 0 = no NaN, the
+ *                            float 1.0 = NaN found.  They live here so that a data-parallel caller's ONE all-reduce of
+ *                            [grads | stats] also carries the pre-scanned flags of the next batch (the per-rank flags
+ *                            are summed; any non-zero word means "some rank saw a NaN": multimodn.py:168 on the GLOBAL batch). */
 size_t mmn_stats_floats(const mmn_model* m);
 
 typedef struct mmn_plan mmn_plan;   /* opaque host handle */
@@ -187,9 +195,22 @@ int mmn_plan_create(const mmn_model* m, int max_batch, void* workspace, size_t w
                     float* stats, mmn_plan** out);
 void mmn_plan_destroy(mmn_plan* p);
 
-/* Plan-owned NaN flags (device, MMN_MAX_ENCODERS ints, zero after plan creation).  Put this
- * pointer into mmn_batch.nan_flags to keep the NaN-skip decision on the device. */
+/* Plan-owned NaN flags (device, MMN_MAX_ENCODERS words, zero after plan creation; inside the stats block).  Put this
+ * pointer into mmn_batch.nan_flags to keep the NaN-skip decision on the device.  There are TWO sets (which = 0, 1;
+ * mmn_nan_flags = set 0) so that one step can consume one set while it pre-scans the next batch into the other. */
 int32_t* mmn_nan_flags(mmn_plan* p);
+int32_t* mmn_nan_flags_set(mmn_plan* p, int which);
+
+/* The chain kernels read the weights from fragment-order copies inside the workspace.  The library rebuilds them
+ * (k_prepare) in the first step after mmn_plan_create, after every training step that does not apply the optimizer
+ * itself (mmn_train_step: somebody else's optimizer is about to change the parameters) and after mmn_pack_invalidate();
+ * a step with the fused Adam tail (mmn_train_step_adam, mmn_adam_step_accumulate) writes every parameter it updates
+ * straight into its copies, so that no repack launch sits in front of the next step.  Call mmn_pack_invalidate whenever
+ * anything but the library writes the parameters (load_state_dict, a foreign optimizer, manual edits). */
+void mmn_pack_invalidate(mmn_plan* p);
+/* Rebuild the copies now (one launch) if they are stale; afterwards they are current.  For callers that capture steps
+ * into a hipGraph: a captured step must not depend on whether a repack was due at capture time. */
+int mmn_pack_refresh(mmn_plan* p, void* stream);
 
 /* Per-step preparation, one launch: (a) if b->nan_flags != NULL, multimodn.py:168:
  * nan_flags[k] = 1 iff any element of data slot k is NaN, for the slots the sequence names (flags
@@ -238,6 +259,21 @@ int mmn_epoch_accumulate(mmn_plan* p, float err_penalty, float state_change_pena
  * launch (single-GPU); pass 0 when an all-reduce of [grads | stats] must happen first. */
 int mmn_train_step(mmn_plan* p, const mmn_batch* b, float err_penalty, float state_change_penalty_x001,
                    int accumulate_epoch, void* stream);
+
+/* mmn_train_step / mmn_train_step_adam with the extras that take k_prepare off the critical path:
+ *   adam   (may be NULL) as in mmn_train_step_adam;
+ *   next   (may be NULL) the batch the NEXT call will run: its NaN scan (multimodn.py:168) rides in THIS step's last
+ *          launch and writes next->nan_flags, which must be the flag set this step does not use.  The next call then
+ *          passes the same batch with flags_ready = 1.  Data parallel: all-reduce [grads | stats] in between - the flag
+ *          sets are part of the stats block.  Ignored for per-sample batches and when next->nan_flags is NULL. */
+typedef struct mmn_step_opts {
+    const struct mmn_adam* adam;
+    const mmn_batch* next;
+    int32_t accumulate_epoch;
+    int32_t reserved;
+} mmn_step_opts;
+int mmn_train_step_ex(mmn_plan* p, const mmn_batch* b, float err_penalty, float state_change_penalty_x001,
+                      const mmn_step_opts* opts, void* stream);
 
 /* Per-sample mode helper: regroup the rows of an ordinary batch, ON THE DEVICE, into the tile layout
  * mmn_batch.tile_rows / tile_seq describe (three launches, deterministic).
@@ -301,6 +337,8 @@ int mmn_adam_step_accumulate(mmn_plan* p, const mmn_adam* d, float err_penalty, 
  * synchronously: make it outside stream capture.  mmn_reduce_adam is the last launch alone. */
 int mmn_train_step_adam(mmn_plan* p, const mmn_batch* b, float err_penalty, float state_change_penalty_x001,
                         int accumulate_epoch, const mmn_adam* adam, void* stream);
+/* The layout check alone: MMN_OK if `adam` can be fused with this plan's launches, else MMN_ERR_UNSUPPORTED / MMN_ERR_ARG. */
+int mmn_adam_fusable(mmn_plan* p, const mmn_adam* adam);
 int mmn_reduce_adam(mmn_plan* p, const mmn_batch* b, const mmn_adam* adam, void* stream);
 
 /* nn.Dropout of the MIMIC_MLPEncoders (mlp_encoder.py:34,41) as ONE launch (k_dropout): draws the multipliers of every
@@ -324,6 +362,8 @@ int mmn_dropout_reset(mmn_plan* p, void* stream);
 size_t mmn_epoch_doubles(const mmn_model* m);
 int mmn_epoch_reset(mmn_plan* p, void* stream);
 int mmn_epoch_read(mmn_plan* p, double* out_host, void* stream);
+/* the inverse (same layout; synchronises): carries an epoch's sums over to a new plan when the workspace had to grow */
+int mmn_epoch_write(mmn_plan* p, const double* in_host, void* stream);
 
 /* Device pointers (into the workspace) to what the last step left behind; the forward-only
  * consumers test() / predict() / get_states() (multimodn.py:255-492) read them, parity tests too.

@@ -96,6 +96,7 @@ class DeviceResidentLoader:
             self.targets = self.targets.view(-1, 1)
         self.sequence = None if seq is None else seq.to(self.device, dtype=torch.int64).contiguous()
         self.n = int(self.targets.shape[0])
+        self._views = None                                   # unshuffled: the batches are the same views every epoch
 
     @staticmethod
     def _materialise(dataset):
@@ -129,6 +130,20 @@ class DeviceResidentLoader:
 
     def __iter__(self):
         perm = None
+        if not self.shuffle:
+            # the SAME tuple objects every epoch: train_epoch recognises them and skips re-deriving what it derived from
+            # their addresses last time (MultiModN._train_steps)
+            if self._views is None:
+                views = []
+                for i in range(len(self)):
+                    lo, hi = i * self.batch_size, min(self.n, (i + 1) * self.batch_size)
+                    item = [[d[lo:hi] for d in self.data], self.targets[lo:hi]]
+                    if self.sequence is not None:
+                        item.append(self.sequence[lo:hi])
+                    views.append(tuple(item))
+                self._views = views
+            yield from self._views
+            return
         if self.shuffle:
             g = self.generator
             perm = (torch.randperm(self.n, generator=g) if g is not None else torch.randperm(self.n)).to(self.device)

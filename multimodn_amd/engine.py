@@ -189,7 +189,13 @@ class HipChainEngine:
         hip.check(lib.mmn_plan_create(C.byref(m), self.max_batch, self._ws_ptr, ws_bytes,
                                       self.stats.data_ptr(), C.byref(plan)), "mmn_plan_create")
         self._plan = plan
-        self._nan_flags_ptr = lib.mmn_nan_flags(plan)      # plan-owned device flags
+        # plan-owned NaN flags: TWO sets at the end of the stats block.  Batches that carry device flags take them in
+        # turn, so that a step can consume one set while its last launch pre-scans the next batch into the other.
+        self._flag_sets = [lib.mmn_nan_flags_set(plan, 0), lib.mmn_nan_flags_set(plan, 1)]
+        self._nan_flags_ptr = self._flag_sets[0]
+        self.flag_tail = self.stats[self.n_stats - 2 * hip.MAX_ENCODERS:]     # both sets, as the floats the all-reduce sums
+        self._flag_turn = 0
+        self._prescanned: Optional[hip.Batch] = None       # the batch whose flags the last step's pre-scan left behind
         self.n_epoch = int(lib.mmn_epoch_doubles(C.byref(m)))
         self._sig = tuple(p.data_ptr() for p in self.params)
         self.E, self.D, self.S = m.n_encoders, m.n_decoders, m.state_size
@@ -200,7 +206,8 @@ class HipChainEngine:
                                                           else 0.0 for enc in model.encoders])
         self._drop_buf = None
         self._drop_seed = None
-        self._step_graphs: Dict[tuple, list] = {}             # replayable_train_step: key -> [sightings, graph, keep-alive]
+        self._step_graphs: Dict[tuple, list] = {}             # run_group: key -> [sightings, graph, keep-alive]
+        self._graph_hits = 0
 
     def __del__(self):
         try:
@@ -210,15 +217,25 @@ class HipChainEngine:
         except Exception:
             pass
 
-    def ensure(self, batch: int) -> None:
-        """Re-plan if the batch outgrew the workspace or the parameters moved (model.to(), ...)."""
+    def ensure(self, batch: int) -> bool:
+        """Re-plan if the batch outgrew the workspace or the parameters moved (model.to(), ...).  Returns True if it
+        did: hip.Batch structs made before hold pointers into the old plan."""
         moved = tuple(p.data_ptr() for p in self.params) != self._sig
         if moved:
             self._flatten_params()
         if moved or batch > self.max_batch:
+            # a new plan starts with empty epoch accumulators: carry the running epoch's sums over (a batch larger than
+            # every earlier one may arrive in the middle of an epoch: variable batch samplers, per-sample mode)
+            carried = np.zeros(self.n_epoch, np.float64)
+            hip.check(self.lib.mmn_epoch_read(self._plan, carried.ctypes.data_as(C.POINTER(C.c_double)), self._stream()),
+                      "mmn_epoch_read")
             self.lib.mmn_plan_destroy(self._plan)
             self._plan = None
             self._build(max(batch, self.max_batch))
+            hip.check(self.lib.mmn_epoch_write(self._plan, carried.ctypes.data_as(C.POINTER(C.c_double)), self._stream()),
+                      "mmn_epoch_write")
+            return True
+        return False
 
     # ------------------------------------------------------------------ per-step
     @staticmethod
@@ -229,24 +246,39 @@ class HipChainEngine:
                    batch_global: Optional[int] = None, device_nan_flags: bool = False) -> hip.Batch:
         """xs / y must be device tensors (float32 / int64).  The returned struct holds raw
         pointers: the caller keeps xs / y alive until the step's launches have run."""
-        b = hip.Batch()
-        B = int(y.shape[0])
-        for k, x in enumerate(xs):
-            if x.dtype != torch.float32 or x.device != self.device or x.dim() != 2 or x.stride(1) != 1:
-                raise ValueError(f"data slot {k}: expected a float32 [B, F] tensor on {self.device} with unit inner stride")
-            b.x[k] = x.data_ptr()
-            b.ldx[k] = x.stride(0)
-        if y.dtype != torch.int64 or not y.is_contiguous() or y.device != self.device:
-            raise ValueError("targets must be a contiguous int64 [B, D] tensor on the model's device")
-        b.y = y.data_ptr()
-        b.nan_flags = self._nan_flags_ptr if device_nan_flags else None
-        b.batch = B
-        b.batch_global = int(batch_global) if batch_global else B
-        b.n_seq = len(pairs)
-        for t, (k, e) in enumerate(pairs):
-            b.seq_data[t] = k
-            b.seq_enc[t] = e
-        return b
+        return self.make_batch_keyed(xs, y, pairs, batch_global, device_nan_flags)[0]
+
+    def make_batch_keyed(self, xs, y, pairs, batch_global=None, device_nan_flags: bool = False, template=None):
+        """make_batch plus what recurring batches are recognised by: returns (struct, key, template).  `key` names the
+        buffers, the sequence and the flag set (run_group's cache key is made of these); `template` = (filled-in struct
+        without flags, key without flags) can be handed back in for the same tensors next time: filling the ctypes
+        arrays field by field costs more host time than a small step's launches."""
+        if template is None:
+            B = int(y.shape[0])
+            bg = int(batch_global) if batch_global else B
+            tmpl = hip.Batch()
+            for k, x in enumerate(xs):
+                if x.dtype != torch.float32 or x.device != self.device or x.dim() != 2 or x.stride(1) != 1:
+                    raise ValueError(f"data slot {k}: expected a float32 [B, F] tensor on {self.device} with unit inner stride")
+                tmpl.x[k] = x.data_ptr()
+                tmpl.ldx[k] = x.stride(0)
+            if y.dtype != torch.int64 or not y.is_contiguous() or y.device != self.device:
+                raise ValueError("targets must be a contiguous int64 [B, D] tensor on the model's device")
+            tmpl.y = y.data_ptr()
+            tmpl.batch = B
+            tmpl.batch_global = bg
+            tmpl.n_seq = len(pairs)
+            for t, (k, e) in enumerate(pairs):
+                tmpl.seq_data[t] = k
+                tmpl.seq_enc[t] = e
+            base = (tuple(tmpl.x[k] for k in range(len(xs))), tuple(tmpl.ldx[k] for k in range(len(xs))), tmpl.y, B,
+                    tuple(pairs), bg)
+            template = (tmpl, base)
+        b = hip.Batch.from_buffer_copy(template[0])
+        if device_nan_flags:                                # the two flag sets alternate in the order batches are made
+            b.nan_flags = self._flag_sets[self._flag_turn]
+            self._flag_turn ^= 1
+        return b, template[1] + (b.nan_flags,), template
 
     def draw_dropout_masks(self, b: hip.Batch, provider=None) -> List[torch.Tensor]:
         """Training-mode nn.Dropout of the MIMIC encoders (mlp_encoder.py:34,41): one [batch, F_e + S]
@@ -298,80 +330,130 @@ class HipChainEngine:
         """Restart the dropout generator's draw index (same seed -> same multipliers again)."""
         hip.check(self.lib.mmn_dropout_reset(self._plan, self._stream()), "mmn_dropout_reset")
 
+    def begin_sequence(self) -> None:
+        """Start of an epoch / an entry point: the flag sets are handed out from set 0 again (so that a replayed group of
+        steps meets the sets it was captured with), no pre-scan is carried over, and the chain kernels' copies of the
+        weights are rebuilt by the first step (anything may have written the parameters since the last call:
+        load_state_dict, another optimizer, the user)."""
+        self._flag_turn = 0
+        self._prescanned = None
+        self.lib.mmn_pack_invalidate(self._plan)
+
     def local_step(self, b: hip.Batch, err_penalty: float, sc_penalty_x001: float, accumulate: bool = False,
-                   optimizer=None) -> bool:
-        """prepare (NaN scan when the batch carries device flags, weight transposes) + fwd + bwd +
-        wgrad + reduce: afterwards reduce_buf = [grads | stats] holds this rank's sums (already
-        divided by batch_global).  accumulate=True also folds the loss combination / epoch
-        accumulation into the last launch (single-GPU).
+                   optimizer=None, next_batch: Optional[hip.Batch] = None, desc=None) -> bool:
+        """[prepare: NaN scan when the batch carries device flags nobody pre-scanned; repack of the weights when the
+        copies are stale] + fwd + bwd + wgrad + reduce: afterwards reduce_buf = [grads | stats] holds this rank's sums
+        (already divided by batch_global).  accumulate=True also folds the loss combination / epoch accumulation into
+        the last launch (single-GPU).
 
         optimizer: a multimodn_amd.optim.Adam over exactly this model's parameters; its step is
         then fused behind the gradient sum in the last launch (single GPU only: with data parallel
         the all-reduce has to come first).  Returns True if the optimizer step was applied by this
-        call (the optimizer's next .step() is then a no-op), False if the caller still has to step."""
+        call (the optimizer's next .step() is then a no-op), False if the caller still has to step.
+
+        next_batch: the batch the NEXT call will run (made right after `b`, so that it holds the other flag set): its NaN
+        scan rides in this step's last launch, and the next call finds its flags ready.
+        desc: optimizer.fused_descriptor(self), when the caller already has it (it walks every parameter)."""
+        if self._launch_step(b, err_penalty, sc_penalty_x001, accumulate, optimizer, next_batch, desc):
+            optimizer.mark_fused_step()
+            return True
+        return False
+
+    def _launch_step(self, b, err_penalty, sc_penalty_x001, accumulate, optimizer, next_batch, desc=None) -> bool:
+        b.flags_ready = 1 if (b.nan_flags and self._prescanned is b) else 0
+        o = hip.StepOpts()
+        o.accumulate_epoch = 1 if accumulate else 0
+        if next_batch is not None:
+            o.next = C.pointer(next_batch)
+        pre = next_batch if (next_batch is not None and next_batch.nan_flags and b.nan_flags
+                             and next_batch.nan_flags != b.nan_flags and not next_batch.tile_seq) else None
         if optimizer is not None:
-            d = optimizer.fused_descriptor(self)
+            d = desc if desc is not None else optimizer.fused_descriptor(self)
             if d is not None:
-                rc = self.lib.mmn_train_step_adam(self._plan, C.byref(b), err_penalty, sc_penalty_x001,
-                                                  1 if accumulate else 0, C.byref(d), self._stream())
+                o.adam = C.pointer(d)
+                rc = self.lib.mmn_train_step_ex(self._plan, C.byref(b), err_penalty, sc_penalty_x001, C.byref(o), self._stream())
                 if rc == 0:
-                    optimizer.mark_fused_step()
+                    self._prescanned = pre
                     return True
                 if rc != hip.ERR_UNSUPPORTED:
-                    hip.check(rc, "mmn_train_step_adam")
+                    hip.check(rc, "mmn_train_step_ex")
                 optimizer.fusion_refused(self)
-        hip.check(self.lib.mmn_train_step(self._plan, C.byref(b), err_penalty, sc_penalty_x001,
-                                          1 if accumulate else 0, self._stream()), "mmn_train_step")
+                o.adam = None
+        hip.check(self.lib.mmn_train_step_ex(self._plan, C.byref(b), err_penalty, sc_penalty_x001, C.byref(o), self._stream()),
+                  "mmn_train_step_ex")
+        self._prescanned = pre
         return False
 
     # ------------------------------------------------------------------ whole steps as replayable hipGraphs
     MAX_STEP_GRAPHS = 64
 
-    def replayable_train_step(self, xs, y, pairs, batch_global, err_penalty: float, sc_penalty_x001: float, optimizer,
-                              draw_dropout: bool) -> bool:
-        """One training step (device NaN policy, Adam fused) for a batch whose device buffers this engine has seen
-        before: the step - k_dropout, k_prepare, chain, k_wgrad, k_reduce+Adam - is captured into a hipGraph on its
-        second sighting and replayed from then on (ONE host submission instead of 4-5 launches; at the reference
-        pipelines' batch sizes of 16-32 rows the step is host-bound otherwise).  Loaders hand the same device buffers
-        back every epoch (DeviceResidentLoader views, the staging ring of host batches), so this pays from the second
-        epoch on.  Everything a replay must see fresh lives in device memory (Adam step counters, epoch accumulators,
-        NaN flags, the dropout draw index); what is baked into the graph is in the key (buffers, sequence,
-        hyper-parameters, dropout seed).  Returns False when the step cannot be cached: the caller runs it eagerly."""
-        d = optimizer.fused_descriptor(self) if hasattr(optimizer, "fused_descriptor") else None
-        if d is None or torch.cuda.is_current_stream_capturing():
+    def run_group(self, steps, nxt, err_penalty: float, sc_penalty_x001: float, optimizer, draw_dropout: bool,
+                  desc=None) -> bool:
+        """`steps`: consecutive training steps (device NaN policy, Adam fused) as (xs, y, pairs, batch_global, hip.Batch,
+        key) tuples (make_batch_keyed) whose device buffers this engine may have seen before; `nxt`: the step after them (or None) - the last
+        step of the group pre-scans its batch.  The group - per step k_dropout, [k_prepare scan], chain, k_wgrad,
+        k_reduce + Adam - is captured into ONE hipGraph on its second sighting and replayed from then on: one host
+        submission for len(steps) steps.  Loaders hand the same device buffers back every epoch (DeviceResidentLoader
+        views, the staging ring of host batches), so this pays from the second epoch on; at the reference pipelines'
+        batch sizes of 16-32 rows the step is host-bound otherwise.  Everything a replay must see fresh lives in device
+        memory (Adam step counters, epoch accumulators, NaN flags, the dropout draw index); what is baked into the
+        graph is in the key: buffers, flag sets, sequences, hyper-parameters, dropout seed, the optimizer's buffers,
+        whether the first batch arrives pre-scanned.  Returns False when the group cannot be replayed: the caller runs
+        its steps eagerly (which is also the warm-up before the capture)."""
+        d = desc if desc is not None else (optimizer.fused_descriptor(self) if hasattr(optimizer, "fused_descriptor") else None)
+        if d is None or torch.cuda.is_current_stream_capturing() or self._step_graphs is None:
             return False
         seed = ((int(torch.initial_seed()) ^ (int(getattr(self, "dropout_salt", 0)) * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF) \
             if draw_dropout else 0
         if draw_dropout and seed != self._drop_seed:            # a new seed restarts the draw index: do that eagerly
             return False
-        key = (tuple(x.data_ptr() for x in xs), tuple(int(x.stride(0)) for x in xs), y.data_ptr(), int(y.shape[0]),
-               tuple(pairs), int(batch_global), float(err_penalty), float(sc_penalty_x001), seed,
+        first = steps[0][4]
+        entry_ready = bool(first.nan_flags and self._prescanned is first)
+        key = (tuple(st[5] for st in steps), None if nxt is None else nxt[5], entry_ready,
+               float(err_penalty), float(sc_penalty_x001), seed,
+               id(optimizer), d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.steps, d.seg_start,
                d.lr, d.beta1, d.beta2, d.eps, d.weight_decay, d.maximize)
         ent = self._step_graphs.get(key)
         if ent is None:
-            if len(self._step_graphs) >= self.MAX_STEP_GRAPHS:  # e.g. an LR scheduler changed the baked hyper-parameters:
-                self._step_graphs.clear()                       # start over with the current ones
-            self._step_graphs[key] = [1, None, None]            # first sighting: the caller's eager step is the warm-up
+            if len(self._step_graphs) >= self.MAX_STEP_GRAPHS:
+                if self._graph_hits == 0:                       # buffers that never come back (shuffled device batches, ...):
+                    self._step_graphs = None                    # stop looking
+                    return False
+                self._step_graphs.clear()                       # e.g. an LR scheduler changed the baked hyper-parameters:
+                self._graph_hits = 0                            # start over with the current ones
+            self._step_graphs[key] = [1, None, None]            # first sighting: the caller's eager steps are the warm-up
             return False
         if ent[1] is None:
             if ent[0] < 0:                                      # capture failed earlier for this key
                 return False
             try:
-                b = self.make_batch(xs, y, pairs, batch_global=batch_global, device_nan_flags=True)
+                hip.check(self.lib.mmn_pack_refresh(self._plan, self._stream()), "mmn_pack_refresh")
                 side = torch.cuda.Stream(device=self.device)
                 side.wait_stream(torch.cuda.current_stream())
                 graph = torch.cuda.CUDAGraph()
+                keep = []
+                saved = self._prescanned
                 with torch.cuda.stream(side):
-                    with torch.cuda.graph(graph, stream=side):
-                        keep = self.draw_dropout_masks(b) if draw_dropout else None
-                        hip.check(self.lib.mmn_train_step_adam(self._plan, C.byref(b), err_penalty, sc_penalty_x001, 1,
-                                                               C.byref(d), side.cuda_stream), "mmn_train_step_adam")
+                    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                        for i, (xs, y, pairs, bg, b, _k) in enumerate(steps):
+                            nb = steps[i + 1][4] if i + 1 < len(steps) else (None if nxt is None else nxt[4])
+                            if draw_dropout:
+                                keep.append(self.draw_dropout_masks(b))
+                            if not self._launch_step(b, err_penalty, sc_penalty_x001, True, optimizer, nb, d):
+                                raise RuntimeError("fusion refused during capture")
                 torch.cuda.current_stream().wait_stream(side)
-                ent[1], ent[2] = graph, (xs, y, b, keep, side)
+                self._prescanned = saved                        # nothing has run yet
+                ent[1], ent[2] = graph, (steps, nxt, keep, side, optimizer)
             except Exception:
                 ent[0] = -1
+                self._prescanned = None
                 return False
+        hip.check(self.lib.mmn_pack_refresh(self._plan, self._stream()), "mmn_pack_refresh")
         ent[1].replay()
+        self._graph_hits += 1
+        last = steps[-1][4]
+        self._prescanned = nxt[4] if (nxt is not None and nxt[4].nan_flags and last.nan_flags
+                                      and nxt[4].nan_flags != last.nan_flags) else None
         optimizer.mark_fused_step()
         return True
 
@@ -466,14 +548,18 @@ class HipChainEngine:
         hip.check(self.lib.mmn_eval_step(self._plan, C.byref(b), 1 if accumulate else 0, self._stream()), "mmn_eval_step")
 
     def nan_scan(self, b: hip.Batch) -> None:
-        """The NaN scan of a batch that carries device flags, on its own (data parallel: the flags are
-        OR-ed across the ranks before the step; the step's own scan then only re-sets local ones)."""
+        """The NaN scan of a batch that carries device flags, on its own launch (data parallel, first step of an epoch:
+        the flags are summed across the ranks - `flag_tail` - before the step; every later batch is pre-scanned by the
+        step before it and its flags ride in that step's all-reduce).  The step that follows finds the flags ready."""
         hip.check(self.lib.mmn_nan_scan(self._plan, C.byref(b), self._stream()), "mmn_nan_scan")
+        self._prescanned = b
 
-    def nan_flags_tensor(self) -> torch.Tensor:
-        """int32 [MAX_ENCODERS] view of the plan's per-data-slot NaN flags (device)."""
-        off = self._nan_flags_ptr - self.workspace.data_ptr()
-        return self.workspace[off:off + 4 * hip.MAX_ENCODERS].view(torch.int32)
+    def adam_fusable(self, optimizer) -> bool:
+        """True if `optimizer`'s step can ride in this engine's launches: a multimodn_amd.optim.Adam over exactly this
+        model's parameters, one group, one contiguous run whose layout the library accepts.  Only then does the fused
+        step leave a skipped encoder's parameters, moments and step count untouched (torch's grad-None behaviour)."""
+        d = optimizer.fused_descriptor(self) if hasattr(optimizer, "fused_descriptor") else None
+        return d is not None and self.lib.mmn_adam_fusable(self._plan, C.byref(d)) == 0
 
     def accumulate_and_step(self, err_penalty: float, sc_penalty_x001: float, optimizer) -> bool:
         """Data-parallel tail after the all-reduce: epoch accumulation + the optimizer's Adam step in ONE

@@ -14,10 +14,10 @@ from typing import Optional
 MAX_ENCODERS = 16
 MAX_DECODERS = 8
 MAX_LAYERS = 8
-MAX_DIM = 256
+MAX_DIM = 128
 ADAM_MAX_SEG = 512
 ERR_UNSUPPORTED = -2
-VERSION = 103
+VERSION = 104
 MAX_DEC_HIDDEN = 3
 ENC_MLP, ENC_MIMIC = 0, 1
 
@@ -34,6 +34,7 @@ ABI_SYMBOLS = (
     "mmn_chain_bwd", "mmn_chain_fwd_bwd", "mmn_wgrad", "mmn_reduce", "mmn_epoch_accumulate", "mmn_train_step",
     "mmn_eval_step", "mmn_adam_blocks", "mmn_adam_step", "mmn_adam_step_accumulate", "mmn_train_step_adam", "mmn_reduce_adam", "mmn_regroup_rows", "mmn_regroup", "mmn_epoch_reset", "mmn_epoch_read", "mmn_debug_buffer",
     "mmn_dropout_floats", "mmn_draw_dropout", "mmn_dropout_reset",
+    "mmn_nan_flags_set", "mmn_pack_invalidate", "mmn_pack_refresh", "mmn_train_step_ex", "mmn_epoch_write", "mmn_adam_fusable",
 )
 
 
@@ -62,7 +63,7 @@ class Batch(C.Structure):
     _fields_ = [("x", C.c_void_p * MAX_ENCODERS), ("ldx", C.c_int32 * MAX_ENCODERS),
                 ("y", C.c_void_p), ("nan_flags", C.c_void_p),
                 ("batch", C.c_int32), ("batch_global", C.c_int32), ("n_seq", C.c_int32),
-                ("reserved", C.c_int32),
+                ("flags_ready", C.c_int32),
                 ("seq_data", C.c_int32 * MAX_ENCODERS), ("seq_enc", C.c_int32 * MAX_ENCODERS),
                 ("tile_rows", C.c_void_p), ("tile_seq", C.c_void_p),
                 ("drop_mask", C.c_void_p * MAX_ENCODERS)]
@@ -74,6 +75,11 @@ class AdamDesc(C.Structure):
                 ("n", C.c_int64),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("weight_decay", C.c_double), ("n_seg", C.c_int32), ("maximize", C.c_int32)]
+
+
+class StepOpts(C.Structure):
+    _fields_ = [("adam", C.POINTER(AdamDesc)), ("next", C.POINTER(Batch)), ("accumulate_epoch", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class MmnError(RuntimeError):
@@ -115,6 +121,18 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_plan_destroy.argtypes = [vp]
     lib.mmn_nan_flags.restype = vp
     lib.mmn_nan_flags.argtypes = [vp]
+    lib.mmn_nan_flags_set.restype = vp
+    lib.mmn_nan_flags_set.argtypes = [vp, i32]
+    lib.mmn_pack_invalidate.restype = None
+    lib.mmn_pack_invalidate.argtypes = [vp]
+    lib.mmn_pack_refresh.restype = i32
+    lib.mmn_pack_refresh.argtypes = [vp, vp]
+    lib.mmn_train_step_ex.restype = i32
+    lib.mmn_train_step_ex.argtypes = [vp, C.POINTER(Batch), f32, f32, C.POINTER(StepOpts), vp]
+    lib.mmn_adam_fusable.restype = i32
+    lib.mmn_adam_fusable.argtypes = [vp, C.POINTER(AdamDesc)]
+    lib.mmn_epoch_write.restype = i32
+    lib.mmn_epoch_write.argtypes = [vp, C.POINTER(C.c_double), vp]
     lib.mmn_prepare.restype = i32
     lib.mmn_prepare.argtypes = [vp, C.POINTER(Batch), i32, vp]
     lib.mmn_nan_scan.restype = i32

@@ -125,11 +125,14 @@ class MultiModN(nn.Module):
         #: reference's batch-size-1 result (the only case the reference defines, multimodn.py:168,518-523)
         self.per_sample = False
         # tests: callable (encoder id, batch, width) -> [batch, width] multipliers replacing the device draw
-        # of the MIMIC encoders' dropout masks (parity runs feed the masks the reference drew)
+        # of the MIMIC encoders' dropout masks (parity runs feed the masks the reference drew); it is asked when a step
+        # is LAUNCHED - train_steps_launched is then the index of that step (batches are ingested ahead of their launch)
         self.dropout_mask_provider = None
-        #: single GPU, nan_policy "device", multimodn_amd.optim.Adam, batches of at most REPLAY_MAX_ROWS rows (the
-        #: reference pipelines train with 16-32): a step whose device buffers were seen before is captured into a
-        #: hipGraph once and replayed afterwards (engine.replayable_train_step)
+        self.train_steps_launched = 0
+        #: single GPU, device-side NaN decision, multimodn_amd.optim.Adam: steps whose device buffers were seen before are
+        #: captured into a hipGraph once and replayed afterwards (engine.run_group) - groups of REPLAY_GROUP steps when
+        #: the batches are device-resident (any batch size), single steps of at most REPLAY_MAX_ROWS rows when they are
+        #: staged from the host (the reference pipelines train with 16-32 rows: host-bound otherwise)
         self.replay_steps = True
         self.REPLAY_MAX_ROWS = 256
 
@@ -137,6 +140,7 @@ class MultiModN(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_engine"] = None
+        state["_batch_cache"] = {}
         state["_dp_group"] = None
         state["_dp_world"] = 1
         state["_dp_rank"] = 0
@@ -179,147 +183,315 @@ class MultiModN(nn.Module):
         return pairs
 
     # ------------------------------------------------------------------------------------------
-    def _ingest(self, data: Sequence[Tensor], target, pairs, optimizer=None, train: bool = False):
-        """Host half of multimodn.py:132-135,168: move the batch to the device, decide NaN skips.
-        Returns (xs_dev, y_dev, executed_pairs, executed_mask or None)."""
+    def _nan_mode(self, eng, optimizer, train: bool) -> str:
+        """How a step decides which encoders a NaN batch skips (multimodn.py:168):
+        "device"  on the GPU, nothing is read back (a skipped encoder's .grad then reads zeros instead of None: harmless for
+                  multimodn_amd.optim.Adam, whose fused step leaves such an encoder untouched exactly as torch does for
+                  grad None, and for the forward-only entry points);
+        "host"    on the host before the step (skipped encoders leave the sequence; their .grad is None): the
+                  reference's exact semantics for ANY optimizer, one readback per step when the batch lives on the device;
+        "readback" on the GPU, and the executed rows are read back after the step so that skipped encoders still get grad
+                  None: what "host" becomes under data parallel, where the decision belongs to the GLOBAL batch and the
+                  flags travel inside the step's one all-reduce.
+        nan_policy "auto" picks "device" only if that gives the reference's result: forward-only, or the optimizer's step
+        really is fused with this engine (a multimodn_amd.optim.Adam over exactly this model's parameters in one group;
+        with several groups, a subset or another order fused_descriptor() is None and the host policy applies)."""
         policy = getattr(self, "nan_policy", "auto")
-        use_device_policy = policy == "device" or (
-            policy == "auto" and (not train or hasattr(optimizer, "fused_descriptor")))
-        present: Optional[List[bool]] = None
-        if not isinstance(target, Tensor):
-            target = torch.as_tensor(np.asarray(target))
-        if target.dim() == 1:
-            target = target.view(-1, 1)
-        on_host = all(t.device.type == "cpu" for t in data) and target.device.type == "cpu"
-        # Host tensors of this size are copied / scanned by torch's intra-op pool; on a many-core
-        # host (128 threads here) that pool turns a 100 us copy into milliseconds, so the handful of
-        # small host ops of one batch run with at most 8 threads.
-        n_thr = torch.get_num_threads() if on_host else 0
-        if n_thr > 8:
-            torch.set_num_threads(8)
-        try:
-            if not use_device_policy:
-                if on_host or not pairs:
-                    present = [not _has_nan_host(data[k]) for k, _ in pairs]
-                else:                                                # device tensors: ONE readback for all slots
-                    flags = torch.stack([torch.isnan(data[k]).any() for k, _ in pairs]).tolist()
-                    present = [not f for f in flags]
-            if on_host and self.device.type == "cuda" and data:
-                if self._stager is None:
-                    self._stager = _HostStager(self.device)
-                xs, y = self._stager.stage(data, target.to(torch.int64))
-            else:
-                xs = [t.to(self.device, dtype=torch.float32, non_blocking=True).contiguous() for t in data]
-                y = target.to(torch.int64).to(self.device, non_blocking=True).contiguous()
-        finally:
-            if n_thr > 8:
-                torch.set_num_threads(n_thr)
-        if use_device_policy:
-            return xs, y, list(pairs), None
-        if self._dp_group is not None:                               # the decision is per GLOBAL batch
-            import torch.distributed as dist
-            flags = torch.tensor([0 if p else 1 for p in present], dtype=torch.int32,
-                                 device=self.device if dist.get_backend(self._dp_group) == "nccl" else "cpu")
-            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self._dp_group)
-            present = [int(f) == 0 for f in flags.tolist()]
-        exec_pairs = [pe for pe, ok in zip(pairs, present) if ok]
-        executed = [False] * len(self.encoders)
-        for _, e in exec_pairs:
-            executed[e] = True
-        return xs, y, exec_pairs, executed
+        if policy == "auto":
+            fused = train and hasattr(optimizer, "fused_descriptor") and hasattr(eng, "adam_fusable") and \
+                eng.adam_fusable(optimizer)
+            policy = "device" if (not train or fused) else "host"
+        if policy == "host" and self._dp_group is not None:
+            return "readback"
+        return policy
 
-    def _run_step(self, eng, data, target, encoder_sequence, train: bool, batch_global: Optional[int] = None,
-                  optimizer=None):
-        pairs = self.get_encoder_iterable(encoder_sequence, self.shuffle_mode, train=train)
-        xs, y, exec_pairs, executed = self._ingest(data, target, pairs, optimizer, train)
-        B = int(y.shape[0])
-        dp = self._dp_group is not None
-        # (replaying pays where the step is host-bound - measured: 50 -> 39 us/step at 32 rows, break-even at 512,
-        #  a replayed single-step graph is ~7 us SLOWER than four eager launches once the GPU is the bottleneck)
-        if (train and not dp and executed is None and getattr(self, "replay_steps", True) and B <= getattr(self, "REPLAY_MAX_ROWS", 256)
-                and self.dropout_mask_provider is None
-                and hasattr(eng, "replayable_train_step")
-                and eng.replayable_train_step(xs, y, exec_pairs, batch_global or B, float(self.err_penalty),
-                                              float(self.state_change_penalty), optimizer, bool(eng.dropout_encoders))):
-            return executed, (xs, y, None)
-        b = eng.make_batch(xs, y, exec_pairs, batch_global=batch_global or B * self._dp_world,
-                           device_nan_flags=executed is None)
-        if dp and executed is None and exec_pairs:
-            # device NaN policy under data parallel: the skip decision belongs to the GLOBAL batch
-            # (multimodn.py:168 looks at the whole batch): OR the per-slot flags over the ranks first
-            import torch.distributed as dist
-            eng.nan_scan(b)
-            flags = eng.nan_flags_tensor()
-            if dist.get_backend(self._dp_group) == "nccl":
-                dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self._dp_group)
-            else:
-                host_flags = flags.cpu()
-                dist.all_reduce(host_flags, op=dist.ReduceOp.MAX, group=self._dp_group)
-                flags.copy_(host_flags)
-        masks = None
-        if train and eng.dropout_encoders:                  # nn.Dropout of the MIMIC encoders is live in train mode only
-            masks = eng.draw_dropout_masks(b, self.dropout_mask_provider)
-        if train:
-            # single GPU + multimodn_amd.optim.Adam: optimizer.step() rides in the last launch
-            fuse = optimizer if (not dp and hasattr(optimizer, "fused_descriptor")) else None
-            eng.local_step(b, float(self.err_penalty), float(self.state_change_penalty), accumulate=not dp,
-                           optimizer=fuse)
-        else:
-            eng.eval_step(b, accumulate=not dp)
-        if dp:
-            import torch.distributed as dist
-            buf = eng.reduce_buf if train else eng.stats
-            if buf.is_cuda and dist.get_backend(self._dp_group) != "nccl":       # e.g. gloo in tests: stage through the host
-                host_buf = buf.cpu()
-                dist.all_reduce(host_buf, group=self._dp_group)
-                buf.copy_(host_buf)
-            else:
-                dist.all_reduce(buf, group=self._dp_group)
-            if train and optimizer is not None:
-                # epoch accumulation + Adam in one launch when the optimizer is multimodn_amd.optim.Adam
-                # (it leaves the parameters of encoders that did not run untouched, like grad None)
-                eng.accumulate_and_step(float(self.err_penalty), float(self.state_change_penalty), optimizer)
-            else:
-                eng.accumulate(float(self.err_penalty) if train else 1.0, float(self.state_change_penalty) if train else 0.0)
-        return executed, (xs, y, masks)
-
-    def _run_step_per_sample(self, eng, data, target, encoder_sequence, optimizer=None, train: bool = True):
-        """One training step in per-sample mode: rows are regrouped on the device into tiles of one
-        executed sequence each (engine.per_sample_batch) and run by the fused kernel."""
+    def _to_device(self, data: Sequence[Tensor], target):
+        """multimodn.py:132-135: the batch on the model's device, float32 features / int64 targets.  Host batches go
+        through one pinned staging buffer and ONE copy."""
+        def here(t):                                        # (a device without an index means the current one)
+            return t.device.type == self.device.type and (self.device.index is None or t.device.index == self.device.index)
+        if self.device.type != "cpu" and isinstance(target, Tensor) and here(target) and target.dtype == torch.int64 \
+                and target.dim() == 2 and target.is_contiguous() \
+                and all(here(t) and t.dtype == torch.float32 and t.is_contiguous() for t in data):
+            return list(data), target, False                # device-resident batch: nothing to move, nothing to convert
         if not isinstance(target, Tensor):
             target = torch.as_tensor(np.asarray(target))
         if target.dim() == 1:
             target = target.view(-1, 1)
         on_host = all(t.device.type == "cpu" for t in data) and target.device.type == "cpu"
         if on_host and self.device.type == "cuda" and data:
-            if self._stager is None:
-                self._stager = _HostStager(self.device)
-            xs, y = self._stager.stage(data, target.to(torch.int64))
+            # Host tensors of this size are copied / scanned by torch's intra-op pool; on a many-core
+            # host (128 threads here) that pool turns a 100 us copy into milliseconds, so the handful of
+            # small host ops of one batch run with at most 8 threads.
+            n_thr = torch.get_num_threads()
+            if n_thr > 8:
+                torch.set_num_threads(8)
+            try:
+                if self._stager is None:
+                    self._stager = _HostStager(self.device)
+                xs, y = self._stager.stage(data, target.to(torch.int64))
+            finally:
+                if n_thr > 8:
+                    torch.set_num_threads(n_thr)
         else:
             xs = [t.to(self.device, dtype=torch.float32, non_blocking=True).contiguous() for t in data]
             y = target.to(torch.int64).to(self.device, non_blocking=True).contiguous()
+        return xs, y, on_host
+
+    def _ingest(self, data: Sequence[Tensor], target, pairs, mode: str = "host"):
+        """Host half of multimodn.py:132-135,168: move the batch to the device and, under the host policy, decide the
+        NaN skips.  Returns (xs_dev, y_dev, executed_pairs, executed list or None, batch came from the host)."""
+        present: Optional[List[bool]] = None
+        if mode == "host":
+            on_host = all(t.device.type == "cpu" for t in data)
+            n_thr = torch.get_num_threads() if on_host else 0
+            if n_thr > 8:
+                torch.set_num_threads(8)
+            try:
+                if on_host or not pairs:
+                    present = [not _has_nan_host(data[k]) for k, _ in pairs]
+                else:                                                # device tensors: ONE readback for all slots
+                    flags = torch.stack([torch.isnan(data[k]).any() for k, _ in pairs]).tolist()
+                    present = [not f for f in flags]
+            finally:
+                if n_thr > 8:
+                    torch.set_num_threads(n_thr)
+        xs, y, on_host = self._to_device(data, target)
+        if present is None:
+            return xs, y, list(pairs), None, on_host
+        exec_pairs = [pe for pe, ok in zip(pairs, present) if ok]
+        executed = [False] * len(self.encoders)
+        for _, e in exec_pairs:
+            executed[e] = True
+        return xs, y, exec_pairs, executed, on_host
+
+    def _dp_all_reduce(self, buf: Tensor) -> None:
+        """Sum over the ranks, in place.  RCCL takes device buffers; any other backend (gloo in the tests) gets the
+        buffer through the host."""
+        import torch.distributed as dist
+        if buf.is_cuda and dist.get_backend(self._dp_group) != "nccl":
+            host_buf = buf.cpu()
+            dist.all_reduce(host_buf, group=self._dp_group)
+            buf.copy_(host_buf)
+        else:
+            dist.all_reduce(buf, group=self._dp_group)
+
+    class _Step:
+        """One ingested mini-batch waiting for its launch."""
+        __slots__ = ("xs", "y", "pairs", "executed", "on_host", "bg", "b", "key", "masks", "cached")
+
+        def __init__(self, xs, y, pairs, executed, on_host, bg, cached=None):
+            self.xs, self.y, self.pairs, self.executed, self.on_host, self.bg = xs, y, pairs, executed, on_host, bg
+            self.b, self.key, self.masks, self.cached = None, None, None, cached
+
+        def key_tuple(self):
+            return (self.xs, self.y, self.pairs, self.bg, self.b, self.key)
+
+    def _make_step(self, data, target, encoder_sequence, mode: str, train: bool) -> "MultiModN._Step":
+        pairs = self.get_encoder_iterable(encoder_sequence, self.shuffle_mode, train=train)
+        xs, y, exec_pairs, executed, on_host = self._ingest(data, target, pairs, mode)
+        return MultiModN._Step(xs, y, exec_pairs, executed, on_host, int(y.shape[0]) * self._dp_world)
+
+    def _launch_step(self, eng, st: "MultiModN._Step", nxt: Optional["MultiModN._Step"], train: bool, optimizer, mode: str,
+                     desc=None):
+        """The launches of ONE step (multimodn.py:137-204 without optimizer.step() unless it is fused): returns the
+        `executed` list for assign_grads (None = every encoder has a gradient buffer)."""
+        dp = self._dp_group is not None
+        b = st.b
+        alpha, beta = float(self.err_penalty), float(self.state_change_penalty)
+        if dp and b.nan_flags and eng._prescanned is not b:
+            # data parallel: the skip decision belongs to the GLOBAL batch (multimodn.py:168 looks at the whole batch).
+            # Every batch but the first of an epoch was pre-scanned by the step before it and its flags rode in that
+            # step's all-reduce; this one is scanned on its own and its flags are summed now.
+            eng.nan_scan(b)
+            self._dp_all_reduce(eng.flag_tail)
+        if train and eng.dropout_encoders:                  # nn.Dropout of the MIMIC encoders is live in train mode only
+            st.masks = eng.draw_dropout_masks(b, self.dropout_mask_provider)
+        if train:
+            # single GPU + multimodn_amd.optim.Adam: optimizer.step() rides in the last launch
+            fuse = optimizer if (not dp and hasattr(optimizer, "fused_descriptor")) else None
+            eng.local_step(b, alpha, beta, accumulate=not dp, optimizer=fuse,
+                           next_batch=None if nxt is None else nxt.b, **({"desc": desc} if desc is not None else {}))
+        else:
+            eng.eval_step(b, accumulate=not dp)
+        if dp:
+            self._dp_all_reduce(eng.reduce_buf if train else eng.stats)     # THE collective of the step: grads + stats + flags
+            if train and optimizer is not None:
+                # epoch accumulation + Adam in one launch when the optimizer is multimodn_amd.optim.Adam
+                # (it leaves the parameters of encoders that did not run untouched, like grad None)
+                eng.accumulate_and_step(alpha, beta, optimizer)
+            else:
+                eng.accumulate(alpha if train else 1.0, beta if train else 0.0)
+        if train:
+            self.train_steps_launched = getattr(self, "train_steps_launched", 0) + 1
+        if mode == "readback":                              # exact grad-None semantics for a foreign optimizer
+            return list(eng.executed_rows()[1:])
+        return st.executed
+
+    def _run_step(self, eng, data, target, encoder_sequence, train: bool, batch_global: Optional[int] = None,
+                  optimizer=None):
+        """One step on its own (no look-ahead): what test() / the parity tests / smoke() drive."""
+        mode = self._nan_mode(eng, optimizer, train)
+        st = self._make_step(data, target, encoder_sequence, mode, train)
+        if batch_global:
+            st.bg = int(batch_global)
+        st.b = eng.make_batch(st.xs, st.y, st.pairs, batch_global=st.bg, device_nan_flags=st.executed is None)
+        executed = self._launch_step(eng, st, None, train, optimizer, mode)
+        return executed, (st.xs, st.y, st.masks)
+
+    def _run_step_per_sample(self, eng, data, target, encoder_sequence, optimizer=None, train: bool = True):
+        """One training step in per-sample mode: rows are regrouped on the device into tiles of one
+        executed sequence each (engine.per_sample_batch) and run by the fused kernel."""
+        xs, y, _ = self._to_device(data, target)
         seq = None
         if encoder_sequence is not None:
             seq = encoder_sequence if isinstance(encoder_sequence, Tensor) else torch.as_tensor(np.asarray(encoder_sequence))
             seq = seq.to(self.device, torch.int64)
         B = int(y.shape[0])
         dp = self._dp_group is not None
+        alpha, beta = float(self.err_penalty), float(self.state_change_penalty)
         b, keep = eng.per_sample_batch(xs, y, seq)
         b.batch_global = B * self._dp_world
         if not train:                                       # forward-only (test / predict / get_states)
             eng.eval_step(b, accumulate=not dp)
             if dp:
-                import torch.distributed as dist
-                dist.all_reduce(eng.stats, group=self._dp_group)
+                self._dp_all_reduce(eng.stats)
                 eng.accumulate(1.0, 0.0)
             return None, (xs, y, keep)
         fuse = optimizer if (not dp and hasattr(optimizer, "fused_descriptor")) else None
-        eng.local_step(b, float(self.err_penalty), float(self.state_change_penalty), accumulate=not dp, optimizer=fuse)
-        if dp:
-            import torch.distributed as dist
-            dist.all_reduce(eng.reduce_buf, group=self._dp_group)
-            eng.accumulate(float(self.err_penalty), float(self.state_change_penalty))
+        eng.local_step(b, alpha, beta, accumulate=not dp, optimizer=fuse)
+        if dp:                                              # per-sample masks / sequences are per-row data: shards add up
+            self._dp_all_reduce(eng.reduce_buf)
+            if optimizer is not None:
+                eng.accumulate_and_step(alpha, beta, optimizer)
+            else:
+                eng.accumulate(alpha, beta)
         return None, (xs, y, keep)
+
+    #: steps captured into one hipGraph when every batch of the group already lives on the device
+    REPLAY_GROUP = 8
+
+    def _train_steps(self, train_loader, optimizer, log_interval=None, logger=None):
+        """The batch loop of train_epoch (multimodn.py:117-212).  Batches are ingested one step ahead of their launch
+        (a group ahead when they are device-resident), so that (a) a step's last launch pre-scans the NEXT batch for
+        NaNs - no scan launch in front of the next chain kernel; under data parallel the flags ride in the step's ONE
+        all-reduce - and (b) recurring groups of steps are replayed as one hipGraph (engine.run_group).
+        Returns (engine, number of steps run)."""
+        import collections
+        import itertools
+        it = iter(train_loader)
+        n_batches = len(train_loader) if hasattr(train_loader, "__len__") else None
+        window: "collections.deque[MultiModN._Step]" = collections.deque()
+        cache = self.__dict__.setdefault("_batch_cache", {})
+        state = {"eng": None, "mode": None, "done": False, "steps": 0, "grads_assigned": False, "fd": None}
+        dp = self._dp_group is not None
+
+        def pull() -> bool:
+            if state["done"]:
+                return False
+            try:
+                batch = next(it)
+            except StopIteration:
+                state["done"] = True
+                return False
+            data, target, encoder_sequence = (list(batch) + [None])[:3]
+            if state["eng"] is None:
+                eng = state["eng"] = self._get_engine(int(target.shape[0]))
+                eng.epoch_reset()
+                eng.begin_sequence()
+                state["mode"] = self._nan_mode(eng, optimizer, True)
+                state["sig"] = (state["mode"], self._dp_world, self.shuffle_mode)
+                # (the optimizer's descriptor walks every parameter: once per epoch, not once per step)
+                if not dp and hasattr(optimizer, "fused_descriptor") and hasattr(eng, "run_group"):
+                    state["fd"] = optimizer.fused_descriptor(eng)
+            # Loaders over device-resident data hand the SAME batch objects back every epoch (DeviceResidentLoader
+            # without shuffling, a list of device batches): what was derived from their tensors' addresses last time
+            # - the sequence, the filled-in mmn_batch struct, its cache key - is reused; checking a batch costs less host
+            # time than a small step's launches.  (Only addresses are kept, never values: the tensors' contents may change.)
+            ent = cache.get(id(batch)) if encoder_sequence is None else None
+            if ent is not None and ent[0] is batch and ent[1] is target and ent[3] == state["sig"] \
+                    and len(ent[2]) == len(data) and all(a is c for a, c in zip(ent[2], data)):
+                window.append(MultiModN._Step(ent[2], target, ent[4], None, False, ent[5], ent))
+                return True
+            st = self._make_step(data, target, encoder_sequence, state["mode"], True)
+            if encoder_sequence is None and st.executed is None and not st.on_host and not self.shuffle_mode \
+                    and isinstance(batch, tuple) and st.y is target and all(a is c for a, c in zip(st.xs, data)):
+                if len(cache) >= 4096:
+                    cache.clear()
+                st.cached = cache[id(batch)] = [batch, target, st.xs, state["sig"], st.pairs, st.bg, None]
+            window.append(st)
+            return True
+
+        def materialise() -> None:
+            """hip.Batch structs for everything in the window (in order: the flag sets alternate); a batch larger than
+            the plan re-plans first, which invalidates the structs made so far."""
+            eng = state["eng"]
+            need = max(int(st.y.shape[0]) for st in window)
+            if eng.ensure(need):
+                for st in window:
+                    st.b = None
+                eng.begin_sequence()
+            for st in window:
+                if st.b is None:
+                    ent = st.cached
+                    st.b, st.key, tk = eng.make_batch_keyed(st.xs, st.y, st.pairs, st.bg, st.executed is None,
+                                                            None if ent is None else ent[6])
+                    if ent is not None:
+                        ent[6] = tk
+
+        while True:
+            if not window and not pull():
+                break
+            eng, mode = state["eng"], state["mode"]
+            # how far to look ahead: device-resident batches by a whole group (+ the batch the group's last step
+            # pre-scans); batches staged from the host by one (the staging ring is three deep)
+            resident = not window[0].on_host
+            can_replay = (not dp and mode == "device" and getattr(self, "replay_steps", True) and not log_interval
+                          and self.dropout_mask_provider is None and hasattr(eng, "run_group") and optimizer is not None)
+            group = 1
+            if can_replay and resident:
+                group = max(1, int(getattr(self, "REPLAY_GROUP", 8)))
+            while len(window) < group + 1 and pull():
+                pass
+            materialise()
+            n = min(group, len(window))
+            if any(st.on_host != window[0].on_host for st in itertools.islice(window, n)):
+                n = 1
+            small = int(window[0].y.shape[0]) <= getattr(self, "REPLAY_MAX_ROWS", 256)
+            # (a replayed SINGLE step pays where the step is host-bound - measured: 50 -> 39 us/step at 32 rows, break-even
+            #  at 512 - a group of 8 pays at any batch size: one host submission for 8 steps)
+            if can_replay and (n > 1 or small):
+                steps = [st.key_tuple() for st in itertools.islice(window, n)]
+                nxt = window[n].key_tuple() if len(window) > n else None
+                if not state["grads_assigned"]:
+                    eng.assign_grads(None)
+                    state["grads_assigned"] = True
+                if eng.run_group(steps, nxt, float(self.err_penalty), float(self.state_change_penalty), optimizer,
+                                 bool(eng.dropout_encoders), state["fd"]):
+                    for _ in range(n):
+                        window.popleft()
+                    state["steps"] += n
+                    self.train_steps_launched = getattr(self, "train_steps_launched", 0) + n
+                    optimizer.step()                         # clears the "already applied" mark: a no-op
+                    continue
+            # eagerly: the whole group (first sighting of its buffers: the groups of later epochs then start at the same
+            # positions), or the single step
+            for _ in range(n):
+                st = window.popleft()
+                nxt = window[0] if window else None
+                optimizer.zero_grad()
+                executed = self._launch_step(eng, st, nxt, True, optimizer, mode, state["fd"])
+                eng.assign_grads(executed)          # what loss.backward() leaves behind (multimodn.py:203)
+                optimizer.step()
+                state["steps"] += 1
+                batch_idx = state["steps"] - 1
+                if log_interval and batch_idx % log_interval == log_interval - 1:
+                    v = eng.step_values()
+                    logger(f"Batch {batch_idx + 1}/{n_batches}\n"
+                           f"\tLoss: {float(v['loss']):.4f}\n"
+                           f"\tErr loss: {float(v['global_err']):.4f}\n"
+                           f"\tState change: {float(v['global_sc']):.4f}")
+        return state["eng"], state["steps"]
 
     def train_epoch(
             self,
@@ -337,32 +509,27 @@ class MultiModN(nn.Module):
             logger = print
         self.train()
         n_batches = len(train_loader)
-        eng = None
-        keep = None
-        for batch_idx, batch in enumerate(train_loader):
-            data, target, encoder_sequence = (list(batch) + [None])[:3]
-            if eng is None:
-                eng = self._get_engine(int(target.shape[0]))
-                eng.epoch_reset()
-            else:
-                eng.ensure(int(target.shape[0]))
-            optimizer.zero_grad()
-            if self.per_sample:
+        if self.per_sample:
+            eng = None
+            keep = None
+            for batch in train_loader:
+                data, target, encoder_sequence = (list(batch) + [None])[:3]
+                if eng is None:
+                    eng = self._get_engine(int(target.shape[0]))
+                    eng.epoch_reset()
+                    eng.begin_sequence()
+                else:
+                    eng.ensure(int(target.shape[0]))
+                optimizer.zero_grad()
                 executed, keep = self._run_step_per_sample(eng, data, target, encoder_sequence, optimizer)
-            else:
-                executed, keep = self._run_step(eng, data, target, encoder_sequence, train=True, optimizer=optimizer)
-            eng.assign_grads(executed)          # what loss.backward() leaves behind (multimodn.py:203)
-            optimizer.step()
-            if log_interval and batch_idx % log_interval == log_interval - 1:
-                v = eng.step_values()
-                logger(f"Batch {batch_idx + 1}/{n_batches}\n"
-                       f"\tLoss: {float(v['loss']):.4f}\n"
-                       f"\tErr loss: {float(v['global_err']):.4f}\n"
-                       f"\tState change: {float(v['global_sc']):.4f}")
+                eng.assign_grads(executed)
+                optimizer.step()
+            del keep
+        else:
+            eng, _ = self._train_steps(train_loader, optimizer, log_interval, logger)
         if eng is None:
             return None
         arrays = self._epoch_arrays(eng, n_batches)
-        del keep
         if history is not None:
             history.state_change_loss.append(arrays["state_change"])
             history.loss["train"].append(arrays["loss"])
@@ -422,6 +589,7 @@ class MultiModN(nn.Module):
             if eng is None:
                 eng = self._get_engine(int(target.shape[0]))
                 eng.epoch_reset()
+                eng.begin_sequence()
             else:
                 eng.ensure(int(target.shape[0]))
             last = len(self.encoders) - 1
@@ -486,6 +654,7 @@ class MultiModN(nn.Module):
             return full
         if self.per_sample:                                    # every sample its own order / missing modalities (skipped)
             eng = self._get_engine(n_samples)
+            eng.begin_sequence()
             dummy = torch.zeros((n_samples, len(self.decoders)), dtype=torch.int64)
             _, keep = self._run_step_per_sample(eng, x, dummy, encoder_sequence, train=False)
             where, codes = eng.per_sample_positions()
@@ -503,6 +672,7 @@ class MultiModN(nn.Module):
         seq = None if encoder_sequence is None else np.asarray(encoder_sequence)
         pairs = self.get_encoder_iterable(seq, self.shuffle_mode, train=False)
         eng = self._get_engine(n_samples)
+        eng.begin_sequence()
         xs = [t.to(self.device, dtype=torch.float32).contiguous() for t in x]
         y = torch.zeros((n_samples, len(self.decoders)), dtype=torch.int64, device=self.device)
         b = eng.make_batch(xs, y, pairs, batch_global=n_samples, device_nan_flags=False)
@@ -523,6 +693,8 @@ class MultiModN(nn.Module):
             data, _, encoder_sequence = (list(batch) + [None])[:3]
             n = int(data[0].shape[0])
             eng = self._get_engine(n)
+            if not batch_states:
+                eng.begin_sequence()
             dummy = torch.zeros((n, len(self.decoders)), dtype=torch.int64)
             if self.per_sample:
                 _, keep = self._run_step_per_sample(eng, data, dummy, encoder_sequence, train=False)
@@ -540,7 +712,7 @@ class MultiModN(nn.Module):
                 batch_states.append(state)
                 continue
             pairs = self.get_encoder_iterable(encoder_sequence, self.shuffle_mode, train=False)
-            xs, y, exec_pairs, executed = self._ingest(data, dummy, pairs)
+            xs, y, exec_pairs, executed, _ = self._ingest(data, dummy, pairs, self._nan_mode(eng, None, False))
             b = eng.make_batch(xs, y, exec_pairs, batch_global=n, device_nan_flags=executed is None)
             eng.eval_step(b, accumulate=False)
             if executed is None:

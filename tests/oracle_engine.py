@@ -40,7 +40,8 @@ class OracleEngine:
                                  if isinstance(enc, MIMIC_MLPEncoder) and enc.dropout > 0]
         self.n_params = sum(p.numel() for p in self.params)
         R = self.E + 1
-        self.n_stats = R * self.D + self.E + 5 * R * self.D + R + 4
+        self.NF = 16                                        # hip.MAX_ENCODERS: words per NaN-flag set
+        self.n_stats = R * self.D + self.E + 5 * R * self.D + R + 4 + 2 * self.NF     # ... + the two flag sets
         self.reduce_buf = torch.zeros(self.n_params + self.n_stats)
         self.flat_grads = self.reduce_buf[:self.n_params]
         self.stats = self.reduce_buf[self.n_params:]
@@ -51,9 +52,34 @@ class OracleEngine:
         self.enc_param_ids = [[id(p) for p in enc.parameters()] for enc in model.encoders]
         self.epoch = np.zeros(R * self.D + self.E + 5 * R * self.D + R + 1)
         self.max_batch = max_batch
+        # the flag protocol of HipChainEngine (engine.py: make_batch / nan_scan / local_step): two sets at the end of
+        # the stats block, handed out in turn; a step consumes (and re-zeroes) its batch's set and pre-scans the next
+        # batch into the other one, so that under data parallel the flags ride in the step's one all-reduce
+        self.flag_tail = self.stats[self.n_stats - 2 * self.NF:]
+        self._flag_turn = 0
+        self._prescanned = None
 
     def ensure(self, batch):
         self.max_batch = max(self.max_batch, batch)
+        return False
+
+    def begin_sequence(self):
+        self._flag_turn = 0
+        self._prescanned = None
+
+    def adam_fusable(self, optimizer):
+        return False
+
+    def _scan(self, b):
+        """k_prepare's / k_reduce's scan blocks: raise the word of every data slot of b's sequence that holds a NaN."""
+        fl = self.flag_tail[b.nan_flags * self.NF:(b.nan_flags + 1) * self.NF]
+        for k, _ in b.pairs:
+            if np.isnan(b.xs[k]).any():
+                fl[k] = 1.0
+
+    def nan_scan(self, b):
+        self._scan(b)
+        self._prescanned = b
 
     def epoch_reset(self):
         self.epoch[:] = 0
@@ -65,8 +91,16 @@ class OracleEngine:
         b.pairs = list(pairs)
         b.batch_global = batch_global or len(b.y)
         b.device_nan = device_nan_flags
+        b.nan_flags = None
+        if device_nan_flags:
+            b.nan_flags = self._flag_turn
+            self._flag_turn ^= 1
+        b.tile_seq = None
         b.masks = None
         return b
+
+    def make_batch_keyed(self, xs, y, pairs, batch_global=None, device_nan_flags=False, template=None):
+        return self.make_batch(xs, y, pairs, batch_global, device_nan_flags), None, None
 
     def draw_dropout_masks(self, b, provider=None):
         """HipChainEngine.draw_dropout_masks on the host (torch's CPU generator)."""
@@ -91,6 +125,8 @@ class OracleEngine:
         b.seq = None if seq is None else seq.numpy()
         b.batch_global = len(b.y)
         b.per_sample = True
+        b.nan_flags = None
+        b.tile_seq = True
         return b, None
 
     def _run(self, b, want_grads):
@@ -107,7 +143,10 @@ class OracleEngine:
             # oracle takes a [B, n_seq] sequence whose t-th entry feeds data slot t
             xs = [b.xs[k] for k, _ in b.pairs]
             seq = np.tile(np.array([e for _, e in b.pairs], np.int64), (len(b.y), 1))
-        override = None if b.device_nan else [True] * len(b.pairs)
+        override = [True] * len(b.pairs)
+        if b.device_nan:                                    # the flag words decide (summed over the ranks under DP)
+            fl = self.flag_tail[b.nan_flags * self.NF:(b.nan_flags + 1) * self.NF]
+            override = [float(fl[k]) == 0.0 for k, _ in b.pairs]
         spec = self.spec
         if not b.pairs:
             xs, seq, override = [], np.zeros((len(b.y), 0), np.int64), []
@@ -129,15 +168,35 @@ class OracleEngine:
         for i, k in enumerate(("n_correct", "tp", "tn", "fp", "fn")):
             st[RD + E + i * RD:RD + E + (i + 1) * RD] = getattr(r, k).reshape(-1)
         st[RD + E + 5 * RD:RD + E + 5 * RD + R] = rows
-        self.stats.copy_(torch.from_numpy(st))
+        nv = self.n_stats - 2 * self.NF                      # (the flag sets behind the step values are not touched)
+        self.stats[:nv].copy_(torch.from_numpy(st[:nv]))
         if want_grads:
             flat = np.concatenate([np.zeros(p.numel(), np.float32) if r.grads[n] is None
                                    else np.asarray(r.grads[n], np.float32).reshape(-1)
                                    for n, p in zip(self.names, self.params)])
             self.flat_grads.copy_(torch.from_numpy(flat))
 
-    def local_step(self, b, alpha, beta, accumulate=False, optimizer=None):
+    def _consume_flags(self, b, next_batch=None):
+        """Before the step: scan unless an earlier step pre-scanned this batch.  After it (k_reduce): the consumed set
+        is zero again and the next batch's flags stand in the other set."""
+        if b.nan_flags is not None and self._prescanned is not b:
+            self.flag_tail[b.nan_flags * self.NF:(b.nan_flags + 1) * self.NF] = 0
+            self._scan(b)
+
+    def _after_step(self, b, next_batch=None):
+        self._prescanned = None
+        if b.nan_flags is not None:
+            self.flag_tail[b.nan_flags * self.NF:(b.nan_flags + 1) * self.NF] = 0
+            if next_batch is not None and next_batch.nan_flags is not None and next_batch.nan_flags != b.nan_flags:
+                self._scan(next_batch)
+                self._prescanned = next_batch
+
+    def local_step(self, b, alpha, beta, accumulate=False, optimizer=None, next_batch=None):
+        if not getattr(b, "per_sample", False):
+            self._consume_flags(b)
         self._run(b, True)
+        if not getattr(b, "per_sample", False):
+            self._after_step(b, next_batch)
         if accumulate:
             self.accumulate(alpha, beta)
         return False                     # never applies the optimizer step itself
@@ -147,7 +206,11 @@ class OracleEngine:
         import dataclasses
         self.spec = dataclasses.replace(spec, err_penalty=1.0, state_change_penalty=0.0)
         try:
+            if not getattr(b, "per_sample", False):
+                self._consume_flags(b)
             self._run(b, False)
+            if not getattr(b, "per_sample", False):
+                self._after_step(b)
         finally:
             self.spec = spec
         if accumulate:

@@ -45,14 +45,16 @@ def test_struct_sizes_match_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "mmn_hip.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mmn_linear), sizeof(mmn_encoder),'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mmn_linear), sizeof(mmn_encoder),'
         ' sizeof(mmn_decoder), sizeof(mmn_model), sizeof(mmn_batch), sizeof(mmn_adam), offsetof(mmn_batch, drop_mask),'
-        ' offsetof(mmn_model, dec), offsetof(mmn_decoder, hidden));return 0;}\n')
+        ' offsetof(mmn_model, dec), offsetof(mmn_decoder, hidden), sizeof(mmn_step_opts), offsetof(mmn_step_opts, accumulate_epoch),'
+        ' offsetof(mmn_batch, flags_ready));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     want = [C.sizeof(hip.Linear), C.sizeof(hip.Encoder), C.sizeof(hip.Decoder), C.sizeof(hip.Model), C.sizeof(hip.Batch),
-            C.sizeof(hip.AdamDesc), hip.Batch.drop_mask.offset, hip.Model.dec.offset, hip.Decoder.hidden.offset]
+            C.sizeof(hip.AdamDesc), hip.Batch.drop_mask.offset, hip.Model.dec.offset, hip.Decoder.hidden.offset,
+            C.sizeof(hip.StepOpts), hip.StepOpts.accumulate_epoch.offset, hip.Batch.flags_ready.offset]
     assert got == want
     assert C.sizeof(hip.Linear) == 40 and C.sizeof(hip.Encoder) == 16 + 40 * hip.MAX_LAYERS
 
@@ -73,7 +75,7 @@ def _model(S=128, F=64, H=(32, 32), E=4, D=3):
 def test_host_side_sizing(lib):
     m = _model()
     R, D, E = 5, 3, 4
-    assert lib.mmn_stats_floats(C.byref(m)) == R * D + E + 5 * R * D + R + 4
+    assert lib.mmn_stats_floats(C.byref(m)) == R * D + E + 5 * R * D + R + 4 + 2 * hip.MAX_ENCODERS   # + the two NaN-flag sets
     assert lib.mmn_epoch_doubles(C.byref(m)) == R * D + E + 5 * R * D + R + 1
     small, big = lib.mmn_workspace_bytes(C.byref(m), 256), lib.mmn_workspace_bytes(C.byref(m), 4096)
     assert 0 < small < big < 1 << 30

@@ -45,16 +45,10 @@ def _worker(rank, world, port, name, out_dir):
             item.append(torch.from_numpy(b[2][lo:hi]))
         loader.append(tuple(item))
     # MIMIC family: every rank feeds ITS rows of the dropout masks the reference drew for the global batch
-    step = {"i": 0}
 
-    class CountingLoader(list):
-        def __iter__(self):
-            for item in list.__iter__(self):
-                yield item
-                step["i"] += 1
 
     def provide(e, batch, width):
-        m = g.step_masks(step["i"]).get(e)
+        m = g.step_masks(model.train_steps_launched).get(e)
         if m is None:
             return None
         n = m.shape[0]
@@ -62,7 +56,7 @@ def _worker(rank, world, port, name, out_dir):
 
     model.dropout_mask_provider = provide
     for _ in range(g.epochs):
-        model.train_epoch(CountingLoader(loader), opt, torch.nn.CrossEntropyLoss(), hist)
+        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=np.stack(hist.loss["train"]),
              acc=np.stack(hist.accuracy["train"]), sc=np.stack(hist.state_change_loss),
              **{"p/" + k: v.numpy() for k, v in model.state_dict().items()})
@@ -111,16 +105,10 @@ def _gpu_worker(rank, world, port, name, policy, out_dir):
         if len(b) > 2:
             item.append(torch.from_numpy(b[2][lo:hi]))
         loader.append(tuple(item))
-    step = {"i": 0}
 
-    class CountingLoader(list):
-        def __iter__(self):
-            for item in list.__iter__(self):
-                yield item
-                step["i"] += 1
 
     def provide(e, batch, width):                         # MIMIC family: this rank's rows of the reference's masks
-        m = g.step_masks(step["i"]).get(e)
+        m = g.step_masks(model.train_steps_launched).get(e)
         if m is None:
             return None
         n = m.shape[0]
@@ -128,7 +116,7 @@ def _gpu_worker(rank, world, port, name, policy, out_dir):
 
     model.dropout_mask_provider = provide
     for _ in range(g.epochs):
-        model.train_epoch(CountingLoader(loader), opt, torch.nn.CrossEntropyLoss(), hist)
+        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=np.stack(hist.loss["train"]),
              acc=np.stack(hist.accuracy["train"]), sc=np.stack(hist.state_change_loss),

@@ -56,22 +56,16 @@ def test_mimic_family_host_logic_reproduces_golden_history(name):
     model._engine_factory = OracleEngine
     opt = torch.optim.Adam(list(model.parameters()), g.cfg["lr"])
     hist = mm.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
-    step = {"i": 0}
 
-    class CountingLoader(list):
-        def __iter__(self):
-            for item in list.__iter__(self):
-                yield item
-                step["i"] += 1
 
     def provide(e, batch, width):
-        m = g.step_masks(step["i"]).get(e)
+        m = g.step_masks(model.train_steps_launched).get(e)
         assert m is None or m.shape == (batch, width)
         return None if m is None else torch.from_numpy(m)
 
     model.dropout_mask_provider = provide
     for _ in range(g.epochs):
-        model.train_epoch(CountingLoader(make_loader(g)), opt, torch.nn.CrossEntropyLoss(), hist)
+        model.train_epoch(make_loader(g), opt, torch.nn.CrossEntropyLoss(), hist)
     z = g.z
     assert rel_err(np.stack(hist.loss["train"]), z["hist/loss"]) < 2e-6
     assert rel_err(np.stack(hist.state_change_loss), z["hist/state_change"]) < 2e-6

@@ -77,21 +77,15 @@ def test_training_matches_reference_golden(lib, name, optimizer):
     hist = lib.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
     crit = torch.nn.CrossEntropyLoss()
     loader = [tuple([[torch.from_numpy(x) for x in b[0]], torch.from_numpy(b[1])]) for b in g.batches()]
-    step = {"i": 0}
 
     def provide(e, batch, width):
-        m = g.step_masks(step["i"]).get(e)
+        m = g.step_masks(model.train_steps_launched).get(e)
         return None if m is None else torch.from_numpy(m)
 
-    class CountingLoader(list):                     # one optimizer step per batch: advance the mask index with it
-        def __iter__(self_inner):
-            for item in list.__iter__(self_inner):
-                yield item
-                step["i"] += 1
 
     model.dropout_mask_provider = provide
     for _ in range(g.epochs):
-        model.train_epoch(CountingLoader(loader), opt, crit, hist)
+        model.train_epoch(loader, opt, crit, hist)
     z = g.z
     assert rel_err(np.stack(hist.loss["train"]), z["hist/loss"]) < 1e-5
     assert rel_err(np.stack(hist.state_change_loss), z["hist/state_change"]) < 1e-5
@@ -153,7 +147,7 @@ def test_replayed_steps_with_host_batches(lib):
 @pytest.mark.parametrize("family", ["classic", "mimic"])
 def test_replayed_steps_equal_eager_steps(lib, family):
     """train_epoch with nan_policy "device" + multimodn_amd.optim.Adam captures a step into a hipGraph the second time
-    it sees the same device buffers and replays it afterwards (engine.replayable_train_step).  Four epochs over the
+    it sees the same device buffers and replays it afterwards (engine.run_group).  Four epochs over the
     same device-resident batches, with replay on and off: History and trained weights must be identical bit for bit
     (deterministic kernels; Adam counters, epoch sums and the dropout draw index live on the device)."""
     if family == "mimic":
@@ -176,7 +170,7 @@ def test_replayed_steps_equal_eager_steps(lib, family):
             model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
         torch.cuda.synchronize()
         n_graphs = sum(1 for v in model._engine._step_graphs.values() if v[1] is not None)
-        assert n_graphs == (5 if replay else 0)
+        assert (n_graphs >= 1) == replay                    # (the first step of an epoch goes out eagerly, the other four as one group)
         runs[replay] = (np.stack(hist.loss["train"]), np.stack(hist.state_change_loss),
                         {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()},
                         {k: v["step"].item() for k, v in list(opt.state.items())[:1]})

@@ -554,18 +554,18 @@ class HipChainEngine:
         hip.check(self.lib.mmn_nan_scan(self._plan, C.byref(b), self._stream()), "mmn_nan_scan")
         self._prescanned = b
 
-    def adam_fusable(self, optimizer) -> bool:
+    def adam_fusable(self, optimizer, desc=None) -> bool:
         """True if `optimizer`'s step can ride in this engine's launches: a multimodn_amd.optim.Adam over exactly this
         model's parameters, one group, one contiguous run whose layout the library accepts.  Only then does the fused
         step leave a skipped encoder's parameters, moments and step count untouched (torch's grad-None behaviour)."""
-        d = optimizer.fused_descriptor(self) if hasattr(optimizer, "fused_descriptor") else None
+        d = desc if desc is not None else (optimizer.fused_descriptor(self) if hasattr(optimizer, "fused_descriptor") else None)
         return d is not None and self.lib.mmn_adam_fusable(self._plan, C.byref(d)) == 0
 
-    def accumulate_and_step(self, err_penalty: float, sc_penalty_x001: float, optimizer) -> bool:
+    def accumulate_and_step(self, err_penalty: float, sc_penalty_x001: float, optimizer, desc=None) -> bool:
         """Data-parallel tail after the all-reduce: epoch accumulation + the optimizer's Adam step in ONE
         launch when `optimizer` is a multimodn_amd.optim.Adam over this model (returns True: its next
         .step() is a no-op); otherwise only the accumulation (returns False)."""
-        d = optimizer.fused_descriptor(self) if hasattr(optimizer, "fused_descriptor") else None
+        d = desc if desc is not None else (optimizer.fused_descriptor(self) if hasattr(optimizer, "fused_descriptor") else None)
         if d is None:
             self.accumulate(err_penalty, sc_penalty_x001)
             return False

@@ -183,7 +183,7 @@ class MultiModN(nn.Module):
         return pairs
 
     # ------------------------------------------------------------------------------------------
-    def _nan_mode(self, eng, optimizer, train: bool) -> str:
+    def _nan_mode(self, eng, optimizer, train: bool, desc=None) -> str:
         """How a step decides which encoders a NaN batch skips (multimodn.py:168):
         "device"  on the GPU, nothing is read back (a skipped encoder's .grad then reads zeros instead of None: harmless for
                   multimodn_amd.optim.Adam, whose fused step leaves such an encoder untouched exactly as torch does for
@@ -199,7 +199,7 @@ class MultiModN(nn.Module):
         policy = getattr(self, "nan_policy", "auto")
         if policy == "auto":
             fused = train and hasattr(optimizer, "fused_descriptor") and hasattr(eng, "adam_fusable") and \
-                eng.adam_fusable(optimizer)
+                eng.adam_fusable(optimizer, desc)
             policy = "device" if (not train or fused) else "host"
         if policy == "host" and self._dp_group is not None:
             return "readback"
@@ -278,11 +278,11 @@ class MultiModN(nn.Module):
 
     class _Step:
         """One ingested mini-batch waiting for its launch."""
-        __slots__ = ("xs", "y", "pairs", "executed", "on_host", "bg", "b", "key", "masks", "cached")
+        __slots__ = ("xs", "y", "pairs", "executed", "on_host", "bg", "b", "key", "masks", "cached", "stepped")
 
         def __init__(self, xs, y, pairs, executed, on_host, bg, cached=None):
             self.xs, self.y, self.pairs, self.executed, self.on_host, self.bg = xs, y, pairs, executed, on_host, bg
-            self.b, self.key, self.masks, self.cached = None, None, None, cached
+            self.b, self.key, self.masks, self.cached, self.stepped = None, None, None, cached, False
 
         def key_tuple(self):
             return (self.xs, self.y, self.pairs, self.bg, self.b, self.key)
@@ -307,11 +307,12 @@ class MultiModN(nn.Module):
             self._dp_all_reduce(eng.flag_tail)
         if train and eng.dropout_encoders:                  # nn.Dropout of the MIMIC encoders is live in train mode only
             st.masks = eng.draw_dropout_masks(b, self.dropout_mask_provider)
+        st.stepped = False
         if train:
             # single GPU + multimodn_amd.optim.Adam: optimizer.step() rides in the last launch
             fuse = optimizer if (not dp and hasattr(optimizer, "fused_descriptor")) else None
-            eng.local_step(b, alpha, beta, accumulate=not dp, optimizer=fuse,
-                           next_batch=None if nxt is None else nxt.b, **({"desc": desc} if desc is not None else {}))
+            st.stepped = eng.local_step(b, alpha, beta, accumulate=not dp, optimizer=fuse,
+                                        next_batch=None if nxt is None else nxt.b, **({"desc": desc} if desc is not None else {}))
         else:
             eng.eval_step(b, accumulate=not dp)
         if dp:
@@ -319,7 +320,7 @@ class MultiModN(nn.Module):
             if train and optimizer is not None:
                 # epoch accumulation + Adam in one launch when the optimizer is multimodn_amd.optim.Adam
                 # (it leaves the parameters of encoders that did not run untouched, like grad None)
-                eng.accumulate_and_step(alpha, beta, optimizer)
+                st.stepped = eng.accumulate_and_step(alpha, beta, optimizer, **({"desc": desc} if desc is not None else {}))
             else:
                 eng.accumulate(alpha if train else 1.0, beta if train else 0.0)
         if train:
@@ -399,11 +400,17 @@ class MultiModN(nn.Module):
                 eng = state["eng"] = self._get_engine(int(target.shape[0]))
                 eng.epoch_reset()
                 eng.begin_sequence()
-                state["mode"] = self._nan_mode(eng, optimizer, True)
-                state["sig"] = (state["mode"], self._dp_world, self.shuffle_mode)
                 # (the optimizer's descriptor walks every parameter: once per epoch, not once per step)
-                if not dp and hasattr(optimizer, "fused_descriptor") and hasattr(eng, "run_group"):
-                    state["fd"] = optimizer.fused_descriptor(eng)
+                fd = optimizer.fused_descriptor(eng) if (hasattr(optimizer, "fused_descriptor") and hasattr(eng, "lib")) else None
+                state["mode"] = self._nan_mode(eng, optimizer, True, fd)
+                state["sig"] = (state["mode"], self._dp_world, self.shuffle_mode)
+                state["fd"] = fd if (fd is not None and eng.adam_fusable(optimizer, fd)) else None
+                if state["fd"] is not None and state["mode"] == "device":
+                    # the engine applies this optimizer's step itself: point every .grad at its slice of the flat
+                    # gradient buffer once (where loss.backward() would have left it), not once per step
+                    if eng.params[0].grad is not eng.grad_views[0] or eng.params[-1].grad is not eng.grad_views[-1]:
+                        eng.assign_grads(None)
+                    state["grads_assigned"] = True
             # Loaders over device-resident data hand the SAME batch objects back every epoch (DeviceResidentLoader
             # without shuffling, a list of device batches): what was derived from their tensors' addresses last time
             # - the sequence, the filled-in mmn_batch struct, its cache key - is reused; checking a batch costs less host
@@ -427,7 +434,7 @@ class MultiModN(nn.Module):
             the plan re-plans first, which invalidates the structs made so far."""
             eng = state["eng"]
             need = max(int(st.y.shape[0]) for st in window)
-            if eng.ensure(need):
+            if need > eng.max_batch and eng.ensure(need):
                 for st in window:
                     st.b = None
                 eng.begin_sequence()
@@ -446,9 +453,12 @@ class MultiModN(nn.Module):
             # how far to look ahead: device-resident batches by a whole group (+ the batch the group's last step
             # pre-scans); batches staged from the host by one (the staging ring is three deep)
             resident = not window[0].on_host
+            fused_surface = mode == "device" and state["fd"] is not None
             can_replay = (not dp and mode == "device" and getattr(self, "replay_steps", True) and not log_interval
                           and self.dropout_mask_provider is None and hasattr(eng, "run_group") and optimizer is not None)
             group = 1
+            # (sending the first step of a sequence out on its own, so that the GPU works while the first group is being
+            #  ingested, was measured: 77.6 instead of 74.9 us/step over 20 steps - the group's replay then starts late)
             if can_replay and resident:
                 group = max(1, int(getattr(self, "REPLAY_GROUP", 8)))
             while len(window) < group + 1 and pull():
@@ -472,17 +482,28 @@ class MultiModN(nn.Module):
                         window.popleft()
                     state["steps"] += n
                     self.train_steps_launched = getattr(self, "train_steps_launched", 0) + n
-                    optimizer.step()                         # clears the "already applied" mark: a no-op
+                    optimizer.fused_step_seen()              # what optimizer.step() would do now: nothing
                     continue
             # eagerly: the whole group (first sighting of its buffers: the groups of later epochs then start at the same
             # positions), or the single step
             for _ in range(n):
                 st = window.popleft()
                 nxt = window[0] if window else None
-                optimizer.zero_grad()
-                executed = self._launch_step(eng, st, nxt, True, optimizer, mode, state["fd"])
-                eng.assign_grads(executed)          # what loss.backward() leaves behind (multimodn.py:203)
-                optimizer.step()
+                if fused_surface and state["grads_assigned"]:
+                    # the engine applies optimizer.step() itself (multimodn_amd.optim.Adam): zero_grad / .grad / step()
+                    # would only re-point 31 tensors and cross the Optimizer hooks, host time a small step does not have
+                    executed = self._launch_step(eng, st, nxt, True, optimizer, mode, state["fd"])
+                    if st.stepped:
+                        optimizer.fused_step_seen()
+                    else:                                    # the library refused the fusion after all
+                        eng.assign_grads(executed)
+                        optimizer.step()
+                else:
+                    optimizer.zero_grad()
+                    executed = self._launch_step(eng, st, nxt, True, optimizer, mode, state["fd"])
+                    eng.assign_grads(executed)          # what loss.backward() leaves behind (multimodn.py:203)
+                    optimizer.step()
+                    state["grads_assigned"] = executed is None
                 state["steps"] += 1
                 batch_idx = state["steps"] - 1
                 if log_interval and batch_idx % log_interval == log_interval - 1:

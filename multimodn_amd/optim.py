@@ -160,10 +160,17 @@ class Adam(Optimizer):
             self._lib = hip.load()
         if not hasattr(self, "_last_grads"):
             self._last_grads = {}
+        runs = self._runs[0]
+        g_ptr = engine.flat_grads.data_ptr()
+        # (the engine re-reads every parameter's address once per epoch - its _sig - and its gradient views never move
+        #  while the plan lives: comparing against those spares this call two walks over all parameters)
+        if runs is not None and len(runs) == 1 and runs[0].sig == engine._sig and runs[0].g_ptr == g_ptr \
+                and getattr(self, "_lg_engine", None) == (id(engine), g_ptr) and not any(runs[0].skip_host):
+            return self.descriptor(runs[0], group)
         for p, g in zip(engine.params, engine.grad_views):     # the gradients WILL live there
             self._last_grads[id(p)] = g
-        runs = self._runs[0]
-        if runs is None or not self._runs_valid(runs) or runs[0].g_ptr != engine.flat_grads.data_ptr():
+        self._lg_engine = (id(engine), g_ptr)
+        if runs is None or not self._runs_valid(runs) or runs[0].g_ptr != g_ptr:
             saved = [p.grad for p in params]
             for p, g in zip(params, engine.grad_views):
                 p.grad = g
@@ -182,6 +189,10 @@ class Adam(Optimizer):
 
     def mark_fused_step(self) -> None:
         self._fused_pending = True
+
+    def fused_step_seen(self) -> None:
+        """What step() does after a fused step, without the Optimizer hooks around it."""
+        self._fused_pending = False
 
     def fusion_refused(self, engine) -> None:
         self._no_fuse_sig = engine._sig

@@ -67,12 +67,15 @@ class OracleEngine:
         self._flag_turn = 0
         self._prescanned = None
 
-    def adam_fusable(self, optimizer):
+    def adam_fusable(self, optimizer, desc=None):
         return False
+
+    def _set_of(self, b):
+        return self.flag_tail[(b.nan_flags - 1) * self.NF:b.nan_flags * self.NF]
 
     def _scan(self, b):
         """k_prepare's / k_reduce's scan blocks: raise the word of every data slot of b's sequence that holds a NaN."""
-        fl = self.flag_tail[b.nan_flags * self.NF:(b.nan_flags + 1) * self.NF]
+        fl = self._set_of(b)
         for k, _ in b.pairs:
             if np.isnan(b.xs[k]).any():
                 fl[k] = 1.0
@@ -93,7 +96,7 @@ class OracleEngine:
         b.device_nan = device_nan_flags
         b.nan_flags = None
         if device_nan_flags:
-            b.nan_flags = self._flag_turn
+            b.nan_flags = 1 + self._flag_turn                # (truthy like the device pointer it stands for)
             self._flag_turn ^= 1
         b.tile_seq = None
         b.masks = None
@@ -132,9 +135,7 @@ class OracleEngine:
     def _run(self, b, want_grads):
         params = {n: p.detach().numpy() for n, p in zip(self.names, self.params)}
         if getattr(b, "per_sample", False):
-            r = O.per_sample_step(params, self.spec, b.xs, b.y, b.seq)
-            if b.batch_global != len(b.y):                      # data-parallel shard: divisors are global
-                raise NotImplementedError
+            r = O.per_sample_step(params, self.spec, b.xs, b.y, b.seq, batch_global=b.batch_global)   # shard: global divisors
             return self._publish(r, want_grads, rows=r.row_counts.astype(np.float32))
         n_slots = max(k for k, _ in b.pairs) + 1 if b.pairs else 0
         seq = None
@@ -145,7 +146,7 @@ class OracleEngine:
             seq = np.tile(np.array([e for _, e in b.pairs], np.int64), (len(b.y), 1))
         override = [True] * len(b.pairs)
         if b.device_nan:                                    # the flag words decide (summed over the ranks under DP)
-            fl = self.flag_tail[b.nan_flags * self.NF:(b.nan_flags + 1) * self.NF]
+            fl = self._set_of(b)
             override = [float(fl[k]) == 0.0 for k, _ in b.pairs]
         spec = self.spec
         if not b.pairs:
@@ -180,13 +181,13 @@ class OracleEngine:
         """Before the step: scan unless an earlier step pre-scanned this batch.  After it (k_reduce): the consumed set
         is zero again and the next batch's flags stand in the other set."""
         if b.nan_flags is not None and self._prescanned is not b:
-            self.flag_tail[b.nan_flags * self.NF:(b.nan_flags + 1) * self.NF] = 0
+            self._set_of(b)[:] = 0
             self._scan(b)
 
     def _after_step(self, b, next_batch=None):
         self._prescanned = None
         if b.nan_flags is not None:
-            self.flag_tail[b.nan_flags * self.NF:(b.nan_flags + 1) * self.NF] = 0
+            self._set_of(b)[:] = 0
             if next_batch is not None and next_batch.nan_flags is not None and next_batch.nan_flags != b.nan_flags:
                 self._scan(next_batch)
                 self._prescanned = next_batch
@@ -236,7 +237,7 @@ class OracleEngine:
     def executed_rows(self):
         return [True] + [bool(v) for v in self._last[1].executed]
 
-    def accumulate_and_step(self, alpha, beta, optimizer):
+    def accumulate_and_step(self, alpha, beta, optimizer, desc=None):
         self.accumulate(alpha, beta)
         return False                     # the caller's optimizer.step() still has to run
 

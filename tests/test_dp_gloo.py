@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-from helpers import Golden, build_torch_model, rel_err
+from helpers import Golden, assert_within_fp32_noise, build_torch_model, fp64_trajectory, rel_err
 
 
 def _free_port():
@@ -21,7 +21,26 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, out_dir):
+def _count_collectives(dist):
+    """Every collective torch.distributed offers, counted: the protocol promises ONE all-reduce per step (+ one for the
+    first batch of an epoch, whose NaN flags no earlier step could carry)."""
+    calls = {"all_reduce": 0, "other": 0}
+    orig = dist.all_reduce
+
+    def counted(*a, **k):
+        calls["all_reduce"] += 1
+        return orig(*a, **k)
+    dist.all_reduce = counted
+    for name in ("broadcast", "all_gather", "reduce", "all_to_all", "reduce_scatter", "barrier", "all_gather_into_tensor"):
+        if hasattr(dist, name):
+            def other(*a, _f=getattr(dist, name), **k):
+                calls["other"] += 1
+                return _f(*a, **k)
+            setattr(dist, name, other)
+    return calls
+
+
+def _worker(rank, world, port, name, out_dir, policy="auto"):
     import torch.distributed as dist
     import multimodn_amd as mm
     from oracle_engine import OracleEngine
@@ -32,7 +51,9 @@ def _worker(rank, world, port, name, out_dir):
     g = Golden(name)
     model = build_torch_model(g.spec, g.init_params(), "cpu", mm)
     model._engine_factory = OracleEngine
+    model.nan_policy = policy
     model.enable_data_parallel()
+    calls = _count_collectives(dist)
     opt = torch.optim.Adam(list(model.parameters()), g.cfg["lr"])
     hist = mm.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
     loader = []
@@ -59,23 +80,41 @@ def _worker(rank, world, port, name, out_dir):
         model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=np.stack(hist.loss["train"]),
              acc=np.stack(hist.accuracy["train"]), sc=np.stack(hist.state_change_loss),
+             collectives=np.array([calls["all_reduce"], calls["other"], g.epochs * len(loader), g.epochs]),
              **{"p/" + k: v.numpy() for k, v in model.state_dict().items()})
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["seq_perm", "nan_skip", "mimic_drop"])
-def test_two_rank_dp_equals_single_process(name, tmp_path):
+def _check_collectives(r):
+    """[all-reduces, other collectives, steps, epochs]: one all-reduce per step - [grads | stats | the NEXT batch's NaN
+    flags] - plus one per epoch for the first batch's flags (the device decides the skips: nan_policy "device", and
+    "host" / "auto" under data parallel, which read the executed rows back instead of exchanging host flags)."""
+    n_ar, n_other, steps, epochs = (int(v) for v in r["collectives"])
+    assert n_other == 0
+    assert n_ar == steps + epochs, (n_ar, steps, epochs)
+
+
+@pytest.mark.parametrize("name,policy", [("seq_perm", "auto"), ("nan_skip", "auto"), ("nan_skip", "device"), ("mimic_drop", "auto")])
+def test_two_rank_dp_equals_single_process(name, policy, tmp_path):
     g = Golden(name)
-    mp.spawn(_worker, args=(2, _free_port(), name, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), name, str(tmp_path), policy), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     for k in r0.files:                                   # replicas stay bit-identical
         assert np.array_equal(r0[k], r1[k]), k
+    _check_collectives(r0)
+    if policy == "device" and name == "nan_skip":
+        # a foreign optimizer under the device policy sees ZERO gradients for a skipped encoder (documented deviation
+        # from grad None): History is the reference's, the skipped encoder's weights may move by Adam's momentum
+        z = g.z                                           # (rows fed by encoders that never skipped stay the reference's)
+        assert rel_err(r0["loss"][0][:2], z["hist/loss"][0][:2]) < 5e-6
+        return
     z = g.z
     assert rel_err(r0["loss"], z["hist/loss"]) < 5e-6
     assert rel_err(r0["sc"], z["hist/state_change"]) < 5e-6
     assert np.abs(r0["acc"] - z["hist/accuracy"]).max() <= 1.0 / g.cfg["B"] + 1e-12
+    w64 = fp64_trajectory(g)[0]                          # 2e-5 of the reference's weights, or within fp32 noise of the fp64 replay
     for n, w in g.final_params().items():
-        assert rel_err(r0["p/" + n], w) < 1e-4, n
+        assert_within_fp32_noise(r0["p/" + n], w, w64[n], n)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -95,6 +134,7 @@ def _gpu_worker(rank, world, port, name, policy, out_dir):
     model = build_torch_model(g.spec, g.init_params(), "cuda", mm)
     model.nan_policy = policy
     model.enable_data_parallel()
+    calls = _count_collectives(dist)
     opt = mm.optim.Adam(list(model.parameters()), g.cfg["lr"])
     hist = mm.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
     loader = []
@@ -120,6 +160,7 @@ def _gpu_worker(rank, world, port, name, policy, out_dir):
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=np.stack(hist.loss["train"]),
              acc=np.stack(hist.accuracy["train"]), sc=np.stack(hist.state_change_loss),
+             collectives=np.array([calls["all_reduce"], calls["other"], g.epochs * len(loader), g.epochs]),
              **{"p/" + k: v.cpu().numpy() for k, v in model.state_dict().items()})
     dist.destroy_process_group()
 
@@ -133,11 +174,35 @@ def test_two_rank_dp_on_one_gpu_equals_reference_golden(name, policy, tmp_path):
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     for k in r0.files:                                   # replicas stay bit-identical
         assert np.array_equal(r0[k], r1[k]), k
+    _check_collectives(r0)                               # ONE all-reduce per step (+ the first batch's flags per epoch)
     z = g.z
     assert rel_err(r0["loss"], z["hist/loss"]) < 1e-5
     assert rel_err(r0["sc"], z["hist/state_change"]) < 1e-5
     assert np.abs(r0["acc"] - z["hist/accuracy"]).max() <= 1.0 / g.cfg["B"] + 1e-12
     # (device policy: the one-launch tail leaves a skipped encoder's parameters untouched, like the
     #  reference's grad-None parameters, so the trained weights agree under both policies)
+    w64 = fp64_trajectory(g)[0]                          # 2e-5 of the reference's weights, or within fp32 noise of the fp64 replay
     for n, w in g.final_params().items():
-        assert rel_err(r0["p/" + n], w) < 1e-4, n
+        assert_within_fp32_noise(r0["p/" + n], w, w64[n], n)
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py --gpus 2 started as plain `python bench.py` (no launcher): the parent spawns the ranks itself.  Here both
+# ranks share the one GPU of the box over gloo (RCCL refuses two ranks per device); what is under test is the launch
+# path and the data-parallel step the driver's scaling run will time: MultiModN._train_steps with ONE all-reduce per step.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                          "--batch", "256", "--dist-backend", "gloo", "--share-gpu", "--preroll", "0.05", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 512
+    assert d["config"]["collectives_per_step"] == 1 and d["value"] > 0 and d["scaling"] == "weak"

@@ -7,15 +7,19 @@ Tolerances (fp32 path, BASELINE.json north_star: 1e-5 relative):
   * gradients of one step vs reference ................... 2e-5 of the tensor's max |g|
     (the reference's own fp32 grads sit ~3e-7 from fp64 truth; see tests/golden/make_golden.py)
   * History loss / state-change after training ........... 1e-5 relative
-  * trained weights ....................................... 1e-4 of the tensor's max |w|; Adam turns
-    1e-7 gradient differences into O(lr * 1e-3) weight differences on near-zero-gradient
-    coordinates (SURVEY.md section 7 "hard parts"), the oracle itself shows 1.5e-5 vs the reference.
+  * History accuracy / sensitivity / specificity / balanced accuracy: EQUAL to the reference's (ratios of integer
+    counts; helpers.assert_counts_match allows a count to move only by as many predictions as tie within 1e-6 in the
+    fp64 replay - none in any golden)
+  * trained weights ....................................... 2e-5 of the tensor's max |w| against the reference's, or -
+    where Adam has amplified rounding-size gradient differences beyond that (it divides by sqrt(v)) - no further from
+    the fp64 replay of the same run than 4x the reference's own fp32 run is (helpers.assert_within_fp32_noise)
 """
 import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN_NAMES, Golden, build_torch_model, rel_err
+from helpers import (GOLDEN_NAMES, Golden, assert_counts_match, assert_within_fp32_noise, build_torch_model,
+                     fp64_trajectory, rel_err)
 from oracle import multimodn_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -114,16 +118,16 @@ def test_training_matches_reference_golden(lib, name, optimizer):
     assert rel_err(np.stack(hist.state_change_loss), z["hist/state_change"]) < 1e-5
     acc = np.stack(hist.accuracy["train"])
     assert acc.dtype == np.float64 and hist.sensitivity["train"][0].dtype == np.float32
-    # counts are integers: a prediction can only flip when two sigmoids are within rounding
-    assert np.abs(acc - z["hist/accuracy"]).max() <= 1.0 / g.cfg["B"] + 1e-12
-    assert np.abs(np.stack(hist.balanced_accuracy["train"]) - z["hist/balanced_accuracy"]).max() < 0.05
+    # counts are integers: a prediction can only flip when its two sigmoids tie (none does in the goldens)
+    assert_counts_match(hist, z, g)
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    # Adam divides by sqrt(v): on coordinates whose gradient is ~0 a 1e-7 gradient difference moves
-    # the update by O(lr), so trained weights only agree to ~1e-4 of the tensor's max after tens of
-    # steps (the oracle itself sits 1.5e-5 from the reference; summation order alone moves 5e-5)
-    tol = 2e-3 if name == "c1_curve20" else 1e-4
+    # trained weights: within 2e-5 of the reference's, or as close to the fp64 replay of the run as the reference's own
+    # fp32 run is (x4): Adam divides by sqrt(v), so rounding-size gradient differences on near-zero-gradient
+    # coordinates become O(lr) weight differences in ANY fp32 implementation
+    w64, l64, s64 = fp64_trajectory(g)[:3]
     for n, w in g.final_params().items():
-        assert rel_err(sd[n], w) < tol, (n, rel_err(sd[n], w))
+        assert_within_fp32_noise(sd[n], w, w64[n], n)
+    assert_within_fp32_noise(np.stack(hist.loss["train"]), z["hist/loss"], l64, "History loss", tight=1e-5)
 
 
 KERNEL_MODES = {"fused8": ("1", "1", "1", "1"), "fast8": ("1", "1", "1", "0"), "par16": ("1", "1", "0", "0"),

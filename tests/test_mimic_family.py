@@ -5,12 +5,13 @@ dropout masks recorded from the reference's own nn.Dropout draws) and against th
 
 Tolerances as in tests/test_hip_parity.py: loss / grid 1e-5 relative, integer counters exact, gradients 2e-5 of
 the tensor's max |g| (5e-5 at batch 4096 against the fp64 oracle: 4096-term sums in another order), trained
-weights 1e-4 of max |w|."""
+weights 2e-5 of max |w| or within 4x the reference's own distance from the fp64 replay (helpers.assert_within_fp32_noise)."""
 import numpy as np
 import pytest
 import torch
 
-from helpers import MIMIC_GOLDEN_NAMES, Golden, build_torch_model, rel_err
+from helpers import (MIMIC_GOLDEN_NAMES, Golden, assert_counts_match, assert_within_fp32_noise, build_torch_model,
+                     fp64_trajectory, rel_err)
 from oracle import multimodn_oracle as O
 from test_hip_parity import check_against, lib  # noqa: F401  (fixture)
 
@@ -89,12 +90,12 @@ def test_training_matches_reference_golden(lib, name, optimizer):
     z = g.z
     assert rel_err(np.stack(hist.loss["train"]), z["hist/loss"]) < 1e-5
     assert rel_err(np.stack(hist.state_change_loss), z["hist/state_change"]) < 1e-5
-    acc = np.stack(hist.accuracy["train"])
-    assert np.abs(acc - z["hist/accuracy"]).max() <= 1.0 / g.cfg["B"] + 1e-12
+    assert_counts_match(hist, z, g)
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     assert list(sd.keys()) == [str(n) for n in z["param_names"]]          # the reference's state_dict keys, in order
+    w64 = fp64_trajectory(g)[0]
     for n, w in g.final_params().items():
-        assert rel_err(sd[n], w) < 1e-4, (n, rel_err(sd[n], w))
+        assert_within_fp32_noise(sd[n], w, w64[n], n)
 
 
 @pytest.mark.parametrize("name", MIMIC_GOLDEN_NAMES)
@@ -170,7 +171,7 @@ def test_replayed_steps_equal_eager_steps(lib, family):
             model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
         torch.cuda.synchronize()
         n_graphs = sum(1 for v in model._engine._step_graphs.values() if v[1] is not None)
-        assert (n_graphs >= 1) == replay                    # (the first step of an epoch goes out eagerly, the other four as one group)
+        assert (n_graphs >= 1) == replay                    # (the five steps of an epoch are one group)
         runs[replay] = (np.stack(hist.loss["train"]), np.stack(hist.state_change_loss),
                         {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()},
                         {k: v["step"].item() for k, v in list(opt.state.items())[:1]})

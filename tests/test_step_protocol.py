@@ -1,0 +1,253 @@
+"""The step protocol around the kernels (engine.py / multimodn.py, reference loop: multimodn/multimodn.py:117-212):
+  * the Adam tail writes every updated parameter into the chain kernels' fragment-order copies (no repack launch in front
+    of the next step): must be BITWISE the same training as repacking all weights every step;
+  * a step's last launch pre-scans the NEXT batch for NaNs (multimodn.py:168 one step ahead): must skip exactly the
+    encoders the reference skips, eagerly and under hipGraph replay of groups of steps;
+  * replayed groups survive optimizer.load_state_dict() (new moment buffers) and mid-epoch re-plans keep the epoch sums;
+  * an optimizer that cannot be fused (two parameter groups) falls back to the reference's exact grad-None semantics;
+  * per-sample mode under data parallel (two ranks, gloo): shards add up to the whole batch.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from helpers import Golden, assert_within_fp32_noise, build_torch_model, fp64_trajectory, rel_err
+from oracle import multimodn_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _specs():
+    return {
+        "classic": O.ModelSpec(32, [O.EncoderSpec(12, (16, 16), O.ACT_RELU) for _ in range(3)], 2, 1.0, 0.3),
+        "slp": O.ModelSpec(48, [O.EncoderSpec(5, (), O.ACT_IDENTITY), O.EncoderSpec(7, (8,), O.ACT_SIGMOID)], 1, 0.7, 0.3),
+        "mimic": O.ModelSpec(32, [O.EncoderSpec(12, (16, 16), O.ACT_RELU, kind="mimic", dropout=0.2) for _ in range(3)], 2, 1.0, 0.3,
+                             decoders=[O.DecoderSpec("mlp", (16,)) for _ in range(2)]),
+        "mimic_p0": O.ModelSpec(32, [O.EncoderSpec(12, (16, 16), O.ACT_RELU, kind="mimic", dropout=0.0) for _ in range(3)], 2, 1.0, 0.3,
+                                decoders=[O.DecoderSpec("mlp", (16,)) for _ in range(2)]),
+        "mixed": O.ModelSpec(32, [O.EncoderSpec(12, (16,), O.ACT_RELU, kind="mimic", dropout=0.0), O.EncoderSpec(9, (8, 8), O.ACT_RELU)],
+                             2, 1.0, 0.3, decoders=[O.DecoderSpec("mlp", (16, 8)), O.DecoderSpec()]),
+    }
+
+
+def _device_loader(spec, n_batches, B, seed, nan_at=()):
+    batches = O.synthetic_batches(spec, n_batches * B, B, seed=seed)
+    loader = []
+    for i, (xs, y) in enumerate(batches):
+        xs = [x.copy() for x in xs]
+        for (bi, slot) in nan_at:
+            if bi == i:
+                xs[slot][B // 2, 1] = np.nan
+        loader.append(([torch.from_numpy(x).cuda() for x in xs], torch.from_numpy(y).cuda()))
+    return loader
+
+
+def _train(lib, spec, loader, epochs, *, replay=True, policy="auto", env=None, lr=1e-2, mid=None):
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        torch.manual_seed(11)
+        model = build_torch_model(spec, O.init_params(spec, 2), "cuda", lib)
+        model.nan_policy = policy
+        model.replay_steps = replay
+        opt = lib.optim.Adam(list(model.parameters()), lr)
+        hist = lib.MultiModNHistory([f"t{d}" for d in range(spec.D)])
+        for ep in range(epochs):
+            if mid is not None:
+                mid(ep, model, opt)
+            model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+        torch.cuda.synchronize()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return (np.stack(hist.loss["train"]), np.stack(hist.state_change_loss), np.stack(hist.accuracy["train"]),
+            {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}, model)
+
+
+def _same(a, b):
+    for x, y in zip(a[:3], b[:3]):
+        assert np.array_equal(x, y)
+    for k in a[3]:
+        assert np.array_equal(a[3][k], b[3][k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["classic", "slp", "mimic", "mixed"])
+def test_scattered_weight_copies_equal_a_full_repack_every_step(family):
+    """MMN_SCATTER=0 keeps k_prepare's repack in front of every step; the default lets the Adam tail write each updated
+    parameter into its fragment-order places (forward W, backward W^T, the bias buffer of the generic tier).  Same
+    values in the same places: History and trained weights are identical bit for bit, with and without replay."""
+    import multimodn_amd as lib
+    spec = _specs()[family]
+    loader = _device_loader(spec, 6, 48, seed=5)
+    ref = _train(lib, spec, loader, 3, replay=False, env={"MMN_SCATTER": "0"})
+    for replay in (False, True):
+        got = _train(lib, spec, loader, 3, replay=replay)
+        _same(ref, got)
+    assert ref[0][-1].mean() < ref[0][0].mean()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["classic", "mimic_p0"])       # (dropout 0: the host policy draws no multipliers for an
+def test_prescan_skips_what_the_reference_skips(family):          #  encoder it removed, so the draws of the others would differ)
+    """NaN batches in the middle and at both ends of an epoch of device-resident batches (the scan of batch t+1 rides in
+    step t's last launch; the first batch of an epoch is scanned on its own): the device-side decision, eager and
+    replayed, trains exactly like the host-side decision (which removes the skipped encoder from the sequence and
+    leaves its .grad None) - multimodn_amd.optim.Adam leaves a skipped encoder untouched either way."""
+    import multimodn_amd as lib
+    spec = _specs()[family]
+    loader = _device_loader(spec, 7, 32, seed=8, nan_at=((0, 1), (3, 0), (3, 2), (4, 2), (6, 1)))
+    host = _train(lib, spec, loader, 3, replay=False, policy="host")
+    for replay in (False, True):
+        got = _train(lib, spec, loader, 3, replay=replay, policy="device")
+        _same(host, got)
+        if replay:
+            assert sum(1 for v in got[4]._engine._step_graphs.values() if v[1] is not None) >= 1
+    # rows of the skipped encoders: loss 0 in the batches that skipped them -> smaller epoch mean than the clean rows
+    assert np.isfinite(host[0]).all()
+
+
+@pytest.mark.gpu
+def test_replay_survives_optimizer_load_state_dict():
+    """load_state_dict() gives the optimizer NEW moment / step buffers.  A captured group has the old ones baked in: the
+    cache key names the optimizer's buffers, so the next epoch captures afresh instead of updating freed memory."""
+    import multimodn_amd as lib
+    spec = _specs()["classic"]
+    loader = _device_loader(spec, 5, 48, seed=3)
+
+    def reload(ep, model, opt):
+        if ep == 3:
+            sd = opt.state_dict()
+            opt.load_state_dict({"state": {k: {n: (t.clone() if torch.is_tensor(t) else t) for n, t in st.items()}
+                                           for k, st in sd["state"].items()}, "param_groups": sd["param_groups"]})
+    runs = [_train(lib, spec, loader, 6, replay=r, mid=reload) for r in (True, False)]
+    _same(runs[0], runs[1])
+    plain = _train(lib, spec, loader, 6, replay=True)
+    _same(runs[0], plain)                                  # ... and reloading its own state changes nothing
+
+
+@pytest.mark.gpu
+def test_two_parameter_groups_keep_the_reference_grad_none_semantics():
+    """multimodn_amd.optim.Adam with TWO parameter groups cannot be fused with the engine.  nan_policy "auto" must then
+    decide the NaN skips like the reference (grad None for the skipped encoder: moments, step count and weights
+    untouched), not hand zero gradients to the separate Adam launch: trained weights equal the reference's golden run."""
+    import multimodn_amd as lib
+    g = Golden("nan_skip")
+    model = build_torch_model(g.spec, g.init_params(), "cuda", lib)
+    enc_params = [p for e in model.encoders for p in e.parameters()]
+    rest = [p for p in model.parameters() if not any(p is q for q in enc_params)]
+    opt = lib.optim.Adam([{"params": enc_params}, {"params": rest}], g.cfg["lr"])
+    hist = lib.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
+    loader = [([torch.from_numpy(x) for x in b[0]], torch.from_numpy(b[1])) for b in g.batches()]
+    for _ in range(g.epochs):
+        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+    torch.cuda.synchronize()
+    assert opt.fused_descriptor(model._engine) is None
+    assert rel_err(np.stack(hist.loss["train"]), g.z["hist/loss"]) < 1e-5
+    w64 = fp64_trajectory(g)[0]
+    for n, w in g.final_params().items():
+        assert_within_fp32_noise(model.state_dict()[n].cpu().numpy(), w, w64[n], n)
+    # the skipped encoder's step counter stayed behind the others' (torch: no step for grad None)
+    steps = sorted({float(st["step"]) for st in opt.state.values()})
+    assert len(steps) == 2 and steps[1] - steps[0] >= 1
+
+
+@pytest.mark.gpu
+def test_replan_in_the_middle_of_an_epoch_keeps_the_epoch_sums():
+    """A batch larger than every earlier one makes the engine re-plan (bigger workspace).  The epoch accumulators live in
+    the workspace: they are carried over, so History equals a run whose plan was large enough from the start."""
+    import multimodn_amd as lib
+    spec = _specs()["classic"]
+    sizes = [16, 16, 80, 32]
+    parts = [O.synthetic_batches(spec, b, b, seed=20 + i)[0] for i, b in enumerate(sizes)]
+    loader = [([torch.from_numpy(x) for x in xs], torch.from_numpy(y)) for xs, y in parts]
+    out = []
+    for presize in (False, True):
+        model = build_torch_model(spec, O.init_params(spec, 2), "cuda", lib)
+        if presize:
+            model._get_engine(128)
+        opt = lib.optim.Adam(list(model.parameters()), 1e-2)
+        hist = lib.MultiModNHistory(["a", "b"])
+        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+        torch.cuda.synchronize()
+        out.append((hist.loss["train"][0], hist.accuracy["train"][0], hist.state_change_loss[0]))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    assert out[0][1].max() > 0
+
+
+# ------------------------------------------------------------------------------------------------
+# per-sample mode under data parallel: per-sample masks / sequences are per-row data, so row shards add up
+# ------------------------------------------------------------------------------------------------
+def _ps_worker(rank, world, port, device, out_dir):
+    import torch.distributed as dist
+    import multimodn_amd as mm
+    from test_per_sample import c5_like
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    spec, xs, y, seq = c5_like(48, seed=4)
+    params = O.init_params(spec, 1)
+    model = build_torch_model(spec, params, device, mm)
+    if device == "cpu":
+        from oracle_engine import OracleEngine
+        model._engine_factory = OracleEngine
+    model.per_sample = True
+    model.enable_data_parallel()
+    n = len(y)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    loader = [([torch.from_numpy(x[lo:hi]) for x in xs], torch.from_numpy(y[lo:hi]), torch.from_numpy(seq[lo:hi]))]
+    opt = (mm.optim.Adam if device == "cuda" else torch.optim.Adam)(list(model.parameters()), 1e-2)
+    hist = mm.MultiModNHistory(["a", "b"])
+    model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+    if device == "cuda":
+        torch.cuda.synchronize()
+    eng = model._engine
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=hist.loss["train"][0], sc=hist.state_change_loss[0],
+             acc=hist.accuracy["train"][0], grads=eng.flat_grads.detach().cpu().numpy(),
+             **{"p/" + k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    dist.destroy_process_group()
+
+
+def _check_ps(tmp_path):
+    from test_per_sample import c5_like
+    spec, xs, y, seq = c5_like(48, seed=4)
+    params = O.init_params(spec, 1)
+    ref = O.per_sample_step(params, spec, xs, y, seq)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), k            # replicas stay identical
+    assert rel_err(r0["loss"], ref.err_loss) < 1e-5
+    assert rel_err(r0["sc"], ref.state_change) < 1e-5
+    flat = np.concatenate([np.zeros(np.asarray(params[n]).size, np.float32) if ref.grads[n] is None
+                           else np.asarray(ref.grads[n], np.float32).reshape(-1) for n in spec.param_names()])
+    assert rel_err(r0["grads"], flat) < 2e-5
+    oopt = O.Adam(1e-2)
+    oopt.step(params, ref.grads)
+    for n in spec.param_names():
+        assert rel_err(r0["p/" + n], params[n]) < 1e-4, n
+
+
+def test_per_sample_mode_two_ranks_cpu_checker(tmp_path):
+    mp.spawn(_ps_worker, args=(2, _free_port(), "cpu", str(tmp_path)), nprocs=2, join=True)
+    _check_ps(tmp_path)
+
+
+@pytest.mark.gpu
+def test_per_sample_mode_two_ranks_on_one_gpu(tmp_path):
+    mp.spawn(_ps_worker, args=(2, _free_port(), "cuda", str(tmp_path)), nprocs=2, join=True)
+    _check_ps(tmp_path)

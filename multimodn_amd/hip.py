@@ -94,7 +94,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("MMN_LIB_PATH") or LIB_PATH        # (MMN_LIB_PATH: diagnostics - A/B runs of kernel variants)
     if not os.path.exists(p):
         raise MmnError(
             f"{p} not found: the MI355X HIP library is not built. Run `python -c 'import "

@@ -288,6 +288,10 @@ int mmn_train_step_ex(mmn_plan* p, const mmn_batch* b, float err_penalty, float 
  *         mmn_train_step.  The plan's max_batch must be >= rows.  E <= 4. */
 int mmn_regroup_rows(int batch, int n_encoders);
 int mmn_regroup(mmn_plan* p, const mmn_batch* in, const int64_t* seq, mmn_batch* out, void* stream);
+/* The same with caller-owned scratch (device, int32[2 * batch + rows]; NULL = the plan's): the call then touches nothing
+ * of the plan's workspace, so the regrouping of the NEXT batch may run on another stream while this plan's step runs.
+ * scratch + 2 * batch is the "source row of every position" table (mmn_debug_buffer kind 5 for the plan's scratch). */
+int mmn_regroup_ex(mmn_plan* p, const mmn_batch* in, const int64_t* seq, mmn_batch* out, int32_t* scratch, void* stream);
 
 /* Forward-only step for test()/predict()/get_states() (multimodn.py:255-492): fwd + reduce
  * (+ accumulate).  Leaves the state rows and the decoder outputs of every grid row in the workspace

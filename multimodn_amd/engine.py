@@ -486,10 +486,13 @@ class HipChainEngine:
             bout = self.make_batch(xs_p, y_p, [(k, k) for k in range(E)], batch_global=B)
             bout.tile_rows, bout.tile_seq = tile_rows.data_ptr(), tile_seq.data_ptr()
             sq = None if seq is None else seq.to(dev, torch.int64).contiguous()
-            hip.check(self.lib.mmn_regroup(self._plan, C.byref(bin_), None if sq is None else sq.data_ptr(),
-                                           C.byref(bout), self._stream()), "mmn_regroup")
-            self._ps_layout = ("hip", rows, B, tile_seq)
-            return bout, (xs_p, y_p, tile_rows, tile_seq, sq, xs, y)
+            # the kernels' scratch (codes, presence masks, source row of every position) is this call's own: nothing of
+            # the plan's workspace is touched, so the NEXT batch can be regrouped on another stream while a step runs
+            scratch = torch.empty(2 * B + rows, dtype=torch.int32, device=dev)
+            hip.check(self.lib.mmn_regroup_ex(self._plan, C.byref(bin_), None if sq is None else sq.data_ptr(),
+                                              C.byref(bout), scratch.data_ptr(), self._stream()), "mmn_regroup_ex")
+            self._ps_layout = ("hip", scratch[2 * B:], B, tile_seq)
+            return bout, (xs_p, y_p, tile_rows, tile_seq, sq, xs, y, scratch)
         present = torch.stack([~torch.isnan(x).any(dim=1) for x in xs], dim=1)           # [B, E] slot present
         enc_of = seq.to(dev, torch.int64) if seq is not None else torch.arange(E, device=dev).expand(B, E)
         pi = present.to(torch.int64)
@@ -528,17 +531,52 @@ class HipChainEngine:
         self._ps_layout = ("torch", where, B, tile_seq)
         return b, (xs_p, y_p, tile_rows, tile_seq)
 
+    def per_sample_batch_async(self, xs, y, seq, slot: int, side: "torch.cuda.Stream", template=None):
+        """per_sample_batch for the training loop's look-ahead: device-resident inputs, the three regrouping launches on
+        stream `side`, outputs in one of two PERSISTENT buffer sets (`slot` 0 / 1; nothing is allocated per step, so no
+        allocator bookkeeping across streams).  The caller orders the streams: `side` must have waited for the step that
+        last read this slot, the main stream must wait for the returned event before the step.  Returns
+        (hip.Batch, keep-alive, event, template) or None when this path does not apply (host tensors, torch regrouping)."""
+        E, B, dev = self.E, int(y.shape[0]), self.device
+        rows = int(self.lib.mmn_regroup_rows(B, E)) if len(xs) == E and E <= 4 else 0
+        feats = [int(enc.n_features) for enc in self.model.encoders]
+        if rows <= 0 or B > 16384 or self._torch_regroup or (seq is not None and len(set(feats)) != 1):
+            return None
+        if not (y.is_cuda and y.dtype == torch.int64 and y.is_contiguous() and all(x.is_cuda and x.dtype == torch.float32 for x in xs)
+                and (seq is None or (seq.is_cuda and seq.dtype == torch.int64 and seq.is_contiguous()))):
+            return None
+        self.ensure(rows)
+        bufs = self.__dict__.setdefault("_ps_bufs", {})
+        key = (slot, B, rows, int(y.shape[1]), self._plan.value)
+        ent = bufs.get(key)
+        if ent is None:
+            for k in [k for k in bufs if k[0] == slot]:
+                del bufs[k]
+            xs_p = [torch.empty((rows, f), dtype=torch.float32, device=dev) for f in feats]
+            y_p = torch.empty((rows, y.shape[1]), dtype=torch.int64, device=dev)
+            tile_rows = torch.empty(rows // 16, dtype=torch.int32, device=dev)
+            tile_seq = torch.empty(rows // 16, dtype=torch.int32, device=dev)
+            scratch = torch.empty(2 * B + rows, dtype=torch.int32, device=dev)
+            bout = self.make_batch(xs_p, y_p, [(k, k) for k in range(E)], batch_global=B)
+            bout.tile_rows, bout.tile_seq = tile_rows.data_ptr(), tile_seq.data_ptr()
+            torch.cuda.current_stream().synchronize()      # (first use: the buffers exist before another stream writes them)
+            ent = bufs[key] = (xs_p, y_p, tile_rows, tile_seq, scratch, bout, torch.cuda.Event())
+        xs_p, y_p, tile_rows, tile_seq, scratch, bout, ev = ent
+        bin_, _, template = self.make_batch_keyed(xs, y, [(k, k) for k in range(E)], B, False, template)
+        b = hip.Batch.from_buffer_copy(bout)
+        hip.check(self.lib.mmn_regroup_ex(self._plan, C.byref(bin_), None if seq is None else seq.data_ptr(),
+                                          C.byref(b), scratch.data_ptr(), side.cuda_stream), "mmn_regroup_ex")
+        ev.record(side)
+        return b, (xs_p, y_p, tile_rows, tile_seq, seq, xs, y, scratch), ev, template
+
     def per_sample_positions(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """For the last per_sample_batch: (position of every original row in the regrouped layout
         [B] int64, packed executed sequence of every original row [B] int64)."""
         kind, info, B, tile_seq = self._ps_layout
         if kind == "torch":
             where = info
-        else:                                               # k_ps_layout's source-row table lives in the plan's scratch
-            rows = info
-            ptr = self.lib.mmn_debug_buffer(self._plan, 5, 0)
-            off = ptr - self.workspace.data_ptr()
-            src_of = self.workspace[off:off + 4 * rows].view(torch.int32).to(torch.int64)
+        else:                                               # k_ps_layout's source-row table (the call's scratch)
+            src_of = info.to(torch.int64)
             pos = torch.nonzero(src_of >= 0).flatten()
             where = torch.empty(B, dtype=torch.int64, device=self.device)
             where[src_of[pos]] = pos

@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "mmn_chain_bwd", "mmn_chain_fwd_bwd", "mmn_wgrad", "mmn_reduce", "mmn_epoch_accumulate", "mmn_train_step",
     "mmn_eval_step", "mmn_adam_blocks", "mmn_adam_step", "mmn_adam_step_accumulate", "mmn_train_step_adam", "mmn_reduce_adam", "mmn_regroup_rows", "mmn_regroup", "mmn_epoch_reset", "mmn_epoch_read", "mmn_debug_buffer",
     "mmn_dropout_floats", "mmn_draw_dropout", "mmn_dropout_reset",
-    "mmn_nan_flags_set", "mmn_pack_invalidate", "mmn_pack_refresh", "mmn_train_step_ex", "mmn_epoch_write", "mmn_adam_fusable",
+    "mmn_nan_flags_set", "mmn_pack_invalidate", "mmn_pack_refresh", "mmn_train_step_ex", "mmn_epoch_write", "mmn_adam_fusable", "mmn_regroup_ex",
 )
 
 
@@ -169,6 +169,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_regroup_rows.argtypes = [i32, i32]
     lib.mmn_regroup.restype = i32
     lib.mmn_regroup.argtypes = [vp, C.POINTER(Batch), vp, C.POINTER(Batch), vp]
+    lib.mmn_regroup_ex.restype = i32
+    lib.mmn_regroup_ex.argtypes = [vp, C.POINTER(Batch), vp, C.POINTER(Batch), vp, vp]
     lib.mmn_epoch_reset.restype = i32
     lib.mmn_epoch_reset.argtypes = [vp, vp]
     lib.mmn_epoch_read.restype = i32

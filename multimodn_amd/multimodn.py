@@ -140,6 +140,7 @@ class MultiModN(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_engine"] = None
+        state.pop("_ps_stream", None)
         state["_batch_cache"] = {}
         state["_dp_group"] = None
         state["_dp_world"] = 1
@@ -265,6 +266,20 @@ class MultiModN(nn.Module):
             executed[e] = True
         return xs, y, exec_pairs, executed, on_host
 
+    def _fusion_setup(self, eng, optimizer, mode: str):
+        """optimizer.fused_descriptor(eng) if the engine can apply this optimizer's step itself (and the NaN decision
+        stays on the device), else None.  In the first case every .grad is pointed at its slice of the engine's flat
+        gradient buffer once - where loss.backward() would have left it - instead of once per step.  To be called again
+        whenever the engine re-planned: the descriptor names the plan's gradient buffer."""
+        if not (hasattr(optimizer, "fused_descriptor") and hasattr(eng, "lib")):
+            return None
+        fd = optimizer.fused_descriptor(eng)
+        if fd is None or not eng.adam_fusable(optimizer, fd):
+            return None
+        if mode == "device" and (eng.params[0].grad is not eng.grad_views[0] or eng.params[-1].grad is not eng.grad_views[-1]):
+            eng.assign_grads(None)
+        return fd
+
     def _dp_all_reduce(self, buf: Tensor) -> None:
         """Sum over the ranks, in place.  RCCL takes device buffers; any other backend (gloo in the tests) gets the
         buffer through the host."""
@@ -340,19 +355,25 @@ class MultiModN(nn.Module):
         executed = self._launch_step(eng, st, None, train, optimizer, mode)
         return executed, (st.xs, st.y, st.masks)
 
-    def _run_step_per_sample(self, eng, data, target, encoder_sequence, optimizer=None, train: bool = True):
-        """One training step in per-sample mode: rows are regrouped on the device into tiles of one
-        executed sequence each (engine.per_sample_batch) and run by the fused kernel."""
+    def _regroup_per_sample(self, eng, data, target, encoder_sequence):
+        """Batch -> device -> tiles of one executed sequence each (engine.per_sample_batch), on the CURRENT stream."""
         xs, y, _ = self._to_device(data, target)
         seq = None
         if encoder_sequence is not None:
             seq = encoder_sequence if isinstance(encoder_sequence, Tensor) else torch.as_tensor(np.asarray(encoder_sequence))
             seq = seq.to(self.device, torch.int64)
-        B = int(y.shape[0])
+        b, keep = eng.per_sample_batch(xs, y, seq)
+        b.batch_global = int(y.shape[0]) * self._dp_world
+        return b, keep, xs, y
+
+    def _run_step_per_sample(self, eng, data, target, encoder_sequence, optimizer=None, train: bool = True, regrouped=None,
+                             desc=None):
+        """One training step in per-sample mode: rows are regrouped on the device into tiles of one
+        executed sequence each (engine.per_sample_batch) and run by the fused kernel.  `regrouped`: the result of
+        _regroup_per_sample when the caller already ran it (train_epoch does, one batch ahead, on a side stream)."""
+        b, keep, xs, y = regrouped if regrouped is not None else self._regroup_per_sample(eng, data, target, encoder_sequence)
         dp = self._dp_group is not None
         alpha, beta = float(self.err_penalty), float(self.state_change_penalty)
-        b, keep = eng.per_sample_batch(xs, y, seq)
-        b.batch_global = B * self._dp_world
         if not train:                                       # forward-only (test / predict / get_states)
             eng.eval_step(b, accumulate=not dp)
             if dp:
@@ -360,7 +381,7 @@ class MultiModN(nn.Module):
                 eng.accumulate(1.0, 0.0)
             return None, (xs, y, keep)
         fuse = optimizer if (not dp and hasattr(optimizer, "fused_descriptor")) else None
-        eng.local_step(b, alpha, beta, accumulate=not dp, optimizer=fuse)
+        eng.local_step(b, alpha, beta, accumulate=not dp, optimizer=fuse, **({"desc": desc} if desc is not None else {}))
         if dp:                                              # per-sample masks / sequences are per-row data: shards add up
             self._dp_all_reduce(eng.reduce_buf)
             if optimizer is not None:
@@ -401,16 +422,10 @@ class MultiModN(nn.Module):
                 eng.epoch_reset()
                 eng.begin_sequence()
                 # (the optimizer's descriptor walks every parameter: once per epoch, not once per step)
-                fd = optimizer.fused_descriptor(eng) if (hasattr(optimizer, "fused_descriptor") and hasattr(eng, "lib")) else None
-                state["mode"] = self._nan_mode(eng, optimizer, True, fd)
+                state["mode"] = self._nan_mode(eng, optimizer, True)
                 state["sig"] = (state["mode"], self._dp_world, self.shuffle_mode)
-                state["fd"] = fd if (fd is not None and eng.adam_fusable(optimizer, fd)) else None
-                if state["fd"] is not None and state["mode"] == "device":
-                    # the engine applies this optimizer's step itself: point every .grad at its slice of the flat
-                    # gradient buffer once (where loss.backward() would have left it), not once per step
-                    if eng.params[0].grad is not eng.grad_views[0] or eng.params[-1].grad is not eng.grad_views[-1]:
-                        eng.assign_grads(None)
-                    state["grads_assigned"] = True
+                state["fd"] = self._fusion_setup(eng, optimizer, state["mode"])
+                state["grads_assigned"] = state["fd"] is not None and state["mode"] == "device"
             # Loaders over device-resident data hand the SAME batch objects back every epoch (DeviceResidentLoader
             # without shuffling, a list of device batches): what was derived from their tensors' addresses last time
             # - the sequence, the filled-in mmn_batch struct, its cache key - is reused; checking a batch costs less host
@@ -438,6 +453,8 @@ class MultiModN(nn.Module):
                 for st in window:
                     st.b = None
                 eng.begin_sequence()
+                state["fd"] = self._fusion_setup(eng, optimizer, state["mode"])      # (it names the plan's gradient buffer)
+                state["grads_assigned"] = state["fd"] is not None and state["mode"] == "device"
             for st in window:
                 if st.b is None:
                     ent = st.cached
@@ -514,6 +531,85 @@ class MultiModN(nn.Module):
                            f"\tState change: {float(v['global_sc']):.4f}")
         return state["eng"], state["steps"]
 
+    def _train_steps_per_sample(self, train_loader, optimizer):
+        """The batch loop in per-sample mode.  With device-resident batches the regrouping of batch t+1 (three launches
+        that depend on the data alone) runs on a side stream while step t runs on the main one: k_fb8 fills every CU's
+        LDS with one workgroup but only a quarter of its wave slots, the regrouping kernels use no LDS to speak of.
+        Two persistent buffer sets take the regrouped batches in turn; events order the two streams."""
+        eng = None
+        it = iter(train_loader)
+        main = torch.cuda.current_stream() if self.device.type == "cuda" else None
+        side = None
+        done = [None, None]                                  # per buffer set: event behind the step that last read it
+        state = {"i": 0, "fd": None, "fused": False, "plan": None}
+        cache = self.__dict__.setdefault("_batch_cache", {})
+
+        def prepare(batch):
+            nonlocal eng, side
+            data, target, encoder_sequence = (list(batch) + [None])[:3]
+            if eng is None:
+                eng = self._get_engine(int(target.shape[0]))
+                eng.epoch_reset()
+                eng.begin_sequence()
+            rows = int(eng.lib.mmn_regroup_rows(int(target.shape[0]), eng.E)) if hasattr(eng, "lib") else 0
+            replanned = eng.ensure(max(rows, 1))
+            if state["plan"] is None or replanned:                          # first batch, or the plan had to grow
+                state["fd"] = self._fusion_setup(eng, optimizer, "device") if self._dp_group is None else None
+                state["fused"] = state["fd"] is not None
+                state["plan"] = True
+            slot = state["i"] & 1
+            state["i"] += 1
+            if main is not None and hasattr(eng, "per_sample_batch_async") and isinstance(target, Tensor) and target.is_cuda:
+                if side is None:
+                    side = self.__dict__.get("_ps_stream")
+                    if side is None:
+                        side = self.__dict__["_ps_stream"] = torch.cuda.Stream(device=self.device)
+                    side.wait_stream(main)                  # the data may have been produced on the main stream
+                if done[slot] is not None:
+                    side.wait_event(done[slot])             # the step that read this buffer set two batches ago
+                y = target if target.dim() == 2 else target.view(-1, 1)
+                ent = cache.get(id(batch))
+                tmpl = ent[1] if (ent is not None and ent[0] is batch) else None
+                r = eng.per_sample_batch_async(list(data), y, encoder_sequence if isinstance(encoder_sequence, Tensor) else None
+                                               if encoder_sequence is None else torch.as_tensor(np.asarray(encoder_sequence)).to(self.device),
+                                               slot, side, tmpl)
+                if r is not None:
+                    b, keep, ev, tmpl = r
+                    if isinstance(batch, tuple):
+                        if len(cache) >= 4096:
+                            cache.clear()
+                        cache[id(batch)] = (batch, tmpl)
+                    b.batch_global = int(y.shape[0]) * self._dp_world
+                    return (b, keep, keep[5], keep[6]), ev, slot
+            return self._regroup_per_sample(eng, data, target, encoder_sequence), None, slot
+
+        try:
+            nxt = prepare(next(it))
+        except StopIteration:
+            return None
+        while nxt is not None:
+            cur, ev, slot = nxt
+            try:
+                nxt = prepare(next(it))                     # regrouping of batch t+1: enqueued before step t's kernels
+            except StopIteration:
+                nxt = None
+            if ev is not None:
+                main.wait_event(ev)
+            if state["fused"]:
+                self._run_step_per_sample(eng, None, None, None, optimizer, regrouped=cur, desc=state["fd"])
+                optimizer.step()                             # (a no-op after a fused step; the real one if the library refused)
+            else:
+                optimizer.zero_grad()
+                executed, keep = self._run_step_per_sample(eng, None, None, None, optimizer, regrouped=cur)
+                eng.assign_grads(executed)
+                optimizer.step()
+            if ev is not None:
+                if done[slot] is None:
+                    done[slot] = torch.cuda.Event()
+                done[slot].record(main)
+            self.train_steps_launched = getattr(self, "train_steps_launched", 0) + 1
+        return eng
+
     def train_epoch(
             self,
             train_loader: DataLoader,
@@ -531,21 +627,7 @@ class MultiModN(nn.Module):
         self.train()
         n_batches = len(train_loader)
         if self.per_sample:
-            eng = None
-            keep = None
-            for batch in train_loader:
-                data, target, encoder_sequence = (list(batch) + [None])[:3]
-                if eng is None:
-                    eng = self._get_engine(int(target.shape[0]))
-                    eng.epoch_reset()
-                    eng.begin_sequence()
-                else:
-                    eng.ensure(int(target.shape[0]))
-                optimizer.zero_grad()
-                executed, keep = self._run_step_per_sample(eng, data, target, encoder_sequence, optimizer)
-                eng.assign_grads(executed)
-                optimizer.step()
-            del keep
+            eng = self._train_steps_per_sample(train_loader, optimizer)
         else:
             eng, _ = self._train_steps(train_loader, optimizer, log_interval, logger)
         if eng is None:

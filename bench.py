@@ -151,18 +151,25 @@ def cpu_match(O, mm, w, device, batch_size, steps=3):
     """The metric's second half, "CPU-match delta-loss": the HIP path and the CPU oracle take the same
     `steps` training steps (same initial weights, same batches, Adam) at the workload's full size;
     reported are the largest relative difference of the (E+1) x D loss grid over the steps and of
-    the trained weights (relative to each tensor's max).  Target: <= 1e-5 on the loss."""
+    the trained weights (relative to each tensor's max).  Target: <= 1e-5 on the loss.
+
+    Trained weights additionally against the yardstick that does not depend on a constant: the same steps in FLOAT64
+    (exact arithmetic for this purpose).  Adam divides by sqrt(v), so on coordinates whose gradient is of rounding size
+    ANY two fp32 implementations end up O(lr) apart; what can be asked of the HIP path is to sit no further from the fp64
+    trajectory than the fp32 CPU oracle does: fp64_ratio = max over tensors of |w_hip - w_fp64| / |w_cpu32 - w_fp64|."""
     import torch
     model = build_model(mm, w, device)
     spec = oracle_spec(O, w)
     params = {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
+    params64 = {n: v.astype(np.float64) for n, v in params.items()}
     assert list(params) == spec.param_names()
     opt = mm.optim.Adam(list(model.parameters()), w["lr"])
-    oopt = O.Adam(w["lr"])
+    oopt, oopt64 = O.Adam(w["lr"]), O.Adam(w["lr"])
     eng = model._get_engine(batch_size)
+    eng.begin_sequence()
     eng.assign_grads(None)
     alpha, beta = float(model.err_penalty), float(model.state_change_penalty)
-    worst = 0.0
+    worst, worst64 = 0.0, 0.0
     for xs, y in synthetic_batches(w, batch_size * steps, batch_size, seed=77):
         dx = [torch.from_numpy(x).to(device) for x in xs]
         dy = torch.from_numpy(y).to(device)
@@ -174,11 +181,24 @@ def cpu_match(O, mm, w, device, batch_size, steps=3):
         got = eng.step_values()["err_loss"]
         r = O.forward_backward(params, spec, xs, y, drop_masks=masks)
         oopt.step(params, r.grads)
+        r64 = O.forward_backward(params64, spec, xs, y, drop_masks=masks, dtype=np.float64)
+        oopt64.step(params64, r64.grads)
         worst = max(worst, float(np.max(np.abs(got - r.err_loss)) / np.max(np.abs(r.err_loss))))
-    dw = max(float(np.max(np.abs(p.detach().cpu().numpy() - params[n])) / max(np.max(np.abs(params[n])), 1e-30))
-             for n, p in model.named_parameters())
-    return {"delta_loss": worst, "delta_weights": dw, "steps": steps, "batch": batch_size,
-            "against": "numpy fp32 oracle (oracle/multimodn_oracle.py), itself pinned to the reference by tests/golden"}
+        worst64 = max(worst64, float(np.max(np.abs(got - r64.err_loss)) / np.max(np.abs(r64.err_loss))))
+    dw, ratio, dw64_hip, dw64_cpu = 0.0, 0.0, 0.0, 0.0
+    for n, p in model.named_parameters():
+        hipw = p.detach().cpu().numpy().astype(np.float64)
+        scale = max(np.max(np.abs(params64[n])), 1e-30)
+        e_hip = float(np.max(np.abs(hipw - params64[n])))
+        e_cpu = float(np.max(np.abs(params[n].astype(np.float64) - params64[n])))
+        dw = max(dw, float(np.max(np.abs(hipw - params[n])) / max(np.max(np.abs(params[n])), 1e-30)))
+        dw64_hip, dw64_cpu = max(dw64_hip, e_hip / scale), max(dw64_cpu, e_cpu / scale)
+        ratio = max(ratio, e_hip / e_cpu if e_cpu > 0 else (0.0 if e_hip == 0 else float("inf")))
+    return {"delta_loss": worst, "delta_loss_vs_fp64": worst64, "delta_weights": dw,
+            "delta_weights_vs_fp64": {"hip": dw64_hip, "cpu_fp32_oracle": dw64_cpu, "fp64_ratio": ratio},
+            "steps": steps, "batch": batch_size,
+            "against": "numpy fp32 oracle (oracle/multimodn_oracle.py), itself pinned to the reference by tests/golden; "
+                       "fp64 = the same oracle in float64"}
 
 
 def cpu_baseline(O, spec, batch_size, budget_s=15.0):

@@ -72,7 +72,7 @@ def check_against(stats, grads, ref: O.StepResult, tol_loss=1e-5, tol_grad=2e-5,
             assert rel_err(grads[n].reshape(g.shape), g) < tol_grad, (n, rel_err(grads[n].reshape(g.shape), g))
 
 
-@pytest.mark.parametrize("mode", ["fused8", "fast8", "par16", "seq16", "gen16"])
+@pytest.mark.parametrize("mode", ["fused8", "fused8p", "fast8", "par16", "seq16", "gen16"])
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_first_step_matches_reference_golden(lib, name, mode, monkeypatch):
     set_mode(monkeypatch, mode)
@@ -130,7 +130,8 @@ def test_training_matches_reference_golden(lib, name, optimizer):
     assert_within_fp32_noise(np.stack(hist.loss["train"]), z["hist/loss"], l64, "History loss", tight=1e-5)
 
 
-KERNEL_MODES = {"fused8": ("1", "1", "1", "1"), "fast8": ("1", "1", "1", "0"), "par16": ("1", "1", "0", "0"),
+KERNEL_MODES = {"fused8": ("1", "1", "1", "1"), "fused8p": ("1", "1", "1", "1"),      # fused8p: the fused kernel's pair-per-encoder
+                "fast8": ("1", "1", "1", "0"), "par16": ("1", "1", "0", "0"),           # form (MMN_FB8_LEAN=0), what wider shapes run
                 "seq16": ("1", "0", "0", "0"), "seq32": ("2", "0", "0", "0"),
                 # the generic tier (k_gen_fwd / k_gen_bwd: written for MIMIC_MLPEncoder / MLPDecoder models) forced
                 # onto MLPEncoder + LogisticDecoder models: same results through different kernels and plan tables
@@ -147,6 +148,7 @@ def set_mode(monkeypatch, mode):
     monkeypatch.setenv("MMN_PAR", par)
     monkeypatch.setenv("MMN_FAST8", fast8)
     monkeypatch.setenv("MMN_FUSED", fused)          # forward+backward chain in one launch (E <= 4)
+    monkeypatch.setenv("MMN_FB8_LEAN", "0" if mode == "fused8p" else "1")
 
 
 @pytest.mark.parametrize("mode", list(KERNEL_MODES))

@@ -43,14 +43,15 @@ def run_step(model, batch, masks=None, batch_global=None, nan_policy="host"):
     return stats, grads, executed
 
 
-@pytest.mark.parametrize("form", ["fast", "sequential"])
+@pytest.mark.parametrize("form", ["batched", "fast", "sequential"])
 @pytest.mark.parametrize("rt", ["1", "2"])
 @pytest.mark.parametrize("name", MIMIC_GOLDEN_NAMES)
 def test_first_step_matches_reference_golden(lib, name, rt, form, monkeypatch):
     """Both forms of the generic tier (k_genf_* where the model is eligible, k_gen_* otherwise or when forced) and
     both tile heights."""
     monkeypatch.setenv("MMN_RT", rt)
-    monkeypatch.setenv("MMN_GEN_FAST", "1" if form == "fast" else "0")
+    monkeypatch.setenv("MMN_GEN_FAST", "0" if form == "sequential" else "1")
+    monkeypatch.setenv("MMN_GEN_BATCHED", "1" if form == "batched" else "0")    # decoders of all grid rows at once (16-row tiles)
     g = Golden(name)
     model = build_torch_model(g.spec, g.init_params(), "cuda", lib)
     stats, grads, _ = run_step(model, g.batch(0), g.step_masks(0))
@@ -261,8 +262,8 @@ def test_kernel_names_and_forms(lib, monkeypatch):
     eng = fast._get_engine(64)
     b = eng.make_batch([torch.zeros(64, 64, device="cuda") for _ in range(4)], torch.zeros(64, 3, dtype=torch.int64, device="cuda"),
                        [(k, k) for k in range(4)])
-    assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 0) == b"k_genf_fwd"
-    assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 1) == b"k_genf_bwd"
+    assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 0) == b"k_genf2_fwd"      # decoders batched over the grid rows
+    assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 1) in (b"k_genf_bwd", b"k_genf2_bwd")
     assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 2) == b""
     g = Golden("mimic_mixed")                               # one MLPEncoder among the MIMIC ones: sequential form
     mixed = build_torch_model(g.spec, g.init_params(), "cuda", lib)
@@ -473,4 +474,4 @@ def test_sweep_ran_both_forms():
     """The sweep above must have exercised both forms of the generic tier (it runs before this test)."""
     if sum(SWEEP_FORMS.values()) < 48:
         pytest.skip("sweep not run in this session")
-    assert SWEEP_FORMS["k_genf_fwd"] >= 8 and SWEEP_FORMS["k_gen_fwd"] >= 8, dict(SWEEP_FORMS)
+    assert SWEEP_FORMS["k_genf_fwd"] + SWEEP_FORMS["k_genf2_fwd"] >= 8 and SWEEP_FORMS["k_gen_fwd"] >= 8, dict(SWEEP_FORMS)

@@ -24,7 +24,7 @@ torch.cuda.synchronize()
 stream = torch.cuda.current_stream().cuda_stream
 eng.workspace[off:off + 8 * 250].zero_()
 if which == "fwd":
-    eng.lib.mmn_chain_fwd(eng._plan, C.byref(b), 1.0, 0.003, 1, stream)
+    eng.lib.mmn_chain_fwd(eng._plan, C.byref(b), 1.0, 0.003, int(os.environ.get("WANT_GRADS", "1")), stream)
 else:
     eng.lib.mmn_chain_bwd(eng._plan, C.byref(b), 0.003, stream)
 torch.cuda.synchronize()

@@ -263,7 +263,7 @@ def test_kernel_names_and_forms(lib, monkeypatch):
     b = eng.make_batch([torch.zeros(64, 64, device="cuda") for _ in range(4)], torch.zeros(64, 3, dtype=torch.int64, device="cuda"),
                        [(k, k) for k in range(4)])
     assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 0) == b"k_genf2_fwd"      # decoders batched over the grid rows
-    assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 1) in (b"k_genf_bwd", b"k_genf2_bwd")
+    assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 1) == b"k_genf2_bwd"     # and their gradients ahead of the reverse chain
     assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 2) == b""
     g = Golden("mimic_mixed")                               # one MLPEncoder among the MIMIC ones: sequential form
     mixed = build_torch_model(g.spec, g.init_params(), "cuda", lib)
@@ -416,19 +416,32 @@ def test_random_models_against_oracle(lib, seed):
     """Seeded sweep over generic-tier models: encoder kinds (all MIMIC in two thirds of the cases, so that the fast
     form runs with 1, 2 and 3 layers, narrow and 64-wide hidden layers, up to 8 encoders / 8 decoders), decoder kinds
     and depths, dropout on some encoders, a NaN-skipped modality, a permuted encoder sequence, ragged batches."""
+    _sweep_case(lib, seed, aligned=False)
+
+
+@pytest.mark.parametrize("seed", list(range(100, 132)))
+def test_random_aligned_models_against_oracle(lib, seed):
+    """The same sweep over all-MIMIC models whose widths are multiples of 4: the shapes the batched backward
+    (k_genf2_bwd: every tile by LDS-DMA, whole float4s only) accepts - 1 to 3 layers, 0 to 3 decoder layers, narrow
+    tiles (a state of 8 is half a DMA request), ragged batches, skipped modalities, permuted sequences."""
+    _sweep_case(lib, seed, aligned=True)
+
+
+def _sweep_case(lib, seed, aligned):
     rng = np.random.default_rng(5000 + seed)
-    all_mimic = seed % 3 != 0
-    E = int(rng.integers(1, 9))
-    S = int(rng.choice([4, 8, 16, 24, 48, 64, 100, 128]))
+    all_mimic = aligned or seed % 3 != 0
+    E = int(rng.integers(1, 6 if aligned else 9))
+    S = int(rng.choice([8, 16, 24, 48, 64, 100, 128] if aligned else [4, 8, 16, 24, 48, 64, 100, 128]))
     D = int(rng.integers(1, 9 if all_mimic else 5))
     B = int(rng.choice([1, 7, 16, 33, 100, 257]))
-    hid_choices = [(), (8,), (16, 16), (32,), (5, 5), (32, 32), (7,), (24, 8), (64, 64), (64,)]
+    hid_choices = ([(), (8,), (16, 16), (32,), (32, 32), (24, 8), (64, 64), (64,), (8, 32)] if aligned else
+                   [(), (8,), (16, 16), (32,), (5, 5), (32, 32), (7,), (24, 8), (64, 64), (64,)])
     encs = []
     for _ in range(E):
         H = hid_choices[int(rng.integers(0, len(hid_choices)))]
         kind = "mimic" if (all_mimic or rng.random() < 0.6) else "mlp"
         act = int(rng.choice([O.ACT_RELU, O.ACT_SIGMOID])) if (H or kind == "mimic") else O.ACT_IDENTITY
-        F = int(rng.choice([1, 3, 4, 6, 16, 33, 64, 100]))
+        F = int(rng.choice([4, 8, 16, 32, 64, 100] if aligned else [1, 3, 4, 6, 16, 33, 64, 100]))
         if kind == "mimic" and (F + 15) // 16 + (S + 15) // 16 > 12:
             F = 16                                            # keep some all-MIMIC models inside the fast form's layer-0 limit
         drop = float(rng.choice([0.0, 0.2, 0.5])) if kind == "mimic" else 0.0
@@ -457,6 +470,7 @@ def test_random_models_against_oracle(lib, seed):
     probe = eng.make_batch([torch.zeros(B, e.n_features, device="cuda") for e in encs],
                            torch.zeros(B, D, dtype=torch.int64, device="cuda"), [(k, k) for k in range(E)])
     SWEEP_FORMS[eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(probe), 0).decode()] += 1
+    SWEEP_FORMS[eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(probe), 1).decode()] += 1
     ref = O.forward_backward(params, spec, batch[0], batch[1], batch[2], drop_masks=masks)
     assert rel_err(stats["loss"], ref.loss) < 1e-5
     assert rel_err(stats["err_loss"], ref.err_loss) < 1e-5
@@ -475,3 +489,4 @@ def test_sweep_ran_both_forms():
     if sum(SWEEP_FORMS.values()) < 48:
         pytest.skip("sweep not run in this session")
     assert SWEEP_FORMS["k_genf_fwd"] + SWEEP_FORMS["k_genf2_fwd"] >= 8 and SWEEP_FORMS["k_gen_fwd"] >= 8, dict(SWEEP_FORMS)
+    assert SWEEP_FORMS["k_genf2_bwd"] >= 16 and SWEEP_FORMS["k_genf_bwd"] >= 4, dict(SWEEP_FORMS)

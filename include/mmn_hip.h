@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MMN_VERSION 104            /* 0.1.4: mmn_train_step_ex (pre-scan of the next batch, flag sets in the stats block), mmn_pack_invalidate;
+#define MMN_VERSION 105            /* 0.1.4: mmn_train_step_ex (pre-scan of the next batch, flag sets in the stats block), mmn_pack_invalidate;
                                       0.1.3: + mmn_draw_dropout; 0.1.2: MIMIC_MLPEncoder / MLPDecoder (mmn_encoder.kind, mmn_decoder.hidden, mmn_batch.drop_mask) */
 #define MMN_MAX_ENCODERS 16
 #define MMN_MAX_DECODERS 8
@@ -265,12 +265,21 @@ int mmn_train_step(mmn_plan* p, const mmn_batch* b, float err_penalty, float sta
  *   next   (may be NULL) the batch the NEXT call will run: its NaN scan (multimodn.py:168) rides in THIS step's last
  *          launch and writes next->nan_flags, which must be the flag set this step does not use.  The next call then
  *          passes the same batch with flags_ready = 1.  Data parallel: all-reduce [grads | stats] in between - the flag
- *          sets are part of the stats block.  Ignored for per-sample batches and when next->nan_flags is NULL. */
+ *          sets are part of the stats block.  Ignored for per-sample batches and when next->nan_flags is NULL.
+ *   next_drop_p != NULL (needs next): the step's last launch also draws the NEXT step's dropout multipliers - what
+ *          mmn_draw_dropout(p, next, next_drop_p, next_drop_seed, next_drop_buf, next_drop_floats, .) would draw in
+ *          front of that step, with the same draw index - so no k_dropout launch sits in front of the next step: the next
+ *          call adopts them with mmn_dropout_adopt.  The buffer may be the one this step's multipliers live in (its last
+ *          reader, the backward kernel, has run). */
 typedef struct mmn_step_opts {
     const struct mmn_adam* adam;
     const mmn_batch* next;
     int32_t accumulate_epoch;
     int32_t reserved;
+    const float* next_drop_p;
+    float* next_drop_buf;
+    uint64_t next_drop_seed;
+    uint64_t next_drop_floats;
 } mmn_step_opts;
 int mmn_train_step_ex(mmn_plan* p, const mmn_batch* b, float err_penalty, float state_change_penalty_x001,
                       const mmn_step_opts* opts, void* stream);
@@ -358,6 +367,10 @@ size_t mmn_dropout_floats(mmn_plan* p, int batch);
 int mmn_draw_dropout(mmn_plan* p, mmn_batch* b, const float* drop_p, uint64_t seed, float* buf, size_t buf_floats,
                      void* stream);
 int mmn_dropout_reset(mmn_plan* p, void* stream);
+/* The multipliers of b's step are already in `buf` (an earlier step drew them: mmn_step_opts.next_drop_p with the same
+ * drop_p / buffer): point b->drop_mask[e] at them exactly as mmn_draw_dropout would, without a launch.  The step that
+ * follows advances the draw index as it does behind mmn_draw_dropout. */
+int mmn_dropout_adopt(mmn_plan* p, mmn_batch* b, const float* drop_p, float* buf, size_t buf_floats, void* stream);
 
 /* Epoch accumulators (device, inside the workspace): reset at epoch start, read at epoch end.
  * mmn_epoch_read synchronises the stream.  Layout of `out` (doubles): err_sum[R*D], sc_sum[E],

@@ -206,6 +206,7 @@ class HipChainEngine:
                                                           else 0.0 for enc in model.encoders])
         self._drop_buf = None
         self._drop_seed = None
+        self._predrawn = None                               # the batch whose multipliers the previous step's last launch drew
         self._step_graphs: Dict[tuple, list] = {}             # run_group: key -> [sightings, graph, keep-alive]
         self._graph_hits = 0
 
@@ -298,12 +299,18 @@ class HipChainEngine:
             need = int(self.lib.mmn_dropout_floats(self._plan, self.max_batch))
             if self._drop_buf is None or self._drop_buf.numel() < need:
                 self._drop_buf = torch.empty(need, dtype=torch.float32, device=self.device)
-            seed = (int(torch.initial_seed()) ^ (int(getattr(self, "dropout_salt", 0)) * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
-            if seed != self._drop_seed:                        # torch.manual_seed(...) restarts the sequence
-                self.reset_dropout()
-                self._drop_seed = seed
-            hip.check(self.lib.mmn_draw_dropout(self._plan, C.byref(b), self._drop_p, seed, self._drop_buf.data_ptr(),
-                                                self._drop_buf.numel(), self._stream()), "mmn_draw_dropout")
+            seed = self._dropout_seed()
+            predrawn, self._predrawn = self._predrawn, None
+            if predrawn is b and seed == self._drop_seed:
+                # the previous step's last launch drew them (mmn_step_opts.next_drop_p): no launch, same draw index
+                hip.check(self.lib.mmn_dropout_adopt(self._plan, C.byref(b), self._drop_p, self._drop_buf.data_ptr(),
+                                                     self._drop_buf.numel(), self._stream()), "mmn_dropout_adopt")
+            else:
+                if seed != self._drop_seed:                    # torch.manual_seed(...) restarts the sequence
+                    self.reset_dropout()
+                    self._drop_seed = seed
+                hip.check(self.lib.mmn_draw_dropout(self._plan, C.byref(b), self._drop_p, seed, self._drop_buf.data_ptr(),
+                                                    self._drop_buf.numel(), self._stream()), "mmn_draw_dropout")
             views, off = [], 0
             for e, enc in enumerate(self.model.encoders):      # the library's layout: MIMIC encoders in id order
                 if not isinstance(enc, MIMIC_MLPEncoder):
@@ -326,6 +333,9 @@ class HipChainEngine:
             keep.append(mk)
         return keep
 
+    def _dropout_seed(self) -> int:
+        return (int(torch.initial_seed()) ^ (int(getattr(self, "dropout_salt", 0)) * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+
     def reset_dropout(self) -> None:
         """Restart the dropout generator's draw index (same seed -> same multipliers again)."""
         hip.check(self.lib.mmn_dropout_reset(self._plan, self._stream()), "mmn_dropout_reset")
@@ -337,10 +347,11 @@ class HipChainEngine:
         load_state_dict, another optimizer, the user)."""
         self._flag_turn = 0
         self._prescanned = None
+        self._predrawn = None
         self.lib.mmn_pack_invalidate(self._plan)
 
     def local_step(self, b: hip.Batch, err_penalty: float, sc_penalty_x001: float, accumulate: bool = False,
-                   optimizer=None, next_batch: Optional[hip.Batch] = None, desc=None) -> bool:
+                   optimizer=None, next_batch: Optional[hip.Batch] = None, desc=None, predraw_next: bool = False) -> bool:
         """[prepare: NaN scan when the batch carries device flags nobody pre-scanned; repack of the weights when the
         copies are stale] + fwd + bwd + wgrad + reduce: afterwards reduce_buf = [grads | stats] holds this rank's sums
         (already divided by batch_global).  accumulate=True also folds the loss combination / epoch accumulation into
@@ -353,18 +364,29 @@ class HipChainEngine:
 
         next_batch: the batch the NEXT call will run (made right after `b`, so that it holds the other flag set): its NaN
         scan rides in this step's last launch, and the next call finds its flags ready.
-        desc: optimizer.fused_descriptor(self), when the caller already has it (it walks every parameter)."""
-        if self._launch_step(b, err_penalty, sc_penalty_x001, accumulate, optimizer, next_batch, desc):
+        desc: optimizer.fused_descriptor(self), when the caller already has it (it walks every parameter).
+        predraw_next: the next call is a training step that draws its dropout multipliers on the device: they are drawn
+        in this step's last launch (same generator, same draw index), and draw_dropout_masks(next_batch) adopts them."""
+        if self._launch_step(b, err_penalty, sc_penalty_x001, accumulate, optimizer, next_batch, desc, predraw_next):
             optimizer.mark_fused_step()
             return True
         return False
 
-    def _launch_step(self, b, err_penalty, sc_penalty_x001, accumulate, optimizer, next_batch, desc=None) -> bool:
+    def _launch_step(self, b, err_penalty, sc_penalty_x001, accumulate, optimizer, next_batch, desc=None,
+                     predraw_next: bool = False) -> bool:
         b.flags_ready = 1 if (b.nan_flags and self._prescanned is b) else 0
         o = hip.StepOpts()
         o.accumulate_epoch = 1 if accumulate else 0
         if next_batch is not None:
             o.next = C.pointer(next_batch)
+        drew = None
+        if (predraw_next and next_batch is not None and self._drop_buf is not None and self._drop_seed is not None
+                and self._drop_seed == self._dropout_seed() and not next_batch.tile_seq):
+            o.next_drop_p = self._drop_p
+            o.next_drop_buf = self._drop_buf.data_ptr()
+            o.next_drop_seed = self._drop_seed
+            o.next_drop_floats = self._drop_buf.numel()
+            drew = next_batch
         pre = next_batch if (next_batch is not None and next_batch.nan_flags and b.nan_flags
                              and next_batch.nan_flags != b.nan_flags and not next_batch.tile_seq) else None
         if optimizer is not None:
@@ -374,6 +396,7 @@ class HipChainEngine:
                 rc = self.lib.mmn_train_step_ex(self._plan, C.byref(b), err_penalty, sc_penalty_x001, C.byref(o), self._stream())
                 if rc == 0:
                     self._prescanned = pre
+                    self._predrawn = drew
                     return True
                 if rc != hip.ERR_UNSUPPORTED:
                     hip.check(rc, "mmn_train_step_ex")
@@ -382,6 +405,7 @@ class HipChainEngine:
         hip.check(self.lib.mmn_train_step_ex(self._plan, C.byref(b), err_penalty, sc_penalty_x001, C.byref(o), self._stream()),
                   "mmn_train_step_ex")
         self._prescanned = pre
+        self._predrawn = drew
         return False
 
     # ------------------------------------------------------------------ whole steps as replayable hipGraphs
@@ -409,7 +433,8 @@ class HipChainEngine:
             return False
         first = steps[0][4]
         entry_ready = bool(first.nan_flags and self._prescanned is first)
-        key = (tuple(st[5] for st in steps), None if nxt is None else nxt[5], entry_ready,
+        entry_drawn = bool(draw_dropout and self._predrawn is first)
+        key = (tuple(st[5] for st in steps), None if nxt is None else nxt[5], entry_ready, entry_drawn,
                float(err_penalty), float(sc_penalty_x001), seed,
                id(optimizer), d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.steps, d.seg_start,
                d.lr, d.beta1, d.beta2, d.eps, d.weight_decay, d.maximize)
@@ -432,21 +457,23 @@ class HipChainEngine:
                 side.wait_stream(torch.cuda.current_stream())
                 graph = torch.cuda.CUDAGraph()
                 keep = []
-                saved = self._prescanned
+                saved, saved_drawn = self._prescanned, self._predrawn
                 with torch.cuda.stream(side):
                     with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                         for i, (xs, y, pairs, bg, b, _k) in enumerate(steps):
                             nb = steps[i + 1][4] if i + 1 < len(steps) else (None if nxt is None else nxt[4])
                             if draw_dropout:
                                 keep.append(self.draw_dropout_masks(b))
-                            if not self._launch_step(b, err_penalty, sc_penalty_x001, True, optimizer, nb, d):
+                            if not self._launch_step(b, err_penalty, sc_penalty_x001, True, optimizer, nb, d,
+                                                     predraw_next=draw_dropout and nb is not None):
                                 raise RuntimeError("fusion refused during capture")
                 torch.cuda.current_stream().wait_stream(side)
-                self._prescanned = saved                        # nothing has run yet
+                self._prescanned, self._predrawn = saved, saved_drawn   # nothing has run yet
                 ent[1], ent[2] = graph, (steps, nxt, keep, side, optimizer)
             except Exception:
                 ent[0] = -1
                 self._prescanned = None
+                self._predrawn = None
                 return False
         hip.check(self.lib.mmn_pack_refresh(self._plan, self._stream()), "mmn_pack_refresh")
         ent[1].replay()
@@ -454,6 +481,7 @@ class HipChainEngine:
         last = steps[-1][4]
         self._prescanned = nxt[4] if (nxt is not None and nxt[4].nan_flags and last.nan_flags
                                       and nxt[4].nan_flags != last.nan_flags) else None
+        self._predrawn = nxt[4] if (draw_dropout and nxt is not None and not nxt[4].tile_seq) else None
         optimizer.mark_fused_step()
         return True
 

@@ -17,7 +17,7 @@ MAX_LAYERS = 8
 MAX_DIM = 128
 ADAM_MAX_SEG = 512
 ERR_UNSUPPORTED = -2
-VERSION = 104
+VERSION = 105
 MAX_DEC_HIDDEN = 3
 ENC_MLP, ENC_MIMIC = 0, 1
 
@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "mmn_nan_scan", "mmn_chain_kernel_name", "mmn_chain_fwd",
     "mmn_chain_bwd", "mmn_chain_fwd_bwd", "mmn_wgrad", "mmn_reduce", "mmn_epoch_accumulate", "mmn_train_step",
     "mmn_eval_step", "mmn_adam_blocks", "mmn_adam_step", "mmn_adam_step_accumulate", "mmn_train_step_adam", "mmn_reduce_adam", "mmn_regroup_rows", "mmn_regroup", "mmn_epoch_reset", "mmn_epoch_read", "mmn_debug_buffer",
-    "mmn_dropout_floats", "mmn_draw_dropout", "mmn_dropout_reset",
+    "mmn_dropout_floats", "mmn_draw_dropout", "mmn_dropout_reset", "mmn_dropout_adopt",
     "mmn_nan_flags_set", "mmn_pack_invalidate", "mmn_pack_refresh", "mmn_train_step_ex", "mmn_epoch_write", "mmn_adam_fusable", "mmn_regroup_ex",
 )
 
@@ -79,7 +79,8 @@ class AdamDesc(C.Structure):
 
 class StepOpts(C.Structure):
     _fields_ = [("adam", C.POINTER(AdamDesc)), ("next", C.POINTER(Batch)), ("accumulate_epoch", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("reserved", C.c_int32), ("next_drop_p", C.POINTER(C.c_float)), ("next_drop_buf", C.c_void_p),
+                ("next_drop_seed", C.c_uint64), ("next_drop_floats", C.c_uint64)]
 
 
 class MmnError(RuntimeError):
@@ -181,6 +182,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_dropout_floats.argtypes = [vp, i32]
     lib.mmn_draw_dropout.restype = i32
     lib.mmn_draw_dropout.argtypes = [vp, C.POINTER(Batch), C.POINTER(C.c_float), C.c_uint64, vp, C.c_size_t, vp]
+    lib.mmn_dropout_adopt.restype = i32
+    lib.mmn_dropout_adopt.argtypes = [vp, C.POINTER(Batch), C.POINTER(C.c_float), vp, C.c_size_t, vp]
     lib.mmn_dropout_reset.restype = i32
     lib.mmn_dropout_reset.argtypes = [vp, vp]
     if lib.mmn_version() != VERSION:

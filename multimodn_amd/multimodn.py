@@ -326,8 +326,11 @@ class MultiModN(nn.Module):
         if train:
             # single GPU + multimodn_amd.optim.Adam: optimizer.step() rides in the last launch
             fuse = optimizer if (not dp and hasattr(optimizer, "fused_descriptor")) else None
+            # (the next step of this loop draws its dropout multipliers on the device too: this step's last launch does it)
+            predraw = bool(nxt is not None and eng.dropout_encoders and self.dropout_mask_provider is None)
             st.stepped = eng.local_step(b, alpha, beta, accumulate=not dp, optimizer=fuse,
-                                        next_batch=None if nxt is None else nxt.b, **({"desc": desc} if desc is not None else {}))
+                                        next_batch=None if nxt is None else nxt.b, predraw_next=predraw,
+                                        **({"desc": desc} if desc is not None else {}))
         else:
             eng.eval_step(b, accumulate=not dp)
         if dp:

@@ -192,7 +192,7 @@ class OracleEngine:
                 self._scan(next_batch)
                 self._prescanned = next_batch
 
-    def local_step(self, b, alpha, beta, accumulate=False, optimizer=None, next_batch=None):
+    def local_step(self, b, alpha, beta, accumulate=False, optimizer=None, next_batch=None, predraw_next=False, desc=None):
         if not getattr(b, "per_sample", False):
             self._consume_flags(b)
         self._run(b, True)

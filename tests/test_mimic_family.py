@@ -395,6 +395,45 @@ def test_device_dropout_draw(lib):
     torch.cuda.synchronize()
 
 
+def test_dropout_drawn_by_the_previous_step(lib):
+    """Look-ahead: a step's last launch (k_reduce) also draws the NEXT step's multipliers (mmn_step_opts.next_drop_p) and
+    the next step adopts them without a launch (mmn_dropout_adopt).  They must be the multipliers a k_dropout launch in
+    front of that step draws - same generator, same draw index, bit for bit - the index must advance once per consumed
+    draw, and a pre-drawn set nobody adopts must not advance it."""
+    spec = mimic_c3_spec()
+    model = build_torch_model(spec, O.init_params(spec, 3), "cuda", lib)
+    B = 272                                                   # 17 tiles
+    eng = model._get_engine(B)
+    bs = []
+    for seed in (11, 12):
+        xs, y = O.synthetic_batches(spec, B, B, seed=seed)[0]
+        keep = ([torch.from_numpy(x).cuda() for x in xs], torch.from_numpy(y).cuda())
+        bs.append((eng.make_batch(keep[0], keep[1], [(k, k) for k in range(4)], device_nan_flags=True), keep))
+    (b1, _k1), (b2, _k2) = bs
+    sizes, ps = [B * 192] * 4, [0.2] * 4
+
+    def same(views, draw):
+        torch.cuda.synchronize()
+        for a, w in zip(views, expected_masks(321, draw, sizes, ps)):
+            assert np.array_equal(a.cpu().numpy().reshape(-1), w)
+
+    torch.manual_seed(321)
+    eng.begin_sequence()
+    same(eng.draw_dropout_masks(b1), 0)                       # k_dropout, draw 0
+    eng.local_step(b1, 1.0, 0.003, accumulate=True, next_batch=b2, predraw_next=True)
+    assert eng._predrawn is b2
+    same(eng.draw_dropout_masks(b2), 1)                       # adopted: drawn by b1's k_reduce with draw index 1
+    assert eng._predrawn is None
+    eng.local_step(b2, 1.0, 0.003, accumulate=True)
+    same(eng.draw_dropout_masks(b1), 2)                       # k_dropout again: the adopted draw advanced the index
+    eng.local_step(b1, 1.0, 0.003, accumulate=True, next_batch=b2, predraw_next=True)
+    same(eng.draw_dropout_masks(b1), 3)                       # b2's pre-drawn set is dropped: b1 draws with the next index
+    eng.local_step(b1, 1.0, 0.003, accumulate=True)
+    same(eng.draw_dropout_masks(b2), 4)
+    eng.local_step(b2, 1.0, 0.003, accumulate=True)
+    torch.cuda.synchronize()
+
+
 def test_unsupported_combinations_are_refused(lib):
     """Per-sample mode exists in the fused MLPEncoder kernel only: a MIMIC model must refuse it loudly."""
     spec = O.ModelSpec(16, [O.EncoderSpec(4, (8,), O.ACT_RELU, kind="mimic"), O.EncoderSpec(4, (8,), O.ACT_RELU, kind="mimic")], 1, 1.0, 0.0,

@@ -11,7 +11,7 @@ chain kernels' weight copies and the NaN scan of the NEXT batch fused in [N>1: r
 ONE RCCL all-reduce of grads + stats + NaN flags, then loss/epoch accumulation + Adam in one launch].
 
 Other workloads (never what the driver reads): --workload c1|c2 (Titanic-shaped), c5 (per-sample missing modalities),
-mimic (the MIMIC pipelines' own modules, MIMIC_MLPEncoder + MLPDecoder, on the generic kernels k_genf_fwd / k_genf_bwd).
+mimic (the MIMIC pipelines' own modules, MIMIC_MLPEncoder + MLPDecoder, on the generic tier's batched-decoder kernels k_genf2_fwd / k_genf2_bwd).
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]      (N>1 without a launcher: it starts its own N ranks)
          N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...

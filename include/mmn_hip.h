@@ -40,7 +40,8 @@
 extern "C" {
 #endif
 
-#define MMN_VERSION 105            /* 0.1.4: mmn_train_step_ex (pre-scan of the next batch, flag sets in the stats block), mmn_pack_invalidate;
+#define MMN_VERSION 105            /* 0.1.5: mmn_step_opts.next_drop_* (the next step's dropout multipliers in this step's last launch), mmn_dropout_adopt;
+                                      0.1.4: mmn_train_step_ex (pre-scan of the next batch, flag sets in the stats block), mmn_pack_invalidate;
                                       0.1.3: + mmn_draw_dropout; 0.1.2: MIMIC_MLPEncoder / MLPDecoder (mmn_encoder.kind, mmn_decoder.hidden, mmn_batch.drop_mask) */
 #define MMN_MAX_ENCODERS 16
 #define MMN_MAX_DECODERS 8

@@ -189,6 +189,7 @@ def cpu_match(O, mm, w, device, batch_size, steps=3):
         worst64 = max(worst64, float(np.max(np.abs(got - r64.err_loss)) / np.max(np.abs(r64.err_loss))))
     dw, ratio, dw64_hip, dw64_cpu = 0.0, 0.0, 0.0, 0.0
     worst_t = None
+    ss_hip, ss_cpu, n_el = 0.0, 0.0, 0
     for n, p in model.named_parameters():
         hipw = p.detach().cpu().numpy().astype(np.float64)
         scale = max(np.max(np.abs(params64[n])), 1e-30)
@@ -196,12 +197,18 @@ def cpu_match(O, mm, w, device, batch_size, steps=3):
         e_cpu = float(np.max(np.abs(params[n].astype(np.float64) - params64[n])))
         dw = max(dw, float(np.max(np.abs(hipw - params[n])) / max(np.max(np.abs(params[n])), 1e-30)))
         dw64_hip, dw64_cpu = max(dw64_hip, e_hip / scale), max(dw64_cpu, e_cpu / scale)
+        ss_hip += float(np.sum(((hipw - params64[n]) / scale) ** 2))
+        ss_cpu += float(np.sum(((params[n].astype(np.float64) - params64[n]) / scale) ** 2))
+        n_el += hipw.size
         r_t = e_hip / e_cpu if e_cpu > 0 else (0.0 if e_hip == 0 else float("inf"))
         if r_t > ratio:
             ratio, worst_t = r_t, {"tensor": n, "ratio": r_t, "hip": e_hip / scale, "cpu_fp32_oracle": e_cpu / scale}
     return {"delta_loss": worst, "delta_loss_vs_fp64": worst64, "delta_weights": dw,
             "delta_weights_vs_fp64": {"hip": dw64_hip, "cpu_fp32_oracle": dw64_cpu,
-                                      "fp64_ratio": dw64_hip / dw64_cpu if dw64_cpu > 0 else 0.0, "worst_tensor": worst_t},
+                                      "fp64_ratio": dw64_hip / dw64_cpu if dw64_cpu > 0 else 0.0, "worst_tensor": worst_t,
+                                      # the same distances as root mean squares over ALL weights (a max is one outlier)
+                                      "rms": {"hip": (ss_hip / max(n_el, 1)) ** 0.5, "cpu_fp32_oracle": (ss_cpu / max(n_el, 1)) ** 0.5,
+                                              "ratio": (ss_hip / ss_cpu) ** 0.5 if ss_cpu > 0 else 0.0}},
             "steps": steps, "batch": batch_size,
             "against": "numpy fp32 oracle (oracle/multimodn_oracle.py), itself pinned to the reference by tests/golden; "
                        "fp64 = the same oracle in float64"}

@@ -48,13 +48,15 @@ def test_struct_sizes_match_header(tmp_path):
         'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mmn_linear), sizeof(mmn_encoder),'
         ' sizeof(mmn_decoder), sizeof(mmn_model), sizeof(mmn_batch), sizeof(mmn_adam), offsetof(mmn_batch, drop_mask),'
         ' offsetof(mmn_model, dec), offsetof(mmn_decoder, hidden), sizeof(mmn_step_opts), offsetof(mmn_step_opts, accumulate_epoch),'
-        ' offsetof(mmn_batch, flags_ready));return 0;}\n')
+        ' offsetof(mmn_batch, flags_ready));'
+        'printf("%zu %zu\\n", offsetof(mmn_step_opts, next_drop_p), offsetof(mmn_step_opts, next_drop_floats));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     want = [C.sizeof(hip.Linear), C.sizeof(hip.Encoder), C.sizeof(hip.Decoder), C.sizeof(hip.Model), C.sizeof(hip.Batch),
             C.sizeof(hip.AdamDesc), hip.Batch.drop_mask.offset, hip.Model.dec.offset, hip.Decoder.hidden.offset,
-            C.sizeof(hip.StepOpts), hip.StepOpts.accumulate_epoch.offset, hip.Batch.flags_ready.offset]
+            C.sizeof(hip.StepOpts), hip.StepOpts.accumulate_epoch.offset, hip.Batch.flags_ready.offset,
+            hip.StepOpts.next_drop_p.offset, hip.StepOpts.next_drop_floats.offset]       # (ABI 105)
     assert got == want
     assert C.sizeof(hip.Linear) == 40 and C.sizeof(hip.Encoder) == 16 + 40 * hip.MAX_LAYERS
 
@@ -118,6 +120,15 @@ def test_plan_create_rejects_bad_arguments(lib):
     plan = C.c_void_p()
     assert lib.mmn_plan_create(C.byref(m), 0, None, 0, None, C.byref(plan)) == -1
     assert lib.mmn_plan_create(C.byref(m), 64, 1, 1 << 30, 4096, C.byref(plan)) == -3    # misaligned workspace
+
+
+def test_dropout_entry_points_reject_null_arguments(lib):
+    """mmn_draw_dropout / mmn_dropout_adopt (ABI 105) validate before they touch a device."""
+    b = hip.Batch()
+    p = (C.c_float * hip.MAX_ENCODERS)()
+    assert lib.mmn_dropout_adopt(None, C.byref(b), p, 16, 64, None) == -1
+    assert lib.mmn_draw_dropout(None, C.byref(b), p, 1, 16, 64, None) == -1
+    assert lib.mmn_dropout_floats(None, 8) == 0
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -443,7 +443,10 @@ def main():
             torch.cuda.synchronize()
             samples.append(e0.elapsed_time(e1) * 1e3 / n_ev)
         dist_us = {"median": float(np.median(samples)), "p10": float(np.percentile(samples, 10)),
-                   "p90": float(np.percentile(samples, 90)), "groups": len(samples), "steps_per_group": n_ev}
+                   "p90": float(np.percentile(samples, 90)), "groups": len(samples), "steps_per_group": n_ev,
+                   "note": "every sample is ONE _train_steps call of steps_per_group steps, i.e. it carries the whole per-sequence "
+                           "cost (epoch reset, repack + scan launch, idle until the first graph is out: ~50-70 us) over few "
+                           "steps; the spread is the information, the level is ms_per_step's"}
 
     # ---- the public entry point itself: MultiModN.train_epoch over a DeviceResidentLoader, History
     #      appended every epoch.  Same step code as `value`; what it adds is the epoch's end (one readback of the epoch

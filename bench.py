@@ -51,7 +51,7 @@ WORKLOADS = {
                   text="SURVEY 8f #1, the MIMIC pipelines' own modules at the MIMIC shape: 4 x MIMIC_MLPEncoder(64 features + "
                        "state 128 -> 32 -> 32 -> 128, relu on every layer, dropout 0.2 on cat[x, state], masks drawn on the "
                        "device inside the step) and 3 x MLPDecoder(128 -> 32 -> 32 -> 2), batch 4096 per GPU, Adam lr 1e-3, "
-                       "penalties 1.0/0.3; generic tier, batched-decoder kernels k_genf2_fwd / k_genf2_bwd"),
+                       "penalties 1.0/0.3; generic tier: chain kernels k_genf2_fwd / k_genf2_bwd, decoders in k_dec_fb"),
     "c2": dict(S=64, F=[3, 2], H=(5, 5), D=2, B=512, lr=1e-2, pen=(0.7, 0.3),
                text="Titanic-shaped, 2 encoders (features split 3+2), hidden (5,5) relu, 2 binary tasks, state_dim 64, "
                     "batch 512, Adam lr 1e-2, penalties 0.7/0.3 (latency-bound)"),
@@ -113,7 +113,7 @@ def flops_per_sample_of(w):
             bwd += full - f * dims[1]
         dd = [S] + list(w["dec_hidden"]) + [2]
         dec = (E + 1) * D * sum(a * b for a, b in zip(dd, dd[1:]))
-        return {"k_chain_fwd": 2 * (fwd + dec), "k_chain_bwd": 2 * (bwd + dec), "k_wgrad": 2 * (wg + dec)}
+        return {"k_chain_fwd": 2 * (fwd + dec), "k_chain_bwd": 2 * (bwd + dec), "k_wgrad": 2 * (wg + dec), "decoders_one_way": 2 * dec}
     for f in w["F"]:
         dims = [f] + list(w["H"])
         hidden = sum(a * b for a, b in zip(dims, dims[1:]))
@@ -495,6 +495,7 @@ def main():
     fwd_name = lib.mmn_chain_kernel_name(plan, C.byref(b0), 0).decode()
     bwd_name = lib.mmn_chain_kernel_name(plan, C.byref(b0), 1).decode()
     fused_name = lib.mmn_chain_kernel_name(plan, C.byref(b0), 2).decode()
+    dec_name = lib.mmn_chain_kernel_name(plan, C.byref(b0), 3).decode()      # generic tier, split form: the decoders' own launch
     # k_prepare (NaN scan + repack of the weights) is NOT part of a steady-state step any more: the scan of batch t+1
     # rides in step t's k_reduce, the repack is replaced by the Adam tail's scatter.  Timed here as what the first step
     # of an epoch still pays.
@@ -502,7 +503,9 @@ def main():
     if fused_name:        # forward + backward chain in one launch (what mmn_train_step uses)
         kern[fused_name] = lambda b: lib.mmn_chain_fwd_bwd(plan, C.byref(b), alpha, beta, stream)
     else:
-        kern[fwd_name] = lambda b: lib.mmn_chain_fwd(plan, C.byref(b), alpha, beta, 1, stream)
+        kern[fwd_name] = lambda b: lib.mmn_chain_fwd(plan, C.byref(b), alpha, beta, 1 | (2 if dec_name else 0), stream)
+        if dec_name:
+            kern[dec_name] = lambda b: lib.mmn_chain_fwd(plan, C.byref(b), alpha, beta, 1 | 4, stream)
         kern[bwd_name] = lambda b: lib.mmn_chain_bwd(plan, C.byref(b), beta, stream)
     kern["k_wgrad"] = lambda b: lib.mmn_wgrad(plan, C.byref(b), stream)
     fuse_opt = opt if (not dp and args.optimizer == "hip") else None
@@ -534,6 +537,9 @@ def main():
     flp = flops_per_sample_of(wl)
     if fused_name:
         fl = {fused_name: flp["k_chain_fwd"] + flp["k_chain_bwd"], "k_wgrad": flp["k_wgrad"]}
+    elif dec_name:     # the decoders' forward AND backward products are k_dec_fb's
+        dd = flp["decoders_one_way"]
+        fl = {fwd_name: flp["k_chain_fwd"] - dd, dec_name: 2 * dd, bwd_name: flp["k_chain_bwd"] - dd, "k_wgrad": flp["k_wgrad"]}
     else:
         fl = {fwd_name: flp["k_chain_fwd"], bwd_name: flp["k_chain_bwd"], "k_wgrad": flp["k_wgrad"]}
     dominant = max(fl, key=lambda k: avg_us[k])

@@ -241,7 +241,9 @@ int mmn_chain_bwd(mmn_plan* p, const mmn_batch* b, float state_change_penalty_x0
 
 /* Forward + reverse chain.  ONE launch (k_fb8) when the 8-wave tier applies and E <= 4: the state
  * tiles, dz and hidden activations then stay in LDS between the two halves; otherwise the two
- * launches above.  (mmn_chain_kernel_name(p, b, 2) names the fused kernel, "" if it does not apply.) */
+ * launches above.  (mmn_chain_kernel_name(p, b, 2) names the fused kernel, "" if it does not apply; 3 names the decoder
+ * kernel of the generic tier's split form, where mmn_chain_fwd is two launches: want_grads | 2 launches only the chain
+ * kernel, want_grads | 4 only the decoder kernel - for per-kernel timing.) */
 int mmn_chain_fwd_bwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float state_change_penalty_x001,
                       void* stream);
 

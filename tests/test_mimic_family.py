@@ -43,7 +43,7 @@ def run_step(model, batch, masks=None, batch_global=None, nan_policy="host"):
     return stats, grads, executed
 
 
-@pytest.mark.parametrize("form", ["batched", "fast", "sequential"])
+@pytest.mark.parametrize("form", ["split", "batched", "fast", "sequential"])
 @pytest.mark.parametrize("rt", ["1", "2"])
 @pytest.mark.parametrize("name", MIMIC_GOLDEN_NAMES)
 def test_first_step_matches_reference_golden(lib, name, rt, form, monkeypatch):
@@ -51,7 +51,8 @@ def test_first_step_matches_reference_golden(lib, name, rt, form, monkeypatch):
     both tile heights."""
     monkeypatch.setenv("MMN_RT", rt)
     monkeypatch.setenv("MMN_GEN_FAST", "0" if form == "sequential" else "1")
-    monkeypatch.setenv("MMN_GEN_BATCHED", "1" if form == "batched" else "0")    # decoders of all grid rows at once (16-row tiles)
+    monkeypatch.setenv("MMN_GEN_BATCHED", "1" if form in ("batched", "split") else "0")   # decoders of all grid rows at once (16-row tiles)
+    monkeypatch.setenv("MMN_GEN_SPLIT", "1" if form == "split" else "0")        # ... in a launch of their own (k_dec_fb)
     g = Golden(name)
     model = build_torch_model(g.spec, g.init_params(), "cuda", lib)
     stats, grads, _ = run_step(model, g.batch(0), g.step_masks(0))
@@ -265,6 +266,7 @@ def test_kernel_names_and_forms(lib, monkeypatch):
     assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 0) == b"k_genf2_fwd"      # decoders batched over the grid rows
     assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 1) == b"k_genf2_bwd"     # and their gradients ahead of the reverse chain
     assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 2) == b""
+    assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 3) == b"k_dec_fb"        # the decoders' own launch (split form)
     g = Golden("mimic_mixed")                               # one MLPEncoder among the MIMIC ones: sequential form
     mixed = build_torch_model(g.spec, g.init_params(), "cuda", lib)
     eng2 = mixed._get_engine(16)
@@ -459,10 +461,12 @@ def test_random_models_against_oracle(lib, seed):
 
 
 @pytest.mark.parametrize("seed", list(range(100, 132)))
-def test_random_aligned_models_against_oracle(lib, seed):
+def test_random_aligned_models_against_oracle(lib, seed, monkeypatch):
     """The same sweep over all-MIMIC models whose widths are multiples of 4: the shapes the batched backward
     (k_genf2_bwd: every tile by LDS-DMA, whole float4s only) accepts - 1 to 3 layers, 0 to 3 decoder layers, narrow
-    tiles (a state of 8 is half a DMA request), ragged batches, skipped modalities, permuted sequences."""
+    tiles (a state of 8 is half a DMA request), ragged batches, skipped modalities, permuted sequences.  Even seeds with
+    the decoders in their own launch (k_dec_fb, the default), odd seeds with the decoders inside the chain kernels."""
+    monkeypatch.setenv("MMN_GEN_SPLIT", "0" if seed % 2 else "1")
     _sweep_case(lib, seed, aligned=True)
 
 

@@ -29,6 +29,13 @@ else:
     eng.lib.mmn_chain_bwd(eng._plan, C.byref(b), 0.003, stream)
 torch.cuda.synchronize()
 st = eng.workspace[off:off + 8 * 250].view(torch.int64).cpu().numpy()
+if st[160] > 0:
+    print("k_dec_fb: first workgroup starts", 0.0, "| (7,1) starts", (st[100] - st[161]) / 100.0, "| last workgroup starts", (st[160] - st[161]) / 100.0,
+          "ends", (st[162] - st[161]) / 100.0, "us")
+st2 = st[100:160]; st2 = st2[st2 > 0]
+if len(st2) > 1:
+    print("k_dec_fb (tile 7, row 1): n stamps", len(st2), "total us", (st2[-1] - st2[0]) / 100.0)
+    print(" ".join(f"{x:.2f}" for x in np.diff(st2) / 100.0))
 st = st[:100]; st = st[st > 0]
 d = np.diff(st) / 100.0
 print(which, "n stamps", len(st), "total us", (st[-1] - st[0]) / 100.0)

@@ -596,10 +596,19 @@ def main():
             out["cpu_match"] = cpu_match(O, mm, wl, dev, B)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(out))
     if dp:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST line of stdout: RCCL prints a version banner through C stdio (block-buffered when stdout
+        # is a pipe, i.e. it would otherwise surface at process exit, behind this line)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

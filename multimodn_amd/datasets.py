@@ -125,6 +125,11 @@ class DeviceResidentLoader:
         return [torch.cat(c, dim=0) for c in cols], torch.from_numpy(np.concatenate(ys, 0)), \
             (torch.from_numpy(np.concatenate(seqs, 0)) if seqs else None)
 
+    @property
+    def stable_batches(self) -> bool:
+        """The same tuple objects every epoch (train_epoch may then cache what it derives from their addresses)."""
+        return not self.shuffle
+
     def __len__(self) -> int:
         return self.n // self.batch_size if self.drop_last else -(-self.n // self.batch_size)
 

@@ -87,6 +87,15 @@ class _HostStager:
         return xs, dy.view(y.shape)
 
 
+_BATCH_CACHE_MAX = 4096
+
+
+def _stable_batches(loader) -> bool:
+    """True if `loader` hands the same batch OBJECTS back every epoch: a list / tuple of batches (it keeps them alive
+    itself), or a loader that promises it (`stable_batches`: DeviceResidentLoader without shuffling)."""
+    return isinstance(loader, (list, tuple)) or bool(getattr(loader, "stable_batches", False))
+
+
 class MultiModN(nn.Module):
     def __init__(
             self,
@@ -408,6 +417,10 @@ class MultiModN(nn.Module):
         n_batches = len(train_loader) if hasattr(train_loader, "__len__") else None
         window: "collections.deque[MultiModN._Step]" = collections.deque()
         cache = self.__dict__.setdefault("_batch_cache", {})
+        # Only loaders that hand the SAME batch objects back every epoch are cached (a python list / tuple of batches,
+        # which holds them alive anyway; a loader that says so: DeviceResidentLoader without shuffling).  Anything else -
+        # a shuffling device loader yields fresh index_select tensors every step - would only pin its batches in HBM.
+        stable = _stable_batches(train_loader)
         state = {"eng": None, "mode": None, "done": False, "steps": 0, "grads_assigned": False, "fd": None}
         dp = self._dp_group is not None
 
@@ -433,15 +446,15 @@ class MultiModN(nn.Module):
             # without shuffling, a list of device batches): what was derived from their tensors' addresses last time
             # - the sequence, the filled-in mmn_batch struct, its cache key - is reused; checking a batch costs less host
             # time than a small step's launches.  (Only addresses are kept, never values: the tensors' contents may change.)
-            ent = cache.get(id(batch)) if encoder_sequence is None else None
+            ent = cache.get(id(batch)) if (stable and encoder_sequence is None) else None
             if ent is not None and ent[0] is batch and ent[1] is target and ent[3] == state["sig"] \
                     and len(ent[2]) == len(data) and all(a is c for a, c in zip(ent[2], data)):
                 window.append(MultiModN._Step(ent[2], target, ent[4], None, False, ent[5], ent))
                 return True
             st = self._make_step(data, target, encoder_sequence, state["mode"], True)
-            if encoder_sequence is None and st.executed is None and not st.on_host and not self.shuffle_mode \
+            if stable and encoder_sequence is None and st.executed is None and not st.on_host and not self.shuffle_mode \
                     and isinstance(batch, tuple) and st.y is target and all(a is c for a, c in zip(st.xs, data)):
-                if len(cache) >= 4096:
+                if len(cache) >= _BATCH_CACHE_MAX:
                     cache.clear()
                 st.cached = cache[id(batch)] = [batch, target, st.xs, state["sig"], st.pairs, st.bg, None]
             window.append(st)
@@ -481,8 +494,11 @@ class MultiModN(nn.Module):
             #  ingested, was measured: 77.6 instead of 74.9 us/step over 20 steps - the group's replay then starts late)
             if can_replay and resident:
                 group = max(1, int(getattr(self, "REPLAY_GROUP", 8)))
+            # (stop at the first batch that arrives the other way - host-staged behind device-resident or vice versa: the
+            #  staging ring is three deep, a longer window of host batches would overwrite buffers of steps not yet launched)
             while len(window) < group + 1 and pull():
-                pass
+                if window[-1].on_host != window[0].on_host:
+                    break
             materialise()
             n = min(group, len(window))
             if any(st.on_host != window[0].on_host for st in itertools.islice(window, n)):
@@ -502,7 +518,7 @@ class MultiModN(nn.Module):
                         window.popleft()
                     state["steps"] += n
                     self.train_steps_launched = getattr(self, "train_steps_launched", 0) + n
-                    optimizer.fused_step_seen()              # what optimizer.step() would do now: nothing
+                    optimizer.fused_step_seen(n)             # what n calls of optimizer.step() would do now
                     continue
             # eagerly: the whole group (first sighting of its buffers: the groups of later epochs then start at the same
             # positions), or the single step
@@ -546,6 +562,7 @@ class MultiModN(nn.Module):
         done = [None, None]                                  # per buffer set: event behind the step that last read it
         state = {"i": 0, "fd": None, "fused": False, "plan": None}
         cache = self.__dict__.setdefault("_batch_cache", {})
+        stable = _stable_batches(train_loader)
 
         def prepare(batch):
             nonlocal eng, side
@@ -567,19 +584,22 @@ class MultiModN(nn.Module):
                     side = self.__dict__.get("_ps_stream")
                     if side is None:
                         side = self.__dict__["_ps_stream"] = torch.cuda.Stream(device=self.device)
-                    side.wait_stream(main)                  # the data may have been produced on the main stream
+                # EVERY batch: the loader may have produced this batch on the main stream inside next(it) (a shuffling
+                # DeviceResidentLoader's index_select, a user's .to(device, non_blocking=True)); the regrouping kernels read
+                # it on the side stream.  Step t is not enqueued yet at this point, so the wait costs no overlap.
+                side.wait_stream(main)
                 if done[slot] is not None:
                     side.wait_event(done[slot])             # the step that read this buffer set two batches ago
                 y = target if target.dim() == 2 else target.view(-1, 1)
-                ent = cache.get(id(batch))
+                ent = cache.get(id(batch)) if stable else None
                 tmpl = ent[1] if (ent is not None and ent[0] is batch) else None
                 r = eng.per_sample_batch_async(list(data), y, encoder_sequence if isinstance(encoder_sequence, Tensor) else None
                                                if encoder_sequence is None else torch.as_tensor(np.asarray(encoder_sequence)).to(self.device),
                                                slot, side, tmpl)
                 if r is not None:
                     b, keep, ev, tmpl = r
-                    if isinstance(batch, tuple):
-                        if len(cache) >= 4096:
+                    if stable and isinstance(batch, tuple):
+                        if len(cache) >= _BATCH_CACHE_MAX:
                             cache.clear()
                         cache[id(batch)] = (batch, tmpl)
                     b.batch_global = int(y.shape[0]) * self._dp_world

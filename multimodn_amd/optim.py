@@ -190,9 +190,21 @@ class Adam(Optimizer):
     def mark_fused_step(self) -> None:
         self._fused_pending = True
 
-    def fused_step_seen(self) -> None:
-        """What step() does after a fused step, without the Optimizer hooks around it."""
+    def fused_step_seen(self, n: int = 1) -> None:
+        """What `n` calls of step() do after `n` fused steps.  Without step hooks that is bookkeeping only (the flag torch's
+        LR schedulers look for included: they warn "lr_scheduler.step() before optimizer.step()" otherwise); with hooks
+        registered (register_step_pre_hook / _post_hook, torch's global optimizer hooks) step() itself is called - it
+        returns at once after a fused step - so that they fire once per step as they would in the reference's loop."""
+        import torch.optim.optimizer as _to
+        hooked = bool(getattr(self, "_optimizer_step_pre_hooks", None) or getattr(self, "_optimizer_step_post_hooks", None)
+                      or getattr(_to, "_global_optimizer_pre_hooks", None) or getattr(_to, "_global_optimizer_post_hooks", None))
+        if hooked:
+            for _ in range(max(int(n), 1)):
+                self._fused_pending = True
+                self.step()
+            return
         self._fused_pending = False
+        self._opt_called = True
 
     def fusion_refused(self, engine) -> None:
         self._no_fuse_sig = engine._sig

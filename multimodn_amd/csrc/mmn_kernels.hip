@@ -76,6 +76,7 @@ namespace {
 #include "mmn_generic.inc"
 #include "mmn_chain_par.inc"
 #include "mmn_chain_8w.inc"
+#include "mmn_chain_fb9.inc"
 #include "mmn_wgrad.inc"
 #include "mmn_per_sample.inc"
 #include "mmn_adam_reduce.inc"

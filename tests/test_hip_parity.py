@@ -386,8 +386,13 @@ def test_integration_md_stub_runs(lib):
     n_params = sum(p.numel() for p in model.parameters())
     stats = flat_g[n_params:].cpu().numpy()
     assert rel_err(stats[:15].reshape(5, 3), ref.err_loss) < 1e-5
+    # a gradient element is a sum of per-sample terms: its fp32 rounding noise scales with the TERMS, not with the sum (a
+    # decoder bias gradient is ~1000 terms of either sign that cancel to 1e-5 of their size), so the tolerance is 2e-5 of
+    # the tensor's own largest element or 2e-6 of the model's largest gradient element, whichever is larger
+    g_all = max(float(np.max(np.abs(g))) for g in ref.grads.values() if g is not None)
     for n, p in model.named_parameters():
-        assert rel_err(p.grad.cpu().numpy().reshape(ref.grads[n].shape), ref.grads[n]) < 2e-5, n
+        got, want = p.grad.cpu().numpy().reshape(ref.grads[n].shape), ref.grads[n]
+        assert float(np.max(np.abs(got - want))) <= max(2e-5 * float(np.max(np.abs(want))), 2e-6 * g_all), n
 
 
 @pytest.mark.parametrize("seed", list(range(40)))

@@ -170,6 +170,51 @@ def _act_grad_from_output(h: np.ndarray, kind: int) -> np.ndarray:
     return np.ones_like(h)
 
 
+#: relative distance to zero under which a relu pre-activation counts as "on the kink" (fp32 implementations place a
+#: pre-activation within ~1e-6 of the exact value, relative to the layer's scale)
+KINK_MARGIN = 4e-6
+
+
+def _note_kinks(kinks, key, pre, activation) -> None:
+    if kinks is None or activation != ACT_RELU:
+        return
+    scale = float(np.abs(pre).max())
+    if scale > 0:
+        kinks[key] = kinks.get(key, 0) + int((np.abs(pre) < KINK_MARGIN * scale).sum())
+
+
+def tied_parameters(spec: "ModelSpec", kinks: Dict[tuple, int]) -> set:
+    """Names of the parameters whose gradient is discontinuous at the relu kinks `kinks` found (forward_backward(...,
+    kinks=...)): on a sample whose pre-activation sits on the kink, act'(.) is 0 or 1 depending on the last rounding, and
+    that sample's whole contribution to the gradients UPSTREAM of the unit comes or goes - two correct fp32
+    implementations may then differ by one sample's share (~1 / sqrt(batch) of a gradient element), far above rounding
+    noise.  MLPEncoder family: the hidden MLP sees x only, so a kink in layer l of encoder e reaches layers 0..l of that
+    encoder and nothing else.  MIMIC_MLPEncoder: the state enters the first layer, so a kink reaches every encoder and
+    the init state.  MLPDecoder hidden layer l of decoder d: that decoder's layers 0..l, every encoder, the init state."""
+    tied = set()
+    enc_all = False
+    for key, n in kinks.items():
+        if not n:
+            continue
+        if key[0] == "enc":
+            _, e, l = key
+            enc = spec.encoders[e]
+            if enc.kind == "mimic":
+                enc_all = True
+            else:
+                for j in range(l + 1):
+                    tied.update({f"encoders.{e}.layers.{j}.weight", f"encoders.{e}.layers.{j}.bias"})
+        else:
+            _, d, l = key
+            names = spec.dec(d).names(d)
+            for j in range(l + 1):
+                tied.update({names[j] + ".weight", names[j] + ".bias"})
+            enc_all = True
+    if enc_all:
+        tied.update(n for n in spec.param_names() if n.startswith("encoders.") or n.startswith("init_state."))
+    return tied
+
+
 def default_sequence(E: int) -> List[Tuple[int, int]]:
     """multimodn.py:515-516: (data_idx, enc_idx) = enumerate(range(E))."""
     return [(i, i) for i in range(E)]
@@ -200,6 +245,7 @@ class StepResult:
     executed: np.ndarray            # [E] bool: encoder ran (no NaN skip) (multimodn.py:168-171)
     grads: Dict[str, Optional[np.ndarray]] = field(default_factory=dict)
     states: Dict[int, np.ndarray] = field(default_factory=dict)   # row -> [B,S] (row 0 = init)
+    hidden: Dict[tuple, np.ndarray] = field(default_factory=dict)  # (encoder, layer) -> hidden activations [B, H] (keep_states)
     row_counts: Optional[np.ndarray] = None   # per-sample mode only: samples that own each grid row, [(E+1)]
 
 
@@ -210,7 +256,8 @@ def forward_backward(params: Dict[str, np.ndarray], spec: ModelSpec,
                      present_override: Optional[Sequence[bool]] = None,
                      dtype=np.float32, want_grads: bool = True,
                      keep_states: bool = False,
-                     drop_masks: Optional[Dict[int, np.ndarray]] = None) -> StepResult:
+                     drop_masks: Optional[Dict[int, np.ndarray]] = None,
+                     kinks: Optional[Dict[tuple, int]] = None) -> StepResult:
     """One mini-batch of train_epoch's body (multimodn.py:119-203) with a hand-derived backward.
 
     xs[k]: [B, F_k] features of data slot k; y: [B, D] int targets in {0,1}.
@@ -222,6 +269,9 @@ def forward_backward(params: Dict[str, np.ndarray], spec: ModelSpec,
     drop_masks[e]: MIMIC_MLPEncoder e's dropout multipliers for this step, [B, F_e + S] with entries
     0 or 1/(1-p) (what nn.Dropout applies to cat([x, state]) in training mode, mlp_encoder.py:34,41);
     absent = no dropout (eval mode or p = 0).
+    kinks: if a dict, it receives for every relu hidden layer the number of (sample, unit) pre-activations within
+    KINK_MARGIN (relative to the layer's largest) of zero: keys ("enc", e, layer) / ("dec", d, layer).  The loss is not
+    differentiable there, so two correct implementations may disagree on act'(.) for that sample (tied_parameters()).
     """
     S, E, D = spec.state_size, spec.E, spec.D
     dt = np.dtype(dtype)
@@ -257,8 +307,10 @@ def forward_backward(params: Dict[str, np.ndarray], spec: ModelSpec,
         for d in range(D):
             ds = spec.dec(d)
             hs = [s]
-            for n in dec_names[d][:-1]:
-                hs.append(_act(hs[-1] @ P[n + ".weight"].T + P[n + ".bias"], ds.hidden_activation))
+            for l, n in enumerate(dec_names[d][:-1]):
+                pre = hs[-1] @ P[n + ".weight"].T + P[n + ".bias"]
+                _note_kinks(kinks, ("dec", d, l), pre, ds.hidden_activation)
+                hs.append(_act(pre, ds.hidden_activation))
             acts_row.append(hs)
             z = hs[-1] @ P[dec_names[d][-1] + ".weight"].T + P[dec_names[d][-1] + ".bias"]
             o = 1.0 / (1.0 + np.exp(-z))
@@ -305,16 +357,18 @@ def forward_backward(params: Dict[str, np.ndarray], spec: ModelSpec,
             hs = [h]
             for l in range(L + 1):
                 k = enc.layer_key(l)
-                h = _act(h @ P[f"encoders.{e}.layers.{k}.weight"].T + P[f"encoders.{e}.layers.{k}.bias"],
-                         enc.activation)
+                pre = h @ P[f"encoders.{e}.layers.{k}.weight"].T + P[f"encoders.{e}.layers.{k}.bias"]
+                _note_kinks(kinks, ("enc", e, l), pre, enc.activation)
+                h = _act(pre, enc.activation)
                 hs.append(h)
             new_state = h
         else:
             hs = [x]
             h = x
             for l in range(L):                                    # mlp_encoder.py:75-76
-                h = _act(h @ P[f"encoders.{e}.layers.{l}.weight"].T + P[f"encoders.{e}.layers.{l}.bias"],
-                         enc.activation)
+                pre = h @ P[f"encoders.{e}.layers.{l}.weight"].T + P[f"encoders.{e}.layers.{l}.bias"]
+                _note_kinks(kinks, ("enc", e, l), pre, enc.activation)
+                h = _act(pre, enc.activation)
                 hs.append(h)
             cat = np.concatenate([h, state], axis=1)              # mlp_encoder.py:78 (h first, state last)
             new_state = cat @ P[f"encoders.{e}.layers.{L}.weight"].T + P[f"encoders.{e}.layers.{L}.bias"]
@@ -333,6 +387,9 @@ def forward_backward(params: Dict[str, np.ndarray], spec: ModelSpec,
     res = StepResult(float(loss), err_loss, state_change, n_correct, tp, tn, fp, fn, executed)
     if keep_states:
         res.states = states
+        for e, _, hs in tape:
+            for l, h in enumerate(hs[1:]):
+                res.hidden[(e, l)] = h
     if not want_grads:
         return res
 
@@ -542,17 +599,23 @@ def test_epoch(params, spec: ModelSpec, batches, dtype=np.float32):
     return ep, outputs
 
 
-def predict(params, spec: ModelSpec, xs, encoder_sequence=None, dtype=np.float32) -> np.ndarray:
+def predict(params, spec: ModelSpec, xs, encoder_sequence=None, dtype=np.float32, margins: Optional[list] = None) -> np.ndarray:
     """multimodn.py:422-458: argmax class of every decoder on every state, [(E+1), D, N] float64;
-    rows of encoders outside the sequence stay 0; NO NaN skip on this path."""
+    rows of encoders outside the sequence stay 0; NO NaN skip on this path.
+    margins: if a list, it receives |o_1 - o_0| of every prediction, [(E+1), D, N] (inf where the row does not exist): a
+    prediction whose margin is of rounding size may legitimately differ between two correct implementations."""
     N = np.asarray(xs[0]).shape[0]
     dummy_y = np.zeros((N, spec.D), np.int64)
     r = forward_backward(params, spec, xs, dummy_y, encoder_sequence, dtype=dtype, want_grads=False,
                          keep_states=True, present_override=[True] * len(encoder_iterable(spec.E, encoder_sequence)))
     full = np.zeros((spec.E + 1, spec.D, N))
+    marg = np.full((spec.E + 1, spec.D, N), np.inf)
     for row, st in r.states.items():
         o = decoder_outputs(params, spec, st, dtype)
         full[row] = (o[:, :, 1] > o[:, :, 0]).T.astype(np.float64)
+        marg[row] = np.abs(o[:, :, 1] - o[:, :, 0]).T
+    if margins is not None:
+        margins.append(marg)
     return full
 
 
@@ -660,18 +723,19 @@ def per_sample_step(params, spec: ModelSpec, xs, y, sequences, dtype=np.float32,
     return acc
 
 
-def per_sample_eval(params, spec: ModelSpec, xs, y, sequences, dtype=np.float32):
+def per_sample_eval(params, spec: ModelSpec, xs, y, sequences, dtype=np.float32, margins: Optional[list] = None):
     """Forward-only counterpart of per_sample_step: every sample is the reference's batch-size-1
     forward (test() / predict() / get_states(), multimodn.py:255-492, with the NaN skip of :327).
     Returns (StepResult summed over samples with row_counts, predictions [(E+1), D, N] (0 where the row
     does not exist for the sample), final states [N, S], last-row outputs [(N_last, D, 2)], index of the
-    samples whose LAST encoder ran)."""
+    samples whose LAST encoder ran).  margins: as in predict()."""
     B = np.asarray(y).shape[0]
     E, D = spec.E, spec.D
     eval_spec = replace(spec, err_penalty=1.0, state_change_penalty=0.0)
     acc = None
     counts = np.zeros(E + 1, np.int64); counts[0] = B
     preds = np.zeros((E + 1, D, B))
+    marg = np.full((E + 1, D, B), np.inf)
     states = np.zeros((B, spec.state_size), np.dtype(dtype))
     last_out, last_idx = [], []
     for b in range(B):
@@ -688,6 +752,7 @@ def per_sample_eval(params, spec: ModelSpec, xs, y, sequences, dtype=np.float32)
         for row, st in r.states.items():
             o = decoder_outputs(params, spec, st, dtype)
             preds[row, :, b] = (o[0, :, 1] > o[0, :, 0])
+            marg[row, :, b] = np.abs(o[0, :, 1] - o[0, :, 0])
             if row == E:
                 last_out.append(o[0]); last_idx.append(b)
         if acc is None:
@@ -697,6 +762,8 @@ def per_sample_eval(params, spec: ModelSpec, xs, y, sequences, dtype=np.float32)
             acc.n_correct += r.n_correct; acc.tp += r.tp; acc.tn += r.tn; acc.fp += r.fp; acc.fn += r.fn
             acc.executed |= r.executed
     acc.row_counts = counts
+    if margins is not None:
+        margins.append(marg)
     return acc, preds, states, (np.stack(last_out) if last_out else np.zeros((0, D, 2))), np.array(last_idx, np.int64)
 
 

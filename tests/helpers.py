@@ -172,3 +172,74 @@ def assert_within_fp32_noise(got, ref, truth, what="", factor=4.0, tight=2e-5):
     ratio = fp32_noise_ratio(got, ref, truth)
     assert ratio <= factor, (what, f"|got-fp64| / |ref-fp64| = {ratio:.2f}", f"got vs ref {rel_err(got, ref):.2e}",
                             f"ref vs fp64 {rel_err(ref, truth):.2e}")
+
+
+# ------------------------------------------------------------------------------------------------
+# Trained weights at FULL size (no golden: the reference never ran these).  The yardstick is the same - distance to the
+# float64 trajectory, against the fp32 numpy oracle's own distance - with one addition the small goldens never needed:
+# relu kinks.  With 4096 rows x 32 units x 8 hidden layers x several steps, some pre-activation lands within fp32
+# rounding of zero in most runs; act'(.) of that sample then is 0 in one correct implementation and 1 in another, and
+# the sample's whole contribution to the gradients upstream of the unit comes or goes (~1/sqrt(batch) of an element:
+# 1e4 x rounding noise).  That is a property of the loss (it is not differentiable there), not of an implementation, so
+# a tensor is taken out of the comparison when - and only when - the HIP path's activation pattern (h > 0) of a layer
+# that feeds its gradient actually DIFFERS from the float64 replay's on some sample of some step.
+# ------------------------------------------------------------------------------------------------
+def full_size_trajectories(lib, spec, params, batches, lr, steps_fn=None):
+    """`len(batches)` fused Adam steps on the HIP path next to the numpy oracle in fp32 and fp64 (same initial weights,
+    same batches).  Returns (model, p32, p64, flipped): `flipped` = names of the parameters whose gradient crossed a relu
+    kink differently on the HIP path than in the fp64 replay (MLPEncoder family: a hidden MLP sees x only, so layer l of
+    encoder e taints layers 0..l of that encoder and nothing else)."""
+    import torch
+    model = build_torch_model(spec, params, "cuda", lib)
+    model.nan_policy = "device"
+    opt = lib.optim.Adam(model.parameters(), lr=lr)
+    p32 = {n: np.asarray(v, np.float32).copy() for n, v in params.items()}
+    p64 = {n: np.asarray(v, np.float64) for n, v in params.items()}
+    o32, o64 = O.Adam(lr), O.Adam(lr)
+    B = len(batches[0][1])
+    eng = model._get_engine(B)
+    eng.begin_sequence()
+    eng.epoch_reset()
+    pairs = [(k, k) for k in range(spec.E)]
+    alpha, beta = float(model.err_penalty), float(model.state_change_penalty)
+    ML = lib.hip.MAX_LAYERS
+    flipped = set()
+    for xs, y in batches:
+        dx = [torch.from_numpy(x).cuda() for x in xs]
+        dy = torch.from_numpy(y).cuda()
+        b = eng.make_batch(dx, dy, pairs, device_nan_flags=False)
+        assert eng.local_step(b, alpha, beta, accumulate=True, optimizer=opt)
+        opt.step()
+        torch.cuda.synchronize()
+        r64 = O.forward_backward(p64, spec, xs, y, dtype=np.float64, keep_states=True)
+        for (e, l), h64 in r64.hidden.items():
+            if spec.encoders[e].activation != O.ACT_RELU:
+                continue
+            h_hip = eng.debug_tensor(6, e * ML + l, eng.max_batch, h64.shape[1])[:B].cpu().numpy()
+            if ((h_hip > 0) != (h64 > 0)).any():
+                for j in range(l + 1):
+                    flipped.update({f"encoders.{e}.layers.{j}.weight", f"encoders.{e}.layers.{j}.bias"})
+        o64.step(p64, r64.grads)
+        r32 = O.forward_backward(p32, spec, xs, y)
+        o32.step(p32, r32.grads)
+    return model, p32, p64, flipped
+
+
+def assert_predictions_match(got, want, margins, what=""):
+    """argmax predictions (multimodn.py:144,443): EQUAL, except where the float64 oracle's two outputs sit within
+    TIE_MARGIN of each other (`margins` = |o_1 - o_0| from oracle.predict / per_sample_eval run in float64)."""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    bad = (got != want) & (np.asarray(margins) >= TIE_MARGIN)
+    assert not bad.any(), (what, int(bad.sum()), "predictions differ away from any tie")
+
+
+def auc_slack(y_true, prob64):
+    """How far the exact AUROC can move when scores within TIE_MARGIN of each other change order: the (positive, negative)
+    pairs that close, over all pairs."""
+    y_true, prob64 = np.asarray(y_true), np.asarray(prob64, np.float64)
+    pos, neg = prob64[y_true == 1], prob64[y_true == 0]
+    if len(pos) == 0 or len(neg) == 0:
+        return 0.0
+    close = (np.abs(pos[:, None] - neg[None, :]) < TIE_MARGIN).sum()
+    return float(close) / (len(pos) * len(neg))

@@ -238,6 +238,29 @@ def test_full_size_c3_step_matches_oracle(lib, mode, monkeypatch):
     assert rel_err(stats["err_loss"], ref64.err_loss) < 2e-6
 
 
+def test_full_size_c3_five_adam_steps_within_fp32_noise(lib):
+    """Trained weights at the BASELINE.json size (configs[2]: batch 4096, 5 fused Adam steps): every tensor sits no further
+    from the float64 trajectory than 4x the fp32 numpy oracle does (or agrees with it to 2e-5 outright), tensor by tensor;
+    tensors whose gradient crossed a relu kink differently than the float64 replay did are reported, not compared
+    (helpers.full_size_trajectories).  The state-update layers, the decoders and the init state have no relu in front of
+    them: they are always compared."""
+    from helpers import full_size_trajectories
+    spec = c3_spec()
+    params = O.init_params(spec, 0)
+    batches = O.synthetic_batches(spec, 5 * 4096, 4096, seed=11)
+    model, p32, p64, flipped = full_size_trajectories(lib, spec, params, batches, 1e-3)
+    always = [n for n in spec.param_names() if ".layers.2." in n or n.startswith("decoders.") or n.startswith("init_state.")]
+    assert not (flipped & set(always))
+    compared = 0
+    for n, p in model.named_parameters():
+        if n in flipped:
+            continue
+        assert_within_fp32_noise(p.detach().cpu().numpy(), p32[n], p64[n], n)
+        compared += 1
+    assert compared >= len(always)
+    print(f"compared {compared} tensors, {len(flipped)} crossed a relu kink: {sorted(flipped)}")
+
+
 def test_shard_linearity_full_size(lib):
     """Size-independent property used by data parallelism: with batch_global fixed, the reduce
     buffer of the full batch equals the sum of the shards' buffers (grads and statistics)."""

@@ -20,12 +20,16 @@ def test_oracle_reproduces_reference_run(name):
             r = O.forward_backward(params, g.spec, b[0], b[1], b[2] if len(b) > 2 else None,
                                    drop_masks=g.step_masks(s))
             assert abs(r.loss - z["step_loss"][s]) / abs(z["step_loss"][s]) < 2e-6
+            r64 = None
             if g.has_step(s):
                 none = set(str(x) for x in z[f"step{s}/grad_none"])
                 for n, gr in r.grads.items():
                     assert (gr is None) == (n in none), (n, s)
-                    if gr is not None:
-                        assert rel_err(gr, z[f"step{s}/grad/{n}"]) < 1e-4
+                    if gr is not None:        # 1e-5 of the reference's gradient outright (north_star's bar), or within fp32 noise of float64
+                        if r64 is None:
+                            r64 = O.forward_backward({k: np.asarray(v, np.float64) for k, v in params.items()}, g.spec, b[0], b[1],
+                                                     b[2] if len(b) > 2 else None, dtype=np.float64, drop_masks=g.step_masks(s))
+                        assert_within_fp32_noise(gr, z[f"step{s}/grad/{n}"], r64.grads[n], (n, s), tight=1e-5)
             opt.step(params, r.grads)
             results.append(r)
             sizes.append(len(b[1]))

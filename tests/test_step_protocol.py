@@ -236,10 +236,13 @@ def _check_ps(tmp_path):
     flat = np.concatenate([np.zeros(np.asarray(params[n]).size, np.float32) if ref.grads[n] is None
                            else np.asarray(ref.grads[n], np.float32).reshape(-1) for n in spec.param_names()])
     assert rel_err(r0["grads"], flat) < 2e-5
+    p64 = {n: np.asarray(v, np.float64) for n, v in params.items()}
+    ref64 = O.per_sample_step(p64, spec, xs, y, seq, dtype=np.float64)
+    O.Adam(1e-2).step(p64, ref64.grads)
     oopt = O.Adam(1e-2)
     oopt.step(params, ref.grads)
-    for n in spec.param_names():
-        assert rel_err(r0["p/" + n], params[n]) < 1e-4, n
+    for n in spec.param_names():       # 2e-5 of the fp32 oracle's step outright, or within 4x its distance to the float64 step
+        assert_within_fp32_noise(r0["p/" + n], params[n], p64[n], n)
 
 
 def test_per_sample_mode_two_ranks_cpu_checker(tmp_path):

@@ -340,14 +340,34 @@ class HipChainEngine:
         """Restart the dropout generator's draw index (same seed -> same multipliers again)."""
         hip.check(self.lib.mmn_dropout_reset(self._plan, self._stream()), "mmn_dropout_reset")
 
+    def _param_versions(self):
+        return (hip.PARAM_WRITES[0],) + tuple(p._version for p in self.params)
+
+    def note_parameters_current(self) -> None:
+        """The chain kernels' weight copies are current NOW (a fused step has just scattered them / a repack has run) and
+        nothing but this engine has written the parameters since: remember torch's per-parameter version counters, which
+        every in-place operation on a Parameter - optimizer steps, load_state_dict's copy_, nn.init.* - advances (the
+        library's own updates go through raw pointers and leave them alone)."""
+        self._versions_seen = self._param_versions()
+
     def begin_sequence(self) -> None:
         """Start of an epoch / an entry point: the flag sets are handed out from set 0 again (so that a replayed group of
-        steps meets the sets it was captured with), no pre-scan is carried over, and the chain kernels' copies of the
-        weights are rebuilt by the first step (anything may have written the parameters since the last call:
-        load_state_dict, another optimizer, the user)."""
+        steps meets the sets it was captured with), no pre-scan is carried over.  The chain kernels' copies of the weights
+        are rebuilt by the first step UNLESS nothing has written the parameters since this engine last left them current
+        (note_parameters_current): the version counters say so, and the storage has not moved.  (Writes that bypass the
+        counters - `p.data.add_(...)`, raw pointers - need `invalidate_weights()`; round 2 repacked at every call: one
+        launch and its boundary in front of every epoch.)"""
         self._flag_turn = 0
         self._prescanned = None
         self._predrawn = None
+        seen = getattr(self, "_versions_seen", None)
+        if seen is None or seen != self._param_versions() or tuple(p.data_ptr() for p in self.params) != self._sig:
+            self.lib.mmn_pack_invalidate(self._plan)
+        self._versions_seen = None                          # whoever runs steps next says when the copies are current again
+
+    def invalidate_weights(self) -> None:
+        """Something wrote the parameters behind torch's back: the next step rebuilds the kernels' weight copies."""
+        self._versions_seen = None
         self.lib.mmn_pack_invalidate(self._plan)
 
     def local_step(self, b: hip.Batch, err_penalty: float, sc_penalty_x001: float, accumulate: bool = False,

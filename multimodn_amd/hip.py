@@ -83,6 +83,11 @@ class StepOpts(C.Structure):
                 ("next_drop_seed", C.c_uint64), ("next_drop_floats", C.c_uint64)]
 
 
+#: advanced by every parameter update that goes through raw pointers OUTSIDE an engine's own step (multimodn_amd.optim.Adam.step
+#: on its own): engines compare it, next to torch's version counters, before trusting the kernels' weight copies across calls
+PARAM_WRITES = [0]
+
+
 class MmnError(RuntimeError):
     pass
 

@@ -244,4 +244,5 @@ class Adam(Optimizer):
                     r.skip_host = skip
                 d = self.descriptor(r, group)
                 hip.check(self._lib.mmn_adam_step(C.byref(d), stream), "mmn_adam_step")
+                hip.PARAM_WRITES[0] += 1                      # (raw-pointer update: torch's version counters do not see it)
         return loss

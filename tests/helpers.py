@@ -163,10 +163,43 @@ def fp32_noise_ratio(got, ref, truth):
     return 0.0 if e_got == 0 else (np.inf if e_ref == 0 else e_got / e_ref)
 
 
-def assert_within_fp32_noise(got, ref, truth, what="", factor=4.0, tight=2e-5):
+def adam_well_conditioned(opt64, name=None, floor=1e-6, rel=1e-3, into=None):
+    """Coordinates on which Adam's update is a well-conditioned function of the gradients, judged on the float64 replay
+    `opt64` (an oracle.Adam) as it stands NOW: sqrt(v_hat) >= max(floor, rel x the tensor's largest).  Call it after every
+    step with `into` = a dict {name: mask}: the masks are ANDed over the steps (one ill-conditioned step is enough to
+    leave two correct implementations apart for good); with `name` it returns that tensor's mask for the current step.
+    Adam normalises every coordinate by ITS OWN gradient scale: the update is m_hat / (sqrt(v_hat) + eps).  fp32 leaves a
+    gradient element with an ABSOLUTE error of ~1e-7 of the tensor's largest gradient (the products that feed it carry
+    that much), so a coordinate whose gradient is 1000x smaller than the tensor's largest carries a RELATIVE error of
+    1e-4, which Adam passes on as 1e-4 of a full lr-sized step; below `floor` = 100 x Adam's eps the denominator is eps
+    itself and the amplification is lr / eps (first steps: v_hat = g^2 of ONE batch).  Any two fp32 implementations end
+    up a visible fraction of a step apart on such coordinates (with 30 % of the modalities missing whole rows of weights
+    are in that regime): they carry no information about correctness, the well-conditioned ones do."""
+    def one(n):
+        st = opt64.state[n]
+        s_hat = np.sqrt(np.asarray(st["v"], np.float64) / (1.0 - opt64.betas[1] ** st["step"]))
+        return s_hat >= max(floor, rel * float(s_hat.max()))
+    if into is not None:
+        for n in opt64.state:
+            m = one(n)
+            into[n] = m if n not in into else (into[n] & m)
+        return into
+    return one(name)
+
+
+def assert_within_fp32_noise(got, ref, truth, what="", factor=4.0, tight=2e-5, mask=None):
     """`got` agrees with the reference's value `ref` to `tight` (relative to the tensor's max) outright, or it is no
-    further from the fp64 truth than `factor` x the reference's own fp32 run is."""
+    further from the fp64 truth than `factor` x the reference's own fp32 run is.  `mask`: compare these coordinates only
+    (adam_well_conditioned)."""
     got = np.asarray(got, np.float64).reshape(np.asarray(truth).shape)
+    if mask is not None:
+        mask = np.asarray(mask).reshape(got.shape)
+        if not mask.any():
+            return
+        scale = max(float(np.max(np.abs(np.asarray(ref, np.float64)))), 1e-30)
+        got, ref, truth = got[mask], np.asarray(ref, np.float64).reshape(mask.shape)[mask], np.asarray(truth, np.float64)[mask]
+        if float(np.max(np.abs(got - ref))) / scale <= tight:
+            return
     if rel_err(got, ref) <= tight:
         return
     ratio = fp32_noise_ratio(got, ref, truth)

@@ -205,4 +205,27 @@ def test_bench_launches_its_own_ranks():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 512
-    assert d["config"]["collectives_per_step"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    # COUNTED around every torch.distributed collective of the timed region: one all-reduce per step, plus one for the
+    # NaN flags of the sequence's first batch (it has no predecessor whose all-reduce could carry them)
+    assert d["config"]["collectives_counted"] == {"all_reduce": 7, "other": 0, "steps": 6}
+    assert d["config"]["dist_world_size"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_bench_launcher_fails_fast_when_a_rank_dies():
+    """One rank exits right after the rendezvous (MMN_BENCH_FAIL_RANK, a testing aid): the launcher must notice, take the
+    surviving rank - which sits in its first collective - down, and return non-zero within seconds instead of leaving it
+    to the caller's timeout."""
+    import subprocess
+    import sys
+    import time
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["MMN_BENCH_FAIL_RANK"] = "1"
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                          "--batch", "256", "--dist-backend", "gloo", "--share-gpu", "--preroll", "0.05", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, timeout=120, cwd=str(os.environ.get("TMPDIR", "/tmp")))
+    assert out.returncode != 0
+    assert time.time() - t0 < 60
+    assert "rank 1 exited" in out.stderr

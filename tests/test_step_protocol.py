@@ -92,12 +92,15 @@ def test_scattered_weight_copies_equal_a_full_repack_every_step(family):
     values in the same places: History and trained weights are identical bit for bit, with and without replay."""
     import multimodn_amd as lib
     spec = _specs()[family]
-    loader = _device_loader(spec, 6, 48, seed=5)
-    ref = _train(lib, spec, loader, 3, replay=False, env={"MMN_SCATTER": "0"})
-    for replay in (False, True):
-        got = _train(lib, spec, loader, 3, replay=replay)
-        _same(ref, got)
-    assert ref[0][-1].mean() < ref[0][0].mean()
+    # (6 batches = one replayed group per epoch; 19 = three groups: the copies must also be current ACROSS groups, where
+    #  the host bookkeeping of a replayed group is the capture's; 4 epochs: eager, capture, replay, the epoch plan)
+    for n_batches, epochs in ((6, 3), (19, 4)):
+        loader = _device_loader(spec, n_batches, 48, seed=5)
+        ref = _train(lib, spec, loader, epochs, replay=False, env={"MMN_SCATTER": "0"})
+        for replay in (False, True):
+            got = _train(lib, spec, loader, epochs, replay=replay)
+            _same(ref, got)
+        assert ref[0][-1].mean() < ref[0][0].mean()
 
 
 @pytest.mark.gpu

@@ -350,7 +350,7 @@ class HipChainEngine:
         library's own updates go through raw pointers and leave them alone)."""
         self._versions_seen = self._param_versions()
 
-    def begin_sequence(self) -> None:
+    def begin_sequence(self, sig_checked: bool = False) -> None:
         """Start of an epoch / an entry point: the flag sets are handed out from set 0 again (so that a replayed group of
         steps meets the sets it was captured with), no pre-scan is carried over.  The chain kernels' copies of the weights
         are rebuilt by the first step UNLESS nothing has written the parameters since this engine last left them current
@@ -361,7 +361,8 @@ class HipChainEngine:
         self._prescanned = None
         self._predrawn = None
         seen = getattr(self, "_versions_seen", None)
-        if seen is None or seen != self._param_versions() or tuple(p.data_ptr() for p in self.params) != self._sig:
+        if seen is None or seen != self._param_versions() or \
+                (not sig_checked and tuple(p.data_ptr() for p in self.params) != self._sig):   # (ensure() has just compared them)
             self.lib.mmn_pack_invalidate(self._plan)
         self._versions_seen = None                          # whoever runs steps next says when the copies are current again
 
@@ -454,10 +455,8 @@ class HipChainEngine:
         first = steps[0][4]
         entry_ready = bool(first.nan_flags and self._prescanned is first)
         entry_drawn = bool(draw_dropout and self._predrawn is first)
-        key = (tuple(st[5] for st in steps), None if nxt is None else nxt[5], entry_ready, entry_drawn,
-               float(err_penalty), float(sc_penalty_x001), seed,
-               id(optimizer), d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.steps, d.seg_start,
-               d.lr, d.beta1, d.beta2, d.eps, d.weight_decay, d.maximize)
+        hp = self.group_hp_key(err_penalty, sc_penalty_x001, optimizer, d, seed)
+        key = (tuple(st[5] for st in steps), None if nxt is None else nxt[5], entry_ready, entry_drawn) + hp
         ent = self._step_graphs.get(key)
         if ent is None:
             if len(self._step_graphs) >= self.MAX_STEP_GRAPHS:
@@ -466,7 +465,7 @@ class HipChainEngine:
                     return False
                 self._step_graphs.clear()                       # e.g. an LR scheduler changed the baked hyper-parameters:
                 self._graph_hits = 0                            # start over with the current ones
-            self._step_graphs[key] = [1, None, None]            # first sighting: the caller's eager steps are the warm-up
+            self._step_graphs[key] = [1, None, None, None]      # first sighting: the caller's eager steps are the warm-up
             return False
         if ent[1] is None:
             if ent[0] < 0:                                      # capture failed earlier for this key
@@ -495,6 +494,19 @@ class HipChainEngine:
                 self._prescanned = None
                 self._predrawn = None
                 return False
+        ent[3] = (hp, entry_ready, entry_drawn)
+        self.replay_entry(ent, steps, nxt, optimizer, draw_dropout)
+        return True
+
+    @staticmethod
+    def group_hp_key(err_penalty, sc_penalty_x001, optimizer, d, seed) -> tuple:
+        """What a captured group has baked in besides its buffers: penalties, dropout seed, the optimizer's buffers and
+        hyper-parameters."""
+        return (float(err_penalty), float(sc_penalty_x001), seed, id(optimizer), d.params, d.grads, d.exp_avg, d.exp_avg_sq,
+                d.steps, d.seg_start, d.lr, d.beta1, d.beta2, d.eps, d.weight_decay, d.maximize)
+
+    def replay_entry(self, ent, steps, nxt, optimizer, draw_dropout: bool) -> None:
+        """Replay a captured group (run_group's cache entry) and leave the look-ahead bookkeeping as its last step did."""
         hip.check(self.lib.mmn_pack_refresh(self._plan, self._stream()), "mmn_pack_refresh")
         ent[1].replay()
         self._graph_hits += 1
@@ -503,7 +515,29 @@ class HipChainEngine:
                                       and nxt[4].nan_flags != last.nan_flags) else None
         self._predrawn = nxt[4] if (draw_dropout and nxt is not None and not nxt[4].tile_seq) else None
         optimizer.mark_fused_step()
+
+    def replay_known(self, ent, steps, nxt, hp, optimizer, draw_dropout: bool) -> bool:
+        """The whole-call replay's shortcut (MultiModN._replay_epoch_plan): `ent` is the cache entry this very group was
+        replayed from last time; it is replayed again without rebuilding its key if what the key stands for is unchanged -
+        hyper-parameters `hp`, and whether the first batch arrives pre-scanned / pre-drawn."""
+        if ent is None or ent[1] is None or ent[3] is None or torch.cuda.is_current_stream_capturing():
+            return False
+        first = steps[0][4]
+        if ent[3] != (hp, bool(first.nan_flags and self._prescanned is first), bool(draw_dropout and self._predrawn is first)):
+            return False
+        self.replay_entry(ent, steps, nxt, optimizer, draw_dropout)
         return True
+
+    def group_entry(self, steps, nxt, err_penalty, sc_penalty_x001, optimizer, draw_dropout: bool, desc):
+        """The cache entry run_group would use for this group right now (None if there is none)."""
+        if self._step_graphs is None or desc is None:
+            return None, None
+        seed = self._dropout_seed() if draw_dropout else 0
+        first = steps[0][4]
+        hp = self.group_hp_key(err_penalty, sc_penalty_x001, optimizer, desc, seed)
+        key = (tuple(st[5] for st in steps), None if nxt is None else nxt[5], bool(first.nan_flags and self._prescanned is first),
+               bool(draw_dropout and self._predrawn is first)) + hp
+        return self._step_graphs.get(key), hp
 
     # ------------------------------------------------------------------ per-sample mode (BASELINE configs[4])
     def per_sample_batch(self, xs: Sequence[torch.Tensor], y: torch.Tensor, seq: Optional[torch.Tensor]):

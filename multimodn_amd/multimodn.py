@@ -522,9 +522,11 @@ class MultiModN(nn.Module):
                 if not state["grads_assigned"]:
                     eng.assign_grads(None)
                     state["grads_assigned"] = True
+                ent_now = eng.group_entry(steps, nxt, float(self.err_penalty), float(self.state_change_penalty), optimizer,
+                                          bool(eng.dropout_encoders), state["fd"])[0] if plan_ok else None
                 if eng.run_group(steps, nxt, float(self.err_penalty), float(self.state_change_penalty), optimizer,
                                  bool(eng.dropout_encoders), state["fd"]):
-                    rec.append((steps, nxt))
+                    rec.append((steps, nxt, ent_now))
                     for _ in range(n):
                         window.popleft()
                     state["steps"] += n
@@ -574,6 +576,9 @@ class MultiModN(nn.Module):
             plans[(len(seen_batches), id(seen_batches[0]), id(seen_batches[-1]))] = {
                 "batches": seen_batches, "groups": rec, "eng": eng, "plan": eng._plan.value, "opt": optimizer,
                 "group": int(getattr(self, "REPLAY_GROUP", 8)), "rows": max(int(st_[1].shape[0]) for g in rec for st_ in g[0])}
+            # (an entry captured DURING this call was looked up before its capture: take it from the cache now)
+            plans[(len(seen_batches), id(seen_batches[0]), id(seen_batches[-1]))]["groups"] = [
+                (g[0], g[1], g[2] if (g[2] is not None and g[2][1] is not None) else None) for g in rec]
         return state["eng"], state["steps"]
 
     def _replay_epoch_plan(self, train_loader, optimizer):
@@ -594,21 +599,28 @@ class MultiModN(nn.Module):
         if ep is None or ep["opt"] is not optimizer or ep["eng"] is not self._engine or ep["group"] != int(getattr(self, "REPLAY_GROUP", 8)) \
                 or len(ep["batches"]) != len(seq) or not all(map(operator.is_, seq, ep["batches"])):
             return None
-        eng = self._get_engine(ep["rows"])
+        eng = self._get_engine(ep["rows"])                   # (compares every parameter's address with the plan's)
         if eng._plan is None or eng._plan.value != ep["plan"]:
             return None
-        mode = self._nan_mode(eng, optimizer, True)
-        fd = self._fusion_setup(eng, optimizer, mode) if mode == "device" else None
-        if fd is None:
+        if getattr(self, "nan_policy", "auto") not in ("auto", "device") or not hasattr(optimizer, "fused_descriptor"):
             return None
+        fd = optimizer.fused_descriptor(eng)
+        if fd is None or not eng.adam_fusable(optimizer, fd):
+            return None
+        mode = "device"
         eng.epoch_reset()
-        eng.begin_sequence()
+        eng.begin_sequence(sig_checked=True)
         if eng.params[0].grad is not eng.grad_views[0] or eng.params[-1].grad is not eng.grad_views[-1]:
             eng.assign_grads(None)
         alpha, beta = float(self.err_penalty), float(self.state_change_penalty)
+        draw = bool(eng.dropout_encoders)
+        hp = eng.group_hp_key(alpha, beta, optimizer, fd, eng._dropout_seed() if draw else 0)
+        if draw and eng._dropout_seed() != eng._drop_seed:    # a new torch seed restarts the draw index: the slow path does that
+            return None
         total = 0
-        for steps, nxt in ep["groups"]:
-            if eng.run_group(steps, nxt, alpha, beta, optimizer, bool(eng.dropout_encoders), fd):
+        for steps, nxt, ent in ep["groups"]:
+            if eng.replay_known(ent, steps, nxt, hp, optimizer, draw) or \
+                    eng.run_group(steps, nxt, alpha, beta, optimizer, draw, fd):
                 optimizer.fused_step_seen(len(steps))
             else:                                            # a key miss (LR schedule, new dropout seed, ...): this group eagerly
                 for i, (xs, y, pairs, bg, b, key) in enumerate(steps):

@@ -742,7 +742,7 @@ def main():
     achieved = fl[dominant] * B / (avg_us[dominant] * 1e-6) / 1e12
     traffic, mfma_busy = None, None
     try:                                                      # HBM bytes per launch / matrix-pipe busy % from the committed PMC passes
-        tag = {"c3": "r02_final", "mimic": "r02_mimic"}.get(args.workload)
+        tag = {"c3": "r03_final", "mimic": "r03_mimic", "c5": "r03_c5"}.get(args.workload)
         if tag and B == wl["B"]:                             # the passes were made on this workload at this batch
             pmc = json.load(open(os.path.join(REPO, "profiles", f"{tag}_pmc_traffic.json")))
             traffic = pmc["kernels"].get(dominant, {}).get("hbm_bytes_per_launch")
@@ -754,8 +754,8 @@ def main():
                 "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "mfma_busy_pct_pmc": mfma_busy,
                 "traffic_note": "HBM bytes per launch of the dominant kernel = (2*FETCH_SIZE + WRITE_SIZE)*1024 and its "
-                                "SQ_VALU_MFMA_BUSY_CYCLES share from profiles/r02_final_pmc_traffic.json / _pmc_util.json "
-                                "(mimic workload: r02_mimic_*), separate rocprofv3 --pmc passes",
+                                "SQ_VALU_MFMA_BUSY_CYCLES share from profiles/r03_final_pmc_traffic.json / _pmc_util.json "
+                                "(mimic workload: r03_mimic_*), separate rocprofv3 --pmc passes",
                 "avg_launch_us": avg_us, "flops_per_sample": fl,
                 "algorithmic_flops_per_launch": fl[dominant] * B,
                 "step_frac_of_fp32_roof": value / world * sum(fl.values()) / (FP32_MFMA_PEAK_TFLOPS * 1e12),

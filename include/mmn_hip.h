@@ -396,6 +396,8 @@ int mmn_epoch_write(mmn_plan* p, const double* in_host, void* stream);
  *   kind 5                  : int32[rows] of the last mmn_regroup: source row of every position, -1 = padding
  *   kind 6 / 7, index = encoder * MMN_MAX_LAYERS + hidden layer : an MLPEncoder's hidden activations h_l [batch x H_l] /
  *                             d loss / d pre-activation of that layer (training only): what k_wgrad multiplies
+ *   kind 8                  : the epoch accumulators as mmn_epoch_read copies them (mmn_epoch_doubles() doubles, device
+ *                             memory): for callers that read them back asynchronously, behind the epoch's last launch
  * Rows of encoders that did not run hold stale data.  Returns NULL if out of range. */
 const float* mmn_debug_buffer(mmn_plan* p, int kind, int index);
 

@@ -719,6 +719,40 @@ class HipChainEngine:
                   "mmn_epoch_read")
         return split_epoch(out, self.E, self.D)
 
+    def epoch_read_async(self):
+        """The epoch accumulators on their way to pinned host memory, WITHOUT synchronising: returns (wait, fetch) - wait()
+        blocks until the copy has landed, fetch() then gives the same dict as epoch_read().  The copy is enqueued on the
+        current stream, i.e. behind the epoch's last launch and in front of the next epoch's reset.  A small ring of pinned
+        buffers; when every buffer is in flight the oldest is waited for first."""
+        ring = self.__dict__.setdefault("_ep_ring", [])
+        slot = None
+        for ent in ring:
+            if ent["free"]:
+                slot = ent
+                break
+        if slot is None:
+            if len(ring) < 8:
+                slot = {"buf": torch.empty(self.n_epoch, dtype=torch.float64, pin_memory=True), "ev": torch.cuda.Event(), "free": True}
+                ring.append(slot)
+            else:
+                return None                                 # (the caller falls back to the synchronous read)
+        ptr = self.lib.mmn_debug_buffer(self._plan, 8, 0)
+        off = ptr - self.workspace.data_ptr()
+        view = self.workspace[off:off + 8 * self.n_epoch].view(torch.float64)
+        slot["free"] = False
+        slot["buf"].copy_(view, non_blocking=True)
+        slot["ev"].record()
+        E, D = self.E, self.D
+
+        def wait():
+            slot["ev"].synchronize()
+
+        def fetch():
+            out = slot["buf"].numpy().copy()
+            slot["free"] = True
+            return split_epoch(out, E, D)
+        return wait, fetch
+
     def step_values(self) -> Dict[str, np.ndarray]:
         """Last step's stats block (synchronises)."""
         return split_stats(self.stats.detach().cpu().numpy(), self.E, self.D)

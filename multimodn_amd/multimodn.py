@@ -23,7 +23,7 @@ from torch.utils.data import DataLoader
 from .decoders import MultiModDecoder
 from .encoders import MultiModEncoder
 from .engine import HipChainEngine, check_criterion
-from .history import MultiModNHistory
+from .history import HistoryList, MultiModNHistory, PendingEpoch
 from .metrics import get_performance_metrics
 from .state import InitState, TrainableInitState
 
@@ -747,21 +747,33 @@ class MultiModN(nn.Module):
             eng, _ = self._train_steps(train_loader, optimizer, log_interval, logger)
         if eng is None:
             return None
-        arrays = self._epoch_arrays(eng, n_batches)
         if history is not None:
-            history.state_change_loss.append(arrays["state_change"])
-            history.loss["train"].append(arrays["loss"])
-            history.accuracy["train"].append(arrays["accuracy"])
-            history.sensitivity["train"].append(arrays["sensitivity"])
-            history.specificity["train"].append(arrays["specificity"])
-            history.balanced_accuracy["train"].append(arrays["balanced_accuracy"])
+            lists = [history.state_change_loss] + [getattr(history, m)["train"] for m in
+                                                   ("loss", "accuracy", "sensitivity", "specificity", "balanced_accuracy")]
+            keys = ("state_change", "loss", "accuracy", "sensitivity", "specificity", "balanced_accuracy")
+            pending = None
+            if all(isinstance(lst, HistoryList) for lst in lists) and hasattr(eng, "epoch_read_async"):
+                # no synchronisation at the end of an epoch: the sums travel to pinned memory behind the last launch and
+                # the six arrays are formed when somebody reads the History (the next epoch can be submitted meanwhile)
+                rd = eng.epoch_read_async()
+                if rd is not None:
+                    wait, fetch = rd
+                    pending = PendingEpoch(wait, lambda: self._epoch_arrays(eng, n_batches, fetch()))
+            if pending is not None:
+                for lst, key in zip(lists, keys):
+                    lst.append_pending(pending, key)
+            else:
+                arrays = self._epoch_arrays(eng, n_batches)
+                for lst, key in zip(lists, keys):
+                    lst.append(arrays[key])
         if last_epoch:
             return self.test(train_loader, criterion, history=None)
         return None
 
-    def _epoch_arrays(self, eng, n_batches: int):
+    def _epoch_arrays(self, eng, n_batches: int, ep=None):
         """multimodn.py:222-242 from the device-side epoch accumulators."""
-        ep = eng.epoch_read()
+        if ep is None:
+            ep = eng.epoch_read()
         n_samples = np.ones((len(self.encoders) + 1, 1)) + ep["rows"].reshape(-1, 1)   # starts at ONE (:105)
         loss = ep["err_sum"] / n_batches
         sc = ep["sc_sum"] / n_batches

@@ -27,6 +27,9 @@
  *   MMN_GENERIC=1                           run MLPEncoder / ClassDecoder models on the generic tier's kernels too
  *   MMN_GEN_FAST=0 / MMN_DEC_LDS=0          generic tier: sequential form only / decoder operands from global memory
  *   MMN_WGRAD_ROWS=n                        rows per k_wgrad row-range split (default 512)
+ *   MMN_SIDE_SCAN=1                         the pre-scan of the next batch on a side stream beside the chain kernel (measured slower
+ *                                           inside replayed hipGraph groups: off by default); MMN_FB9=0 / MMN_FB9_FULLK=0: k_fb8 instead of
+ *                                           k_fb9 / k_fb9 with run-time trip counts
  *   MMN_STAMPS=1                            phase timestamps of one workgroup (mmn_debug_buffer kind 3; tools/stamps*.py)
  *   MMN_VERBOSE=1                           plan summary on stderr
  */

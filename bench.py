@@ -10,7 +10,7 @@ reverse chain (one fused kernel) + weight grads + reduction with the Adam step, 
 chain kernels' weight copies and the NaN scan of the NEXT batch fused in [N>1: reduction + pre-scan,
 ONE RCCL all-reduce of grads + stats + NaN flags, then loss/epoch accumulation + Adam in one launch].
 
-Other workloads (never what the driver reads): --workload c1|c2 (Titanic-shaped), c5 (per-sample missing modalities),
+Other workloads (never what the driver reads): --workload c1|c2 (Titanic-shaped), c5 (per-sample missing modalities), c5m (the same with the MIMIC modules),
 mimic (the MIMIC pipelines' own modules, MIMIC_MLPEncoder + MLPDecoder, on the generic tier's batched-decoder kernels k_genf2_fwd / k_genf2_bwd).
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]      (N>1 without a launcher: it starts its own N ranks)
@@ -52,6 +52,12 @@ WORKLOADS = {
                        "state 128 -> 32 -> 32 -> 128, relu on every layer, dropout 0.2 on cat[x, state], masks drawn on the "
                        "device inside the step) and 3 x MLPDecoder(128 -> 32 -> 32 -> 2), batch 4096 per GPU, Adam lr 1e-3, "
                        "penalties 1.0/0.3; generic tier: chain kernels k_genf2_fwd / k_genf2_bwd, decoders in k_dec_fb"),
+    "c5m": dict(S=128, F=[64] * 4, H=(32, 32), D=3, B=4096, lr=1e-3, pen=(1.0, 0.3), per_sample=True, family="mimic",
+                dec_hidden=(32, 32), dropout=0.2,
+                text="BASELINE configs[4] with the modules the reference's MNAR pipeline builds (MIMIC_MLPEncoder + MLPDecoder, "
+                     "pipelines/mimic/mimic_single_task_mnar_missingness_pipeline.py:163-165): per-sample missing modalities (30 % "
+                     "not at random) and encoder order, dropout 0.2 drawn on the device, batch 4096 per GPU; generic tier, "
+                     "sequential form on regrouped 16-row tiles (k_gen_fwd / k_gen_bwd)"),
     "c2": dict(S=64, F=[3, 2], H=(5, 5), D=2, B=512, lr=1e-2, pen=(0.7, 0.3),
                text="Titanic-shaped, 2 encoders (features split 3+2), hidden (5,5) relu, 2 binary tasks, state_dim 64, "
                     "batch 512, Adam lr 1e-2, penalties 0.7/0.3 (latency-bound)"),
@@ -417,7 +423,7 @@ def spawn_ranks(n_gpus: int) -> int:
     return rc
 
 
-def secondary_workloads(names=("mimic", "c5", "c1", "c2"), steps=40, warmup=10):
+def secondary_workloads(names=("mimic", "c5", "c5m", "c1", "c2"), steps=40, warmup=10):
     """The other workloads through the same entry point, each as a CHILD process of this one (a fresh process: the parent
     has initialised the GPU and must not exec): `python bench.py --workload <w> --steps 40 --warmup 10` without CPU legs.
     Reported per workload: samples/s, ms per step, launch mode, per-kernel HIP-event times."""

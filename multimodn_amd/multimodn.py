@@ -394,6 +394,23 @@ class MultiModN(nn.Module):
                 eng.accumulate(1.0, 0.0)
             return None, (xs, y, keep)
         fuse = optimizer if (not dp and hasattr(optimizer, "fused_descriptor")) else None
+        if eng.dropout_encoders:
+            # nn.Dropout of the MIMIC encoders (train mode): multipliers per REGROUPED row, drawn on the device for the
+            # padded batch; a test's provider speaks in original rows - its masks are carried to where the rows went
+            prov = self.dropout_mask_provider
+            if prov is not None:
+                where, _ = eng.per_sample_positions()
+                rows = int(b.batch)
+
+                def regrouped(e, n_rows, width, _prov=prov, _where=where, _n=int(y.shape[0])):
+                    mk = _prov(e, _n, width)
+                    if mk is None:
+                        return None
+                    out = torch.ones((n_rows, width), dtype=torch.float32, device=self.device)
+                    out[_where] = mk.to(self.device, torch.float32)
+                    return out
+                prov = regrouped
+            keep = (keep, eng.draw_dropout_masks(b, prov))
         eng.local_step(b, alpha, beta, accumulate=not dp, optimizer=fuse, **({"desc": desc} if desc is not None else {}))
         if dp:                                              # per-sample masks / sequences are per-row data: shards add up
             self._dp_all_reduce(eng.reduce_buf)

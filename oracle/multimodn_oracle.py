@@ -687,14 +687,15 @@ PERFORMANCE_METRICS = ["f1", "auc", "accuracy", "sensitivity", "specificity", "f
 
 
 def per_sample_step(params, spec: ModelSpec, xs, y, sequences, dtype=np.float32,
-                    batch_global: Optional[int] = None) -> StepResult:
+                    batch_global: Optional[int] = None, drop_masks: Optional[Dict[int, np.ndarray]] = None) -> StepResult:
     """Build-defined extension for per-sample missingness / per-sample encoder order (SURVEY 9.6,
     BASELINE config 5): the reference only defines this at batch size 1 (multimodn.py:518-523 raises
     otherwise, :168 skips per batch).  The batch result is the mean over samples of the reference's
     batch-size-1 result: cells sum_present CE / B, state change sum_present mean_j(ds^2) / B,
     counters over present samples only; grads are the mean of per-sample grads (None -> 0).
     batch_global: the divisor (defaults to B); a data-parallel shard passes the global sample count, so that the
-    shards' results add up to the whole batch's."""
+    shards' results add up to the whole batch's.
+    drop_masks[e]: MIMIC_MLPEncoder e's dropout multipliers, [B, F_e + S], row b = sample b's (as in forward_backward)."""
     B = np.asarray(y).shape[0]
     Bg = int(batch_global) if batch_global else B
     E, D = spec.E, spec.D
@@ -705,7 +706,8 @@ def per_sample_step(params, spec: ModelSpec, xs, y, sequences, dtype=np.float32,
     for b in range(B):
         xb = [np.asarray(x)[b:b + 1] for x in xs]
         sb = None if sequences is None else np.asarray(sequences)[b:b + 1]
-        r = forward_backward(params, spec, xb, np.asarray(y)[b:b + 1], sb, batch_global=Bg, dtype=dtype)
+        mb = None if drop_masks is None else {e: np.asarray(m)[b:b + 1] for e, m in drop_masks.items()}
+        r = forward_backward(params, spec, xb, np.asarray(y)[b:b + 1], sb, batch_global=Bg, dtype=dtype, drop_masks=mb)
         counts[1:] += r.executed.astype(np.int64)
         for n, g in r.grads.items():
             if g is not None:

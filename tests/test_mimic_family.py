@@ -436,16 +436,87 @@ def test_dropout_drawn_by_the_previous_step(lib):
     torch.cuda.synchronize()
 
 
-def test_unsupported_combinations_are_refused(lib):
-    """Per-sample mode exists in the fused MLPEncoder kernel only: a MIMIC model must refuse it loudly."""
-    spec = O.ModelSpec(16, [O.EncoderSpec(4, (8,), O.ACT_RELU, kind="mimic"), O.EncoderSpec(4, (8,), O.ACT_RELU, kind="mimic")], 1, 1.0, 0.0,
-                       decoders=[O.DecoderSpec("mlp", (8,))])
-    model = build_torch_model(spec, O.init_params(spec, 0), "cuda", lib)
+def _per_sample_case(spec, B, seed, p_missing=0.3):
+    """Synthetic per-sample batch (BASELINE configs[4]): missing-not-at-random NaN rows, a random encoder order per sample."""
+    rng = np.random.default_rng(seed)
+    xs, y = O.synthetic_batches(spec, B, B, seed=seed + 1)[0]
+    pm = np.where(y[:, :1] == 1, 1.5 * p_missing, 0.5 * p_missing)
+    miss = rng.random((B, spec.E)) < pm
+    xs = [x.copy() for x in xs]
+    for e in range(spec.E):
+        xs[e][miss[:, e]] = np.nan
+    seq = np.stack([rng.permutation(spec.E) for _ in range(B)]).astype(np.int64)
+    masks = {e: ((rng.random((B, enc.n_features + spec.state_size)) >= enc.dropout) / (1.0 - enc.dropout)).astype(np.float32)
+             for e, enc in enumerate(spec.encoders) if enc.kind == "mimic" and enc.dropout > 0}
+    return xs, y, seq, masks
+
+
+@pytest.mark.parametrize("B", [37, 4096])
+@pytest.mark.parametrize("family", ["mimic", "mixed"])
+def test_per_sample_mode_of_the_mimic_modules(lib, family, B):
+    """BASELINE configs[4] with the modules the reference's MNAR pipeline builds (MIMIC_MLPEncoder + MLPDecoder,
+    pipelines/mimic/mimic_single_task_mnar_missingness_pipeline.py:163-165): per-sample missing modalities and encoder order
+    on the generic tier (sequential form on regrouped 16-row tiles), dropout multipliers of the reference's kind handed in
+    per ORIGINAL row, against the oracle's sample-by-sample loop: loss cells 1e-5, exact row counts and counters,
+    gradients 2e-5 of float64 truth."""
+    if family == "mimic":
+        F = 64 if B == 4096 else 12
+        S = 128 if B == 4096 else 32
+        H = (32, 32) if B == 4096 else (16,)
+        spec = O.ModelSpec(S, [O.EncoderSpec(F, H, O.ACT_RELU, kind="mimic", dropout=0.2) for _ in range(4)], 3, 1.0, 0.3,
+                           decoders=[O.DecoderSpec("mlp", (32, 32) if B == 4096 else (16,)) for _ in range(3)])
+    else:
+        spec = O.ModelSpec(32, [O.EncoderSpec(12, (16,), O.ACT_RELU, kind="mimic", dropout=0.25), O.EncoderSpec(12, (8, 8), O.ACT_RELU),
+                                O.EncoderSpec(12, (16, 16), O.ACT_RELU, kind="mimic", dropout=0.0)],
+                           2, 1.0, 0.3, decoders=[O.DecoderSpec("mlp", (16, 8)), O.DecoderSpec()])
+    params = O.init_params(spec, 3)
+    xs, y, seq, masks = _per_sample_case(spec, B, seed=21)
+    model = build_torch_model(spec, params, "cuda", lib)
     model.per_sample = True
-    xs = [torch.randn(32, 4), torch.randn(32, 4)]
-    with pytest.raises((lib.hip.MmnError, lib.UnsupportedModelError)):
-        eng = model._get_engine(32)
-        model._run_step_per_sample(eng, xs, torch.zeros(32, 1, dtype=torch.int64), None)
+    model.train()
+    model.dropout_mask_provider = mask_provider(masks)
+    eng = model._get_engine(B)
+    eng.epoch_reset()
+    model._run_step_per_sample(eng, [torch.from_numpy(x) for x in xs], torch.from_numpy(y), torch.from_numpy(seq))
+    eng.assign_grads(None)
+    torch.cuda.synchronize()
+    stats = {k: np.array(v) for k, v in eng.step_values().items()}
+    grads = {n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
+    ref = O.per_sample_step(params, spec, xs, y, seq, drop_masks=masks)
+    p64 = {n: np.asarray(v, np.float64) for n, v in params.items()}
+    ref64 = O.per_sample_step(p64, spec, xs, y, seq, dtype=np.float64, drop_masks=masks)
+    # (against float64: the fp32 oracle ADDS 4096 per-sample results one by one and is itself 3e-5 off at this size)
+    assert rel_err(stats["err_loss"], ref64.err_loss) < 1e-5 and rel_err(stats["state_change"], ref64.state_change) < 1e-5
+    assert np.array_equal(stats["rows"].astype(np.int64), ref.row_counts)
+    for k in ("n_correct", "tp", "tn", "fp", "fn"):
+        assert np.array_equal(stats[k].astype(np.int64), getattr(ref, k)), k
+    g_all = max(float(np.max(np.abs(g))) for g in ref64.grads.values() if g is not None)
+    for n, g in ref64.grads.items():
+        got = grads[n].reshape(np.asarray(params[n]).shape)
+        if g is None:
+            assert np.abs(got).max() == 0.0, n
+        else:
+            assert float(np.max(np.abs(got - g))) <= max(2e-5 * float(np.max(np.abs(g))), 2e-6 * g_all), n
+
+
+def test_per_sample_training_of_the_mimic_modules(lib):
+    """train_epoch in per-sample mode with MIMIC modules (device-drawn dropout, fused Adam): runs, the loss falls, test()
+    and predict() agree with each other on the regrouped path."""
+    spec = O.ModelSpec(32, [O.EncoderSpec(12, (16,), O.ACT_RELU, kind="mimic", dropout=0.1) for _ in range(3)], 2, 1.0, 0.3,
+                       decoders=[O.DecoderSpec("mlp", (16,)) for _ in range(2)])
+    xs, y, seq, _ = _per_sample_case(spec, 192, seed=5)
+    model = build_torch_model(spec, O.init_params(spec, 1), "cuda", lib)
+    model.per_sample = True
+    opt = lib.optim.Adam(model.parameters(), lr=1e-2)
+    hist = lib.MultiModNHistory(["a", "b"])
+    loader = [([torch.from_numpy(x[s:s + 64]) for x in xs], torch.from_numpy(y[s:s + 64]), torch.from_numpy(seq[s:s + 64]))
+              for s in range(0, 192, 64)]
+    for _ in range(12):
+        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+    loss = np.stack(hist.loss["train"])
+    assert np.isfinite(loss).all() and loss[-1].mean() < loss[0].mean()
+    model.test(loader, torch.nn.CrossEntropyLoss(), hist, tag="val")
+    assert np.isfinite(hist.loss["val"][0]).all()
 
 
 import collections

@@ -1,0 +1,62 @@
+"""Diagnostic: when and where every k_wgrad workgroup ran (MMN_STAMPS=1): start / end on the 100 MHz wall clock, CU and XCD."""
+import os, sys
+os.environ["MMN_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import multimodn_amd as mm
+import bench
+wl = bench.WORKLOADS["c3"]
+model = bench.build_model(mm, wl, torch.device("cuda"))
+model.nan_policy = "device"
+B = wl["B"]
+host = bench.synthetic_batches(wl, B * 8, B, seed=1)
+res = [([torch.from_numpy(x).cuda() for x in xs], torch.from_numpy(y).cuda()) for xs, y in host]
+opt = mm.optim.Adam(list(model.parameters()), wl["lr"])
+steps = [res[i % 8] for i in range(64)]
+for _ in range(3):
+    model._train_steps(steps, opt)              # the real step sequence (fused Adam, pre-scan blocks, graphs)
+torch.cuda.synchronize()
+eng = model._engine
+ptr = eng.lib.mmn_debug_buffer(eng._plan, 3, 0)
+off = ptr - eng.workspace.data_ptr()
+raw = eng.workspace[off:off + 8 * (256 + 4096 + 1024)].view(torch.int64).cpu().numpy()
+rd = raw[256 + 4096:].reshape(512, 2)
+st = raw[256:256 + 4096].reshape(1024, 4)
+n = int((st[:, 0] > 0).sum())
+st = st[:n]
+t0 = st[:, 0].min()
+start = (st[:, 0] - t0) / 100.0; end = (st[:, 1] - t0) / 100.0
+hw = st[:, 2]; xcc = st[:, 3] & 15
+cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+cuid = xcc * 64 + se * 16 + sh * 8 + cu          # not dense, only an identity
+print("workgroups", n, "kernel span", end.max(), "us; starts: median", np.median(start), "max", start.max())
+dur = end - start
+order = np.argsort(-end)
+print("last 12 to finish: (block, start, end, dur, xcc, cu)")
+for i in order[:12]:
+    print(f"  {i:4d} {start[i]:6.2f} {end[i]:6.2f} {dur[i]:6.2f} xcc {xcc[i]} cu {cuid[i]}")
+from collections import Counter
+per_cu = Counter(cuid.tolist())
+print("distinct CUs", len(per_cu), "workgroups per CU histogram", Counter(per_cu.values()))
+# duration by co-residency
+multi = np.array([per_cu[c] for c in cuid])
+for k in sorted(set(multi.tolist())):
+    sel = multi == k
+    print(f"  CUs with {k} workgroups: {sel.sum()} wgs, dur mean {dur[sel].mean():.2f} max {dur[sel].max():.2f}, end max {end[sel].max():.2f}")
+qs = np.percentile(dur, [0, 25, 50, 75, 100])
+print("duration quartiles", " ".join(f"{q:.2f}" for q in qs))
+# duration by launch position (cost class follows the sorted order)
+for lo in range(0, n, 32):
+    sel = slice(lo, min(n, lo + 32))
+    print(f"  blocks {lo:3d}+: start {start[sel].mean():5.2f} dur {dur[sel].mean():5.2f} (max {dur[sel].max():5.2f}) end {end[sel].max():5.2f}")
+
+nr = int((rd[:, 0] > 0).sum()); rd = rd[:nr]
+r0 = rd[0, 0]
+print("k_reduce: workgroups", nr, "start of first after k_wgrad's last end:", (r0 - st[:, 1].max()) / 100.0, "us; span", (rd[:, 1].max() - r0) / 100.0)
+gb = eng.lib.mmn_debug_buffer  # noqa
+for i in list(range(0, nr, 16)) + [93, 94, 95, nr - 1]:
+    print(f"  block {i:3d}: start {(rd[i,0]-r0)/100.0:5.2f} end {(rd[i,1]-r0)/100.0:5.2f}")
+
+g = raw[120:123]
+print("stats block: start -> partials summed", (g[0] - rd[94, 0]) / 100.0, "-> barrier", (g[1] - g[0]) / 100.0, "-> stats stored", (g[2] - g[1]) / 100.0,
+      "-> end (epoch)", (rd[94, 1] - g[2]) / 100.0)

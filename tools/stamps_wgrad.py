@@ -43,6 +43,12 @@ multi = np.array([per_cu[c] for c in cuid])
 for k in sorted(set(multi.tolist())):
     sel = multi == k
     print(f"  CUs with {k} workgroups: {sel.sum()} wgs, dur mean {dur[sel].mean():.2f} max {dur[sel].max():.2f}, end max {end[sel].max():.2f}")
+if n > 256:
+    same = sum(int(cuid[j] == cuid[j - 256]) for j in range(256, n))
+    print("second-round workgroups on the CU of block j - 256:", same, "of", n - 256)
+    first = {int(cuid[j]): j for j in range(256)}
+    print("  partner (first-round block on the same CU) of blocks 256..271:", [first.get(int(cuid[j]), -1) for j in range(256, min(n, 272))])
+    print("  xcc of blocks 0..15:", xcc[:16].tolist(), " cu-in-xcc of blocks 0,8,16,..:", [int(cuid[j]) % 64 for j in range(0, 128, 8)])
 qs = np.percentile(dur, [0, 25, 50, 75, 100])
 print("duration quartiles", " ".join(f"{q:.2f}" for q in qs))
 # duration by launch position (cost class follows the sorted order)

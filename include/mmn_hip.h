@@ -43,7 +43,8 @@
 extern "C" {
 #endif
 
-#define MMN_VERSION 105            /* 0.1.5: mmn_step_opts.next_drop_* (the next step's dropout multipliers in this step's last launch), mmn_dropout_adopt;
+#define MMN_VERSION 106            /* 0.1.6: mmn_dp_rescale (uneven data-parallel shards);
+                                      0.1.5: mmn_step_opts.next_drop_* (the next step's dropout multipliers in this step's last launch), mmn_dropout_adopt;
                                       0.1.4: mmn_train_step_ex (pre-scan of the next batch, flag sets in the stats block), mmn_pack_invalidate;
                                       0.1.3: + mmn_draw_dropout; 0.1.2: MIMIC_MLPEncoder / MLPDecoder (mmn_encoder.kind, mmn_decoder.hidden, mmn_batch.drop_mask) */
 #define MMN_MAX_ENCODERS 16
@@ -259,6 +260,14 @@ int mmn_reduce(mmn_plan* p, const mmn_batch* b, void* stream);
 /* Loss combination (multimodn.py:194-202) and epoch accumulators (multimodn.py:206-212) from
  * `stats` (call after the all-reduce when data-parallel). */
 int mmn_epoch_accumulate(mmn_plan* p, float err_penalty, float state_change_penalty_x001, void* stream);
+
+/* Data parallel with uneven shards (ranks feed different numbers of rows, e.g. the last batch of an epoch): every rank
+ * runs its step with mmn_batch.batch_global = `nominal_batch` - the same power of two on all ranks - and, after the
+ * all-reduce of [grads | stats], calls this in front of mmn_epoch_accumulate / mmn_adam_step_accumulate: the n floats
+ * at `grads` (n may be 0: evaluation), the loss cells and the state changes are multiplied by
+ * nominal_batch / (rows of grid row 0 in the summed stats = the true global batch), which makes them the reference's
+ * means over the global batch (multimodn.py:184-196).  Counters and row counts are sums already. */
+int mmn_dp_rescale(mmn_plan* p, float* grads, int64_t n, int nominal_batch, void* stream);
 
 /* prepare + chain_fwd + chain_bwd + wgrad + reduce in order: one full multimodn.py:137-203 body
  * (without optimizer.step).  accumulate_epoch != 0 folds mmn_epoch_accumulate into the reduce

@@ -694,6 +694,14 @@ class HipChainEngine:
         optimizer.mark_fused_step()
         return True
 
+    def dp_rescale(self, nominal_batch: int, with_grads: bool = True) -> None:
+        """Data parallel with uneven shards, after the all-reduce and in front of accumulate*(): the step ran with
+        batch_global = nominal_batch on every rank; gradients, loss cells and state changes become means over the
+        true global batch (the summed row count of grid row 0), include/mmn_hip.h mmn_dp_rescale."""
+        hip.check(self.lib.mmn_dp_rescale(self._plan, self.flat_grads.data_ptr() if with_grads else None,
+                                          self.n_params if with_grads else 0, int(nominal_batch), self._stream()),
+                  "mmn_dp_rescale")
+
     def accumulate(self, err_penalty: float, sc_penalty_x001: float) -> None:
         hip.check(self.lib.mmn_epoch_accumulate(self._plan, err_penalty, sc_penalty_x001, self._stream()),
                   "mmn_epoch_accumulate")

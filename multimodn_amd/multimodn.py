@@ -159,12 +159,23 @@ class MultiModN(nn.Module):
         return state
 
     # ------------------------------------------------------------------------------------------
-    def enable_data_parallel(self, process_group=None) -> None:
+    #: divisor every rank uses when shards may be uneven: a power of two (exact division), corrected to the true
+    #: global batch after the all-reduce (engine.dp_rescale)
+    DP_NOMINAL_BATCH = 1 << 16
+
+    def enable_data_parallel(self, process_group=None, uneven_shards: bool = False) -> None:
         """One process per GPU: every rank feeds its shard of each global mini-batch; gradients and
-        the per-step statistics are summed with ONE all-reduce (RCCL over xGMI) per step."""
+        the per-step statistics are summed with ONE all-reduce (RCCL over xGMI) per step.
+
+        By default every rank must feed the same number of rows per step (global batch = rows x world: what
+        DistributedSampler's padding guarantees).  `uneven_shards=True` lifts that (a last batch of 4096 + 4095 + ...
+        rows; every rank still needs at least one row per step): all ranks divide by the same nominal batch and the
+        true global row count, which rides in the step's one all-reduce anyway, corrects the means afterwards - one
+        more small launch per step, no further collective."""
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
+        self._dp_nominal = int(self.DP_NOMINAL_BATCH) if uneven_shards else 0
         self._dp_group = process_group if process_group is not None else dist.group.WORLD
         self._dp_world = dist.get_world_size(self._dp_group)
         self._dp_rank = dist.get_rank(self._dp_group)
@@ -290,6 +301,12 @@ class MultiModN(nn.Module):
             eng.assign_grads(None)
         return fd
 
+    def _global_rows(self, local_rows: int) -> int:
+        """The divisor of this step's means: the global batch (local rows x ranks), or the nominal batch all ranks
+        agree on when shards may be uneven (enable_data_parallel)."""
+        nominal = getattr(self, "_dp_nominal", 0) if self._dp_group is not None else 0
+        return nominal if nominal else local_rows * self._dp_world
+
     def _dp_all_reduce(self, buf: Tensor) -> None:
         """Sum over the ranks, in place.  RCCL takes device buffers; any other backend (gloo in the tests) gets the
         buffer through the host."""
@@ -315,7 +332,7 @@ class MultiModN(nn.Module):
     def _make_step(self, data, target, encoder_sequence, mode: str, train: bool) -> "MultiModN._Step":
         pairs = self.get_encoder_iterable(encoder_sequence, self.shuffle_mode, train=train)
         xs, y, exec_pairs, executed, on_host = self._ingest(data, target, pairs, mode)
-        return MultiModN._Step(xs, y, exec_pairs, executed, on_host, int(y.shape[0]) * self._dp_world)
+        return MultiModN._Step(xs, y, exec_pairs, executed, on_host, self._global_rows(int(y.shape[0])))
 
     def _launch_step(self, eng, st: "MultiModN._Step", nxt: Optional["MultiModN._Step"], train: bool, optimizer, mode: str,
                      desc=None):
@@ -345,6 +362,8 @@ class MultiModN(nn.Module):
             eng.eval_step(b, accumulate=not dp)
         if dp:
             self._dp_all_reduce(eng.reduce_buf if train else eng.stats)     # THE collective of the step: grads + stats + flags
+            if getattr(self, "_dp_nominal", 0):
+                eng.dp_rescale(self._dp_nominal, with_grads=train)
             if train and optimizer is not None:
                 # epoch accumulation + Adam in one launch when the optimizer is multimodn_amd.optim.Adam
                 # (it leaves the parameters of encoders that did not run untouched, like grad None)
@@ -376,7 +395,7 @@ class MultiModN(nn.Module):
             seq = encoder_sequence if isinstance(encoder_sequence, Tensor) else torch.as_tensor(np.asarray(encoder_sequence))
             seq = seq.to(self.device, torch.int64)
         b, keep = eng.per_sample_batch(xs, y, seq)
-        b.batch_global = int(y.shape[0]) * self._dp_world
+        b.batch_global = self._global_rows(int(y.shape[0]))
         return b, keep, xs, y
 
     def _run_step_per_sample(self, eng, data, target, encoder_sequence, optimizer=None, train: bool = True, regrouped=None,
@@ -391,6 +410,8 @@ class MultiModN(nn.Module):
             eng.eval_step(b, accumulate=not dp)
             if dp:
                 self._dp_all_reduce(eng.stats)
+                if getattr(self, "_dp_nominal", 0):
+                    eng.dp_rescale(self._dp_nominal, with_grads=False)
                 eng.accumulate(1.0, 0.0)
             return None, (xs, y, keep)
         fuse = optimizer if (not dp and hasattr(optimizer, "fused_descriptor")) else None
@@ -414,6 +435,8 @@ class MultiModN(nn.Module):
         eng.local_step(b, alpha, beta, accumulate=not dp, optimizer=fuse, **({"desc": desc} if desc is not None else {}))
         if dp:                                              # per-sample masks / sequences are per-row data: shards add up
             self._dp_all_reduce(eng.reduce_buf)
+            if getattr(self, "_dp_nominal", 0):
+                eng.dp_rescale(self._dp_nominal)
             if optimizer is not None:
                 eng.accumulate_and_step(alpha, beta, optimizer)
             else:
@@ -711,7 +734,7 @@ class MultiModN(nn.Module):
                         if len(cache) >= _BATCH_CACHE_MAX:
                             cache.clear()
                         cache[id(batch)] = (batch, tmpl)
-                    b.batch_global = int(y.shape[0]) * self._dp_world
+                    b.batch_global = self._global_rows(int(y.shape[0]))
                     return (b, keep, keep[5], keep[6]), ev, slot
             return self._regroup_per_sample(eng, data, target, encoder_sequence), None, slot
 

@@ -241,6 +241,16 @@ class OracleEngine:
         self.accumulate(alpha, beta)
         return False                     # the caller's optimizer.step() still has to run
 
+    def dp_rescale(self, nominal_batch, with_grads=True):
+        """numpy twin of k_dp_rescale."""
+        st = self.stats.numpy()
+        R, D, E = self.E + 1, self.D, self.E
+        RD = R * D
+        f = np.float32(nominal_batch) / st[RD + E + 5 * RD]
+        st[:RD + E] *= f
+        if with_grads:
+            self.flat_grads.mul_(float(f))
+
     def accumulate(self, alpha, beta):
         """numpy twin of k_epoch_accumulate."""
         st = self.stats.numpy()

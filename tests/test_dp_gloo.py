@@ -21,6 +21,18 @@ def _free_port():
     return p
 
 
+def _cut(rank, world, n, uneven):
+    """[lo, hi) of this rank's rows of an n-row global batch: equal parts, or (uneven) rank 0 takes one row more than its
+    share from its neighbour - shards of different sizes, every rank keeps at least one row."""
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    if uneven and world > 1 and n // world > 1:
+        if rank == 0:
+            hi += 1
+        elif rank == 1:
+            lo += 1
+    return lo, hi
+
+
 def _count_collectives(dist):
     """Every collective torch.distributed offers, counted: the protocol promises ONE all-reduce per step (+ one for the
     first batch of an epoch, whose NaN flags no earlier step could carry)."""
@@ -40,7 +52,7 @@ def _count_collectives(dist):
     return calls
 
 
-def _worker(rank, world, port, name, out_dir, policy="auto"):
+def _worker(rank, world, port, name, out_dir, policy="auto", uneven=False):
     import torch.distributed as dist
     import multimodn_amd as mm
     from oracle_engine import OracleEngine
@@ -52,7 +64,7 @@ def _worker(rank, world, port, name, out_dir, policy="auto"):
     model = build_torch_model(g.spec, g.init_params(), "cpu", mm)
     model._engine_factory = OracleEngine
     model.nan_policy = policy
-    model.enable_data_parallel()
+    model.enable_data_parallel(uneven_shards=uneven)
     calls = _count_collectives(dist)
     opt = torch.optim.Adam(list(model.parameters()), g.cfg["lr"])
     hist = mm.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
@@ -60,7 +72,7 @@ def _worker(rank, world, port, name, out_dir, policy="auto"):
     for b in g.batches():
         n = len(b[1])
         assert n % world == 0
-        lo, hi = rank * n // world, (rank + 1) * n // world
+        lo, hi = _cut(rank, world, n, uneven)
         item = [[torch.from_numpy(x[lo:hi]) for x in b[0]], torch.from_numpy(b[1][lo:hi])]
         if len(b) > 2:
             item.append(torch.from_numpy(b[2][lo:hi]))
@@ -72,8 +84,8 @@ def _worker(rank, world, port, name, out_dir, policy="auto"):
         m = g.step_masks(model.train_steps_launched).get(e)
         if m is None:
             return None
-        n = m.shape[0]
-        return torch.from_numpy(m[rank * n // world:(rank + 1) * n // world])
+        lo, hi = _cut(rank, world, m.shape[0], uneven)
+        return torch.from_numpy(m[lo:hi])
 
     model.dropout_mask_provider = provide
     for _ in range(g.epochs):
@@ -117,13 +129,37 @@ def test_two_rank_dp_equals_single_process(name, policy, tmp_path):
         assert_within_fp32_noise(r0["p/" + n], w, w64[n], n)
 
 
+def _assert_equals_golden(r0, g, tol):
+    z = g.z
+    assert rel_err(r0["loss"], z["hist/loss"]) < tol
+    assert rel_err(r0["sc"], z["hist/state_change"]) < tol
+    assert np.abs(r0["acc"] - z["hist/accuracy"]).max() <= 1.0 / g.cfg["B"] + 1e-12
+    w64 = fp64_trajectory(g)[0]
+    for n, w in g.final_params().items():
+        assert_within_fp32_noise(r0["p/" + n], w, w64[n], n)
+
+
+@pytest.mark.parametrize("name,policy", [("seq_perm", "auto"), ("nan_skip", "auto"), ("mimic_drop", "auto")])
+def test_two_rank_dp_with_uneven_shards_equals_single_process(name, policy, tmp_path):
+    """enable_data_parallel(uneven_shards=True): rank 0 feeds one row more than rank 1 in every step; the ranks divide by
+    the same nominal batch and correct with the summed row count that rides in the step's ONE all-reduce (no further
+    collective): History and trained weights are the single-process golden run's."""
+    g = Golden(name)
+    mp.spawn(_worker, args=(2, _free_port(), name, str(tmp_path), policy, True), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), k
+    _check_collectives(r0)
+    _assert_equals_golden(r0, g, 5e-6)
+
+
 # ------------------------------------------------------------------------------------------------
 # The same protocol on the HIP engine: two ranks sharing ONE GPU (gloo moves the reduce buffer through
 # the host, RCCL refuses two ranks on one device).  Checks the real kernels' shard arithmetic
 # (batch_global divisors), the one-buffer all-reduce, the global NaN decision under both policies and
 # the one-launch data-parallel tail.
 # ------------------------------------------------------------------------------------------------
-def _gpu_worker(rank, world, port, name, policy, out_dir):
+def _gpu_worker(rank, world, port, name, policy, out_dir, uneven=False):
     import torch.distributed as dist
     import multimodn_amd as mm
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -133,14 +169,14 @@ def _gpu_worker(rank, world, port, name, policy, out_dir):
     g = Golden(name)
     model = build_torch_model(g.spec, g.init_params(), "cuda", mm)
     model.nan_policy = policy
-    model.enable_data_parallel()
+    model.enable_data_parallel(uneven_shards=uneven)
     calls = _count_collectives(dist)
     opt = mm.optim.Adam(list(model.parameters()), g.cfg["lr"])
     hist = mm.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
     loader = []
     for b in g.batches():
         n = len(b[1])
-        lo, hi = rank * n // world, (rank + 1) * n // world
+        lo, hi = _cut(rank, world, n, uneven)
         item = [[torch.from_numpy(x[lo:hi]) for x in b[0]], torch.from_numpy(b[1][lo:hi])]
         if len(b) > 2:
             item.append(torch.from_numpy(b[2][lo:hi]))
@@ -151,8 +187,8 @@ def _gpu_worker(rank, world, port, name, policy, out_dir):
         m = g.step_masks(model.train_steps_launched).get(e)
         if m is None:
             return None
-        n = m.shape[0]
-        return torch.from_numpy(m[rank * n // world:(rank + 1) * n // world])
+        lo, hi = _cut(rank, world, m.shape[0], uneven)
+        return torch.from_numpy(m[lo:hi])
 
     model.dropout_mask_provider = provide
     for _ in range(g.epochs):
@@ -184,6 +220,78 @@ def test_two_rank_dp_on_one_gpu_equals_reference_golden(name, policy, tmp_path):
     w64 = fp64_trajectory(g)[0]                          # 2e-5 of the reference's weights, or within fp32 noise of the fp64 replay
     for n, w in g.final_params().items():
         assert_within_fp32_noise(r0["p/" + n], w, w64[n], n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,policy", [("seq_perm", "device"), ("nan_skip", "host"), ("c2_split", "device"), ("mimic_mixed", "device")])
+def test_two_rank_dp_with_uneven_shards_on_one_gpu(name, policy, tmp_path):
+    """Uneven shards on the real kernels (mmn_dp_rescale between the all-reduce and the one-launch tail)."""
+    g = Golden(name)
+    mp.spawn(_gpu_worker, args=(2, _free_port(), name, policy, str(tmp_path), True), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), k
+    _check_collectives(r0)
+    _assert_equals_golden(r0, g, 1e-5)
+
+
+def _c3_case():
+    from oracle import multimodn_oracle as O
+    spec = O.ModelSpec(128, [O.EncoderSpec(64, (32, 32), O.ACT_RELU) for _ in range(4)], 3, 1.0, 0.3)
+    return spec, O.init_params(spec, 0), O.synthetic_batches(spec, 3 * 4096, 4096, seed=11)
+
+
+def _strong_worker(rank, world, port, out_dir):
+    """Strong scaling: the 4,096-row global batch of BASELINE.json's configs[2] split over the ranks (2,048 rows each)."""
+    import torch.distributed as dist
+    import multimodn_amd as mm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    spec, params, batches = _c3_case()
+    model = build_torch_model(spec, params, "cuda", mm)
+    model.nan_policy = "device"
+    model.enable_data_parallel()
+    opt = mm.optim.Adam(list(model.parameters()), 1e-3)
+    hist = mm.MultiModNHistory([f"t{d}" for d in range(spec.D)])
+    loader = []
+    for xs, y in batches:
+        lo, hi = _cut(rank, world, len(y), False)
+        loader.append(([torch.from_numpy(x[lo:hi]).cuda() for x in xs], torch.from_numpy(y[lo:hi]).cuda()))
+    model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=np.stack(hist.loss["train"]),
+             **{"p/" + k: v.cpu().numpy() for k, v in model.state_dict().items()})
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_strong_scaling_two_ranks_equal_the_single_process_run(tmp_path):
+    """configs[3] in its strong-scaling form on the one GPU of the box: 4,096 rows per step as 2 x 2,048 over two ranks
+    (gloo carries the reduce buffer; both ranks run the real kernels) against the SAME three fused Adam steps in one
+    process: weights within fp32 noise of the float64 trajectory by the single-process test's yardstick (helpers.
+    full_size_trajectories / assert_within_fp32_noise), epoch loss equal to 1e-5."""
+    import multimodn_amd as lib
+    from helpers import full_size_trajectories
+    lib.hip.load()
+    spec, params, batches = _c3_case()
+    model, p32, p64, flipped = full_size_trajectories(lib, spec, params, batches, 1e-3)
+    single_loss = model._engine.epoch_read()
+    mp.spawn(_strong_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), k
+    compared = 0
+    for n, p in model.named_parameters():
+        if n in flipped:
+            continue
+        assert_within_fp32_noise(r0["p/" + n], p32[n], p64[n], n)
+        compared += 1
+    assert compared >= 12
+    R, D = spec.E + 1, spec.D
+    want = (single_loss["err_sum"] / single_loss["n_steps"]).reshape(R, D)
+    assert rel_err(r0["loss"][0].reshape(R, D), want) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------

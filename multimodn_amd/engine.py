@@ -433,7 +433,7 @@ class HipChainEngine:
     MAX_STEP_GRAPHS = 64
 
     def run_group(self, steps, nxt, err_penalty: float, sc_penalty_x001: float, optimizer, draw_dropout: bool,
-                  desc=None) -> bool:
+                  desc=None, reset_first: bool = False) -> bool:
         """`steps`: consecutive training steps (device NaN policy, Adam fused) as (xs, y, pairs, batch_global, hip.Batch,
         key) tuples (make_batch_keyed) whose device buffers this engine may have seen before; `nxt`: the step after them (or None) - the last
         step of the group pre-scans its batch.  The group - per step k_dropout, [k_prepare scan], chain, k_wgrad,
@@ -443,8 +443,10 @@ class HipChainEngine:
         batch sizes of 16-32 rows the step is host-bound otherwise.  Everything a replay must see fresh lives in device
         memory (Adam step counters, epoch accumulators, NaN flags, the dropout draw index); what is baked into the
         graph is in the key: buffers, flag sets, sequences, hyper-parameters, dropout seed, the optimizer's buffers,
-        whether the first batch arrives pre-scanned.  Returns False when the group cannot be replayed: the caller runs
-        its steps eagerly (which is also the warm-up before the capture)."""
+        whether the first batch arrives pre-scanned.  `reset_first`: the group is the first of an epoch and its graph
+        starts with the reset of the epoch accumulators (a memset node: epoch_reset() as a call of its own costs ~10 us of
+        host time in front of the call's first launch).  Returns False when the group cannot be replayed - nothing has
+        been launched, not even the reset: the caller runs it eagerly (which is also the warm-up before the capture)."""
         d = desc if desc is not None else (optimizer.fused_descriptor(self) if hasattr(optimizer, "fused_descriptor") else None)
         if d is None or torch.cuda.is_current_stream_capturing() or self._step_graphs is None:
             return False
@@ -456,7 +458,7 @@ class HipChainEngine:
         entry_ready = bool(first.nan_flags and self._prescanned is first)
         entry_drawn = bool(draw_dropout and self._predrawn is first)
         hp = self.group_hp_key(err_penalty, sc_penalty_x001, optimizer, d, seed)
-        key = (tuple(st[5] for st in steps), None if nxt is None else nxt[5], entry_ready, entry_drawn) + hp
+        key = (tuple(st[5] for st in steps), None if nxt is None else nxt[5], entry_ready, entry_drawn, bool(reset_first)) + hp
         ent = self._step_graphs.get(key)
         if ent is None:
             if len(self._step_graphs) >= self.MAX_STEP_GRAPHS:
@@ -479,6 +481,8 @@ class HipChainEngine:
                 saved, saved_drawn = self._prescanned, self._predrawn
                 with torch.cuda.stream(side):
                     with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                        if reset_first:
+                            self.epoch_reset()
                         for i, (xs, y, pairs, bg, b, _k) in enumerate(steps):
                             nb = steps[i + 1][4] if i + 1 < len(steps) else (None if nxt is None else nxt[4])
                             if draw_dropout:
@@ -494,7 +498,7 @@ class HipChainEngine:
                 self._prescanned = None
                 self._predrawn = None
                 return False
-        ent[3] = (hp, entry_ready, entry_drawn)
+        ent[3] = (hp, entry_ready, entry_drawn, bool(reset_first))
         self.replay_entry(ent, steps, nxt, optimizer, draw_dropout)
         return True
 
@@ -516,19 +520,20 @@ class HipChainEngine:
         self._predrawn = nxt[4] if (draw_dropout and nxt is not None and not nxt[4].tile_seq) else None
         optimizer.mark_fused_step()
 
-    def replay_known(self, ent, steps, nxt, hp, optimizer, draw_dropout: bool) -> bool:
+    def replay_known(self, ent, steps, nxt, hp, optimizer, draw_dropout: bool, reset_first: bool = False) -> bool:
         """The whole-call replay's shortcut (MultiModN._replay_epoch_plan): `ent` is the cache entry this very group was
         replayed from last time; it is replayed again without rebuilding its key if what the key stands for is unchanged -
         hyper-parameters `hp`, and whether the first batch arrives pre-scanned / pre-drawn."""
         if ent is None or ent[1] is None or ent[3] is None or torch.cuda.is_current_stream_capturing():
             return False
         first = steps[0][4]
-        if ent[3] != (hp, bool(first.nan_flags and self._prescanned is first), bool(draw_dropout and self._predrawn is first)):
+        if ent[3] != (hp, bool(first.nan_flags and self._prescanned is first), bool(draw_dropout and self._predrawn is first),
+                      bool(reset_first)):
             return False
         self.replay_entry(ent, steps, nxt, optimizer, draw_dropout)
         return True
 
-    def group_entry(self, steps, nxt, err_penalty, sc_penalty_x001, optimizer, draw_dropout: bool, desc):
+    def group_entry(self, steps, nxt, err_penalty, sc_penalty_x001, optimizer, draw_dropout: bool, desc, reset_first: bool = False):
         """The cache entry run_group would use for this group right now (None if there is none)."""
         if self._step_graphs is None or desc is None:
             return None, None
@@ -536,7 +541,7 @@ class HipChainEngine:
         first = steps[0][4]
         hp = self.group_hp_key(err_penalty, sc_penalty_x001, optimizer, desc, seed)
         key = (tuple(st[5] for st in steps), None if nxt is None else nxt[5], bool(first.nan_flags and self._prescanned is first),
-               bool(draw_dropout and self._predrawn is first)) + hp
+               bool(draw_dropout and self._predrawn is first), bool(reset_first)) + hp
         return self._step_graphs.get(key), hp
 
     # ------------------------------------------------------------------ per-sample mode (BASELINE configs[4])

@@ -485,7 +485,7 @@ class MultiModN(nn.Module):
             data, target, encoder_sequence = (list(batch) + [None])[:3]
             if state["eng"] is None:
                 eng = state["eng"] = self._get_engine(int(target.shape[0]))
-                eng.epoch_reset()
+                state["need_reset"] = True                   # (in front of the first launch: inside its graph when it is a replay)
                 eng.begin_sequence()
                 # (the optimizer's descriptor walks every parameter: once per epoch, not once per step)
                 state["mode"] = self._nan_mode(eng, optimizer, True)
@@ -562,10 +562,12 @@ class MultiModN(nn.Module):
                 if not state["grads_assigned"]:
                     eng.assign_grads(None)
                     state["grads_assigned"] = True
+                reset_now = bool(state.get("need_reset"))
                 ent_now = eng.group_entry(steps, nxt, float(self.err_penalty), float(self.state_change_penalty), optimizer,
-                                          bool(eng.dropout_encoders), state["fd"])[0] if plan_ok else None
+                                          bool(eng.dropout_encoders), state["fd"], reset_now)[0] if plan_ok else None
                 if eng.run_group(steps, nxt, float(self.err_penalty), float(self.state_change_penalty), optimizer,
-                                 bool(eng.dropout_encoders), state["fd"]):
+                                 bool(eng.dropout_encoders), state["fd"], reset_first=reset_now):
+                    state["need_reset"] = False
                     rec.append((steps, nxt, ent_now))
                     for _ in range(n):
                         window.popleft()
@@ -576,6 +578,9 @@ class MultiModN(nn.Module):
             # eagerly: the whole group (first sighting of its buffers: the groups of later epochs then start at the same
             # positions), or the single step
             plan_ok = False                                  # (a step outside a replayed group: no plan from this call)
+            if state.get("need_reset"):
+                eng.epoch_reset()
+                state["need_reset"] = False
             for _ in range(n):
                 st = window.popleft()
                 nxt = window[0] if window else None
@@ -648,7 +653,6 @@ class MultiModN(nn.Module):
         if fd is None or not eng.adam_fusable(optimizer, fd):
             return None
         mode = "device"
-        eng.epoch_reset()
         eng.begin_sequence(sig_checked=True)
         if eng.params[0].grad is not eng.grad_views[0] or eng.params[-1].grad is not eng.grad_views[-1]:
             eng.assign_grads(None)
@@ -658,9 +662,14 @@ class MultiModN(nn.Module):
         if draw and eng._dropout_seed() != eng._drop_seed:    # a new torch seed restarts the draw index: the slow path does that
             return None
         total = 0
+        need_reset = True                                    # the epoch accumulators: zeroed by the first group's graph
         for steps, nxt, ent in ep["groups"]:
-            if eng.replay_known(ent, steps, nxt, hp, optimizer, draw) or \
-                    eng.run_group(steps, nxt, alpha, beta, optimizer, draw, fd):
+            ok = eng.replay_known(ent, steps, nxt, hp, optimizer, draw, reset_first=need_reset) or \
+                eng.run_group(steps, nxt, alpha, beta, optimizer, draw, fd, reset_first=need_reset)
+            if need_reset and not ok:
+                eng.epoch_reset()
+            need_reset = False
+            if ok:
                 optimizer.fused_step_seen(len(steps))
             else:                                            # a key miss (LR schedule, new dropout seed, ...): this group eagerly
                 for i, (xs, y, pairs, bg, b, key) in enumerate(steps):

@@ -60,7 +60,7 @@ nr = int((rd[:, 0] > 0).sum()); rd = rd[:nr]
 r0 = rd[0, 0]
 print("k_reduce: workgroups", nr, "start of first after k_wgrad's last end:", (r0 - st[:, 1].max()) / 100.0, "us; span", (rd[:, 1].max() - r0) / 100.0)
 gb = eng.lib.mmn_debug_buffer  # noqa
-for i in list(range(0, nr, 16)) + [93, 94, 95, nr - 1]:
+for i in list(range(0, nr, 16)) + [92, 93, 94, 95, 96, nr - 1]:
     print(f"  block {i:3d}: start {(rd[i,0]-r0)/100.0:5.2f} end {(rd[i,1]-r0)/100.0:5.2f}")
 
 g = raw[120:123]

@@ -562,8 +562,8 @@ class HipChainEngine:
             raise UnsupportedModelError("per-sample encoder order needs modalities of equal width "
                                         "(slot k must be able to feed any encoder)")
         rows = int(self.lib.mmn_regroup_rows(B, E))
-        if rows > 0 and B <= 16384 and not self._torch_regroup:
-            # three HIP launches (k_ps_code / k_ps_layout / k_ps_gather) instead of ~40 torch ops
+        if rows > 0 and not self._torch_regroup:
+            # four HIP launches (k_ps_code / k_ps_hist / k_ps_layout / k_ps_gather) instead of ~40 torch ops, any batch size
             self.ensure(rows)
             xs_p = [torch.empty((rows, f), dtype=torch.float32, device=dev) for f in feats]
             y_p = torch.empty((rows, y.shape[1]), dtype=torch.int64, device=dev)
@@ -627,7 +627,7 @@ class HipChainEngine:
         E, B, dev = self.E, int(y.shape[0]), self.device
         rows = int(self.lib.mmn_regroup_rows(B, E)) if len(xs) == E and E <= 4 else 0
         feats = [int(enc.n_features) for enc in self.model.encoders]
-        if rows <= 0 or B > 16384 or self._torch_regroup or (seq is not None and len(set(feats)) != 1):
+        if rows <= 0 or self._torch_regroup or (seq is not None and len(set(feats)) != 1):
             return None
         if not (y.is_cuda and y.dtype == torch.int64 and y.is_contiguous() and all(x.is_cuda and x.dtype == torch.float32 for x in xs)
                 and (seq is None or (seq.is_cuda and seq.dtype == torch.int64 and seq.is_contiguous()))):

@@ -692,7 +692,7 @@ class MultiModN(nn.Module):
         return eng, total
 
     def _train_steps_per_sample(self, train_loader, optimizer):
-        """The batch loop in per-sample mode.  With device-resident batches the regrouping of batch t+1 (three launches
+        """The batch loop in per-sample mode.  With device-resident batches the regrouping of batch t+1 (four launches
         that depend on the data alone) runs on a side stream while step t runs on the main one: k_fb8 fills every CU's
         LDS with one workgroup but only a quarter of its wave slots, the regrouping kernels use no LDS to speak of.
         Two persistent buffer sets take the regrouped batches in turn; events order the two streams."""

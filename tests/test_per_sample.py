@@ -49,7 +49,7 @@ def run_step(model, xs, y, seq, torch_regroup=False):
     model.per_sample = True
     data = [torch.from_numpy(x) for x in xs]
     eng = model._get_engine(len(y))
-    eng._torch_regroup = torch_regroup      # regrouping by torch ops instead of mmn_regroup's three kernels
+    eng._torch_regroup = torch_regroup      # regrouping by torch ops instead of mmn_regroup's kernels
     eng.epoch_reset()
     _, keep = model._run_step_per_sample(eng, data, torch.from_numpy(y), None if seq is None else torch.from_numpy(seq))
     eng.assign_grads(None)
@@ -84,10 +84,11 @@ def test_per_sample_step_matches_oracle(B, E, permute):
 
 @pytest.mark.gpu
 def test_hip_regrouping_equals_torch_regrouping():
-    """mmn_regroup (k_ps_code / k_ps_layout / k_ps_gather) and the torch-op regrouping build the same
-    layout: bit-identical statistics and gradients."""
+    """mmn_regroup (k_ps_code / k_ps_hist / k_ps_layout / k_ps_gather: one workgroup per 1,024 rows) and the torch-op
+    regrouping build the same layout: bit-identical statistics and gradients - also where a batch is not a whole number of
+    1,024-row blocks, and beyond the 16,384 rows the one-workgroup layout of round 2 stopped at."""
     mm.hip.load()
-    for B, E, perm in ((333, 4, True), (64, 3, False), (4096, 4, True)):
+    for B, E, perm in ((333, 4, True), (64, 3, False), (4096, 4, True), (1025, 4, True), (5000, 3, True), (20000, 4, True)):
         spec, xs, y, seq = c5_like(B, E=E, seed=7 + B)
         if not perm:
             seq = None

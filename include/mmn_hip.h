@@ -302,7 +302,7 @@ int mmn_train_step_ex(mmn_plan* p, const mmn_batch* b, float err_penalty, float 
 /* Per-sample mode helper: regroup the rows of an ordinary batch, ON THE DEVICE, into the tile layout
  * mmn_batch.tile_rows / tile_seq describe (four launches, deterministic: no atomics).
  *   in  : x[k] = data slot k [batch x F] (NaN anywhere in a row = that sample's modality is missing),
- *         y, batch = number of samples (any: one workgroup per 1,024 rows), batch_global; sequence fields are ignored
+ *         y, batch = number of samples (any: one workgroup per 512 rows), batch_global; sequence fields are ignored
  *   seq : device int64 [batch x n_encoders], sample b feeds data slot k to encoder seq[b][k]
  *         (all modalities then need the same width), or NULL: slot k feeds encoder k
  *   out : caller-allocated device buffers for rows = mmn_regroup_rows(batch, n_encoders) rows:

@@ -84,9 +84,9 @@ def test_per_sample_step_matches_oracle(B, E, permute):
 
 @pytest.mark.gpu
 def test_hip_regrouping_equals_torch_regrouping():
-    """mmn_regroup (k_ps_code / k_ps_hist / k_ps_layout / k_ps_gather: one workgroup per 1,024 rows) and the torch-op
+    """mmn_regroup (k_ps_code / k_ps_hist / k_ps_layout / k_ps_gather: one workgroup per 512 rows) and the torch-op
     regrouping build the same layout: bit-identical statistics and gradients - also where a batch is not a whole number of
-    1,024-row blocks, and beyond the 16,384 rows the one-workgroup layout of round 2 stopped at."""
+    512-row blocks, and beyond the 16,384 rows the one-workgroup layout of round 2 stopped at."""
     mm.hip.load()
     for B, E, perm in ((333, 4, True), (64, 3, False), (4096, 4, True), (1025, 4, True), (5000, 3, True), (20000, 4, True)):
         spec, xs, y, seq = c5_like(B, E=E, seed=7 + B)

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MMN_VERSION 106            /* 0.1.6: mmn_dp_rescale (uneven data-parallel shards);
+#define MMN_VERSION 107            /* 0.1.7: mmn_eval_step_ex (test(): outputs and row flag of a step collected by the call); 0.1.6: mmn_dp_rescale (uneven data-parallel shards);
                                       0.1.5: mmn_step_opts.next_drop_* (the next step's dropout multipliers in this step's last launch), mmn_dropout_adopt;
                                       0.1.4: mmn_train_step_ex (pre-scan of the next batch, flag sets in the stats block), mmn_pack_invalidate;
                                       0.1.3: + mmn_draw_dropout; 0.1.2: MIMIC_MLPEncoder / MLPDecoder (mmn_encoder.kind, mmn_decoder.hidden, mmn_batch.drop_mask) */
@@ -321,6 +321,12 @@ int mmn_regroup_ex(mmn_plan* p, const mmn_batch* in, const int64_t* seq, mmn_bat
  * (+ accumulate).  Leaves the state rows and the decoder outputs of every grid row in the workspace
  * (mmn_debug_buffer kinds 0 and 1). */
 int mmn_eval_step(mmn_plan* p, const mmn_batch* b, int accumulate_epoch, void* stream);
+/* mmn_eval_step plus what the reference's test() keeps of the step (multimodn.py:354-357,410-419): the decoders'
+ * outputs on grid row `row` (the state after encoder row - 1; [batch x 2D] floats, decoder d at columns 2d, 2d + 1) are
+ * copied to out_dst and "that row exists in this step" (0 / 1) to *flag_dst (may be NULL) - device pointers, e.g. the
+ * step's slice of an epoch-sized buffer: no host synchronisation, one call per step. */
+int mmn_eval_step_ex(mmn_plan* p, const mmn_batch* b, int accumulate_epoch, int row, float* out_dst, int32_t* flag_dst,
+                     void* stream);
 
 /* optimizer.step() (multimodn.py:204) for torch.optim.Adam as the reference pipelines build it
  * (titanic_mlp_pipeline.py:74), over FLAT buffers: one launch (k_adam) for the whole model.

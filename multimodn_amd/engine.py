@@ -669,6 +669,15 @@ class HipChainEngine:
             where[src_of[pos]] = pos
         return where, tile_seq.to(torch.int64)[where // 16]
 
+    def eval_step_collect(self, b: hip.Batch, row: int, out_dst: torch.Tensor, flag_dst: Optional[torch.Tensor],
+                          accumulate: bool = True) -> None:
+        """eval_step plus, in the same call, the decoders' outputs on grid row `row` -> out_dst ([batch, 2D] float32,
+        contiguous) and "the row exists" -> flag_dst (int32 scalar view or None): what test() keeps of a step, without a
+        torch copy per kept thing (include/mmn_hip.h mmn_eval_step_ex)."""
+        hip.check(self.lib.mmn_eval_step_ex(self._plan, C.byref(b), 1 if accumulate else 0, int(row), out_dst.data_ptr(),
+                                            None if flag_dst is None else flag_dst.data_ptr(), self._stream()),
+                  "mmn_eval_step_ex")
+
     def eval_step(self, b: hip.Batch, accumulate: bool = False) -> None:
         hip.check(self.lib.mmn_eval_step(self._plan, C.byref(b), 1 if accumulate else 0, self._stream()), "mmn_eval_step")
 

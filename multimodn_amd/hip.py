@@ -17,7 +17,7 @@ MAX_LAYERS = 8
 MAX_DIM = 128
 ADAM_MAX_SEG = 512
 ERR_UNSUPPORTED = -2
-VERSION = 106
+VERSION = 107
 MAX_DEC_HIDDEN = 3
 ENC_MLP, ENC_MIMIC = 0, 1
 
@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "mmn_chain_bwd", "mmn_chain_fwd_bwd", "mmn_wgrad", "mmn_reduce", "mmn_epoch_accumulate", "mmn_train_step",
     "mmn_eval_step", "mmn_adam_blocks", "mmn_adam_step", "mmn_adam_step_accumulate", "mmn_train_step_adam", "mmn_reduce_adam", "mmn_regroup_rows", "mmn_regroup", "mmn_epoch_reset", "mmn_epoch_read", "mmn_debug_buffer",
     "mmn_dropout_floats", "mmn_draw_dropout", "mmn_dropout_reset", "mmn_dropout_adopt",
-    "mmn_nan_flags_set", "mmn_pack_invalidate", "mmn_pack_refresh", "mmn_train_step_ex", "mmn_epoch_write", "mmn_adam_fusable", "mmn_regroup_ex", "mmn_dp_rescale",
+    "mmn_nan_flags_set", "mmn_pack_invalidate", "mmn_pack_refresh", "mmn_train_step_ex", "mmn_epoch_write", "mmn_adam_fusable", "mmn_regroup_ex", "mmn_dp_rescale", "mmn_eval_step_ex",
 )
 
 
@@ -155,6 +155,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_wgrad.argtypes = [vp, C.POINTER(Batch), vp]
     lib.mmn_reduce.restype = i32
     lib.mmn_reduce.argtypes = [vp, C.POINTER(Batch), vp]
+    lib.mmn_eval_step_ex.restype = i32
+    lib.mmn_eval_step_ex.argtypes = [vp, C.POINTER(Batch), i32, i32, vp, vp, vp]
     lib.mmn_dp_rescale.restype = i32
     lib.mmn_dp_rescale.argtypes = [vp, vp, C.c_int64, i32, vp]
     lib.mmn_epoch_accumulate.restype = i32

@@ -165,3 +165,38 @@ def test_hip_eval_device_nan_policy_and_large_predict(monkeypatch):
     marg = []
     O.predict({n: np.asarray(v, np.float64) for n, v in params.items()}, spec, xs, dtype=np.float64, margins=marg)
     assert_predictions_match(pred, ref, marg[0], "predict() on 3000 rows")     # equal, except where the float64 outputs tie
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c2_split", "nan_skip", "seq_perm", "mimic_drop"])
+def test_hip_test_collecting_loop_equals_general_loop(name):
+    """test() over batches that already live on the device takes its one-call-per-step loop (MultiModN._test_steps_collected,
+    mmn_eval_step_ex: the step's last-row outputs and its "row exists" flag are collected by the library call); the result -
+    History arrays and every value of the per-decoder report - equals the general loop's bit for bit, also with a last
+    batch that is smaller than the others and when the same loader is evaluated again (reused batch structs)."""
+    mm.hip.load()
+    g = Golden(name)
+    loader = []
+    for b in g.batches():
+        if len(b) > 2:
+            pytest.skip("explicit sequences go through the general loop")
+        loader.append(([torch.from_numpy(x).cuda() for x in b[0]], torch.from_numpy(b[1]).cuda()))
+    xs, y = loader[-1]
+    loader.append(([x[:max(1, x.shape[0] // 2)].contiguous() for x in xs], y[:max(1, y.shape[0] // 2)].contiguous()))
+    out = []
+    for fast in (True, False):
+        model = trained_model(g, "cuda")
+        model.nan_policy = "device"
+        model.collect_in_step = fast
+        hist = mm.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
+        res = [model.test(loader, torch.nn.CrossEntropyLoss(), hist, tag="test") for _ in range(2)]
+        assert ("_eval_bufs" in model._engine.__dict__) == fast          # the collecting loop really ran (or did not)
+        out.append((hist, res))
+    (h1, r1), (h0, r0) = out
+    for k in ("loss", "accuracy", "sensitivity", "specificity", "balanced_accuracy"):
+        for a, b in zip(getattr(h1, k)["test"], getattr(h0, k)["test"]):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), k
+    for ra, rb in zip(r1, r0):
+        for da, db in zip(ra, rb):
+            for va, vb in zip(da, db):
+                assert np.array_equal(np.asarray(va), np.asarray(vb))

@@ -166,7 +166,7 @@ typedef struct mmn_batch {
      * cat([x, state]) before the first Linear of encoder e, forward and backward.  NULL = no dropout
      * for that encoder this step (eval mode, p = 0, or an MLPEncoder).  The caller provides them: from its own generator,
      * or with mmn_draw_dropout below (what multimodn_amd does; tests hand in the reference's recorded draws). */
-    const float* drop_mask[MMN_MAX_ENCODERS];
+    const float* drop_mask[MMN_MAX_ENCODERS];    /* 16-byte aligned (the backward kernel fetches them as float4s; MMN_ERR_ARG otherwise) */
 } mmn_batch;
 
 /* Per-step statistics block, fp32, written by mmn_reduce (local sums, ready for an all-reduce)

@@ -11,7 +11,7 @@ epoch.  There is no torch-op fallback for that body: without the HIP library or 
 from __future__ import annotations
 
 import random
-from typing import Callable, Iterable, List, Optional, Sequence, Tuple, Union
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
@@ -48,43 +48,46 @@ class _HostStager:
 
     def __init__(self, device: torch.device, depth: int = 3):
         self.device, self.depth = device, depth
-        self.slots: List[Optional[Tuple[Tensor, Tensor, torch.cuda.Event]]] = [None] * depth
+        self.slots: List[Optional[tuple]] = [None] * depth
         self.turn = 0
 
     def stage(self, data: Sequence[Tensor], y: Tensor) -> Tuple[List[Tensor], Tensor]:
-        shapes = [tuple(t.shape) for t in data]
-        n_f = sum(int(np.prod(sh)) for sh in shapes)
-        n_y = int(y.numel())
-        nbytes = 4 * n_f + 8 * n_y + 64
+        # (the views into a slot's pinned and device buffers are made once per batch shape: at the reference pipelines' 16-row
+        #  batches the shape arithmetic and the fourteen views of a batch cost more host time than its copies)
+        sig = (tuple(tuple(t.shape) for t in data), tuple(y.shape))
         i = self.turn
         self.turn = (self.turn + 1) % self.depth
         ent = self.slots[i]
         if ent is not None:
             ent[2].synchronize()                                 # its previous copy has left the buffer
-        if ent is None or ent[0].numel() < nbytes:
-            pinned = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-            dev = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            ent = (pinned, dev, torch.cuda.Event())
+        if ent is None or ent[3] != sig:
+            sizes = [int(t.numel()) for t in data]
+            n_f, n_y = sum(sizes), int(y.numel())
+            off_y = (4 * n_f + 15) // 16 * 16
+            used = off_y + 8 * n_y
+            if ent is None or ent[0].numel() < used + 64:
+                pinned = torch.empty(used + 64, dtype=torch.uint8).pin_memory()
+                dev = torch.empty(used + 64, dtype=torch.uint8, device=self.device)
+                ev = torch.cuda.Event()
+            else:
+                pinned, dev, ev = ent[0], ent[1], ent[2]
+            pf, df = pinned[:4 * n_f].view(torch.float32), dev[:4 * n_f].view(torch.float32)
+            p_views, d_views, o = [], [], 0
+            for t, k in zip(data, sizes):
+                p_views.append(pf[o:o + k].view(t.shape))
+                d_views.append(df[o:o + k].view(t.shape))
+                o += k
+            p_y = pinned[off_y:off_y + 8 * n_y].view(torch.int64).view(y.shape)
+            d_y = dev[off_y:off_y + 8 * n_y].view(torch.int64).view(y.shape)
+            ent = (pinned, dev, ev, sig, p_views, d_views, p_y, d_y, pinned[:used], dev[:used])
             self.slots[i] = ent
-        pinned, dev, ev = ent
-        off_y = (4 * n_f + 15) // 16 * 16
-        pf, py = pinned[:4 * n_f].view(torch.float32), pinned[off_y:off_y + 8 * n_y].view(torch.int64)
-        o = 0
-        for t, sh in zip(data, shapes):
-            k = int(np.prod(sh))
-            pf[o:o + k].view(sh).copy_(t)                        # converts dtype if needed
-            o += k
-        py.view(y.shape).copy_(y)
-        used = off_y + 8 * n_y
-        dev[:used].copy_(pinned[:used], non_blocking=True)
+        _, _, ev, _, p_views, d_views, p_y, d_y, p_used, d_used = ent
+        for pv, t in zip(p_views, data):
+            pv.copy_(t)                                          # converts dtype if needed
+        p_y.copy_(y)
+        d_used.copy_(p_used, non_blocking=True)
         ev.record()
-        df, dy = dev[:4 * n_f].view(torch.float32), dev[off_y:off_y + 8 * n_y].view(torch.int64)
-        xs, o = [], 0
-        for sh in shapes:
-            k = int(np.prod(sh))
-            xs.append(df[o:o + k].view(sh))
-            o += k
-        return xs, dy.view(y.shape)
+        return list(d_views), d_y
 
 
 _BATCH_CACHE_MAX = 4096
@@ -246,7 +249,10 @@ class MultiModN(nn.Module):
             # Host tensors of this size are copied / scanned by torch's intra-op pool; on a many-core
             # host (128 threads here) that pool turns a 100 us copy into milliseconds, so the handful of
             # small host ops of one batch run with at most 8 threads.
-            n_thr = torch.get_num_threads()
+            # (torch runs tensors below its grain size - 32,768 elements - on the calling thread anyway: the reference
+            #  pipelines' 16-row batches skip the two set_num_threads calls, which cost more than their copies)
+            big = sum(int(t.numel()) for t in data) >= 32768
+            n_thr = torch.get_num_threads() if big else 0
             if n_thr > 8:
                 torch.set_num_threads(8)
             try:
@@ -267,7 +273,7 @@ class MultiModN(nn.Module):
         present: Optional[List[bool]] = None
         if mode == "host":
             on_host = all(t.device.type == "cpu" for t in data)
-            n_thr = torch.get_num_threads() if on_host else 0
+            n_thr = torch.get_num_threads() if (on_host and sum(int(t.numel()) for t in data) >= 32768) else 0
             if n_thr > 8:
                 torch.set_num_threads(8)
             try:
@@ -511,6 +517,8 @@ class MultiModN(nn.Module):
             window.append(st)
             return True
 
+        staged: Dict[int, tuple] = {}                        # device tensors of the staging ring -> their filled-in struct
+
         def materialise() -> None:
             """hip.Batch structs for everything in the window (in order: the flag sets alternate); a batch larger than
             the plan re-plans first, which invalidates the structs made so far."""
@@ -525,10 +533,21 @@ class MultiModN(nn.Module):
             for st in window:
                 if st.b is None:
                     ent = st.cached
-                    st.b, st.key, tk = eng.make_batch_keyed(st.xs, st.y, st.pairs, st.bg, st.executed is None,
-                                                            None if ent is None else ent[6])
+                    tmpl = None if ent is None else ent[6]
+                    if ent is None and st.on_host:
+                        # a staged host batch: the staging ring hands the SAME device tensors back every `depth` batches; the
+                        # struct filled for them is reused as long as sequence and global batch are the same
+                        sl = staged.get(id(st.y))
+                        if sl is not None and sl[0] is st.y and len(sl[1]) == len(st.xs) and all(a is c for a, c in zip(sl[1], st.xs)) \
+                                and sl[2] == (tuple(st.pairs), st.bg):
+                            tmpl = sl[3]
+                    st.b, st.key, tk = eng.make_batch_keyed(st.xs, st.y, st.pairs, st.bg, st.executed is None, tmpl)
                     if ent is not None:
                         ent[6] = tk
+                    elif st.on_host:
+                        if len(staged) > 16:
+                            staged.clear()
+                        staged[id(st.y)] = (st.y, list(st.xs), (tuple(st.pairs), st.bg), tk)
 
         while True:
             if not window and not pull():

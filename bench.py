@@ -484,6 +484,7 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:          # plain `python bench.py --gpus N`: be our own launcher
         raise SystemExit(spawn_ranks(args.gpus))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (dmabuf IPC only on this stack: RCCL's peer mappings need it)
     global torch
     import torch
     import multimodn_amd as mm

@@ -460,6 +460,7 @@ def main():
     ap.add_argument("--resident-batches", type=int, default=8)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying hipGraphs")
     ap.add_argument("--graph-steps", type=int, default=8, help="consecutive steps captured into one hipGraph")
+    ap.add_argument("--graph-steps-next", type=int, default=0, help="... behind the first group of a call (0: the package's default)")
     ap.add_argument("--optimizer", choices=("hip", "torch"), default="hip",
                     help="hip: multimodn_amd.optim.Adam (fused into the step's last launch); torch: torch.optim.Adam(fused, capturable)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -519,6 +520,8 @@ def main():
     model.nan_policy = "device"
     model.replay_steps = not args.no_graph
     model.REPLAY_GROUP = max(1, args.graph_steps)
+    if args.graph_steps_next:
+        model.REPLAY_GROUP_NEXT = max(1, args.graph_steps_next)
     per_sample = bool(wl.get("per_sample"))
     model.per_sample = per_sample
     if dp:

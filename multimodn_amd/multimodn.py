@@ -452,6 +452,11 @@ class MultiModN(nn.Module):
 
     #: steps captured into one hipGraph when every batch of the group already lives on the device
     REPLAY_GROUP = 8
+    #: ... and behind the first group of a call (0 = the same).  A graph-to-graph boundary costs ~8 us of idle GPU (a
+    #: boundary between two kernels of one graph ~1.2) and a long graph's launch is hidden behind the group in front of it:
+    #: 24 measured 54.1 instead of 54.7 us/step over 200-step calls, but 59.4 instead of 57.3 over 20-step calls (8 + 12
+    #: steps) - off by default
+    REPLAY_GROUP_NEXT = 0
 
     def _train_steps(self, train_loader, optimizer, log_interval=None, logger=None):
         """The batch loop of train_epoch (multimodn.py:117-212).  Batches are ingested one step ahead of their launch
@@ -564,6 +569,8 @@ class MultiModN(nn.Module):
             #  ingested, was measured: 77.6 instead of 74.9 us/step over 20 steps - the group's replay then starts late)
             if can_replay and resident:
                 group = max(1, int(getattr(self, "REPLAY_GROUP", 8)))
+                if state["steps"] > 0 and int(getattr(self, "REPLAY_GROUP_NEXT", 0)) > 0:
+                    group = max(1, int(self.REPLAY_GROUP_NEXT))
             # (stop at the first batch that arrives the other way - host-staged behind device-resident or vice versa: the
             #  staging ring is three deep, a longer window of host batches would overwrite buffers of steps not yet launched)
             while len(window) < group + 1 and pull():
@@ -640,7 +647,7 @@ class MultiModN(nn.Module):
             eng = state["eng"]
             plans[(len(seen_batches), id(seen_batches[0]), id(seen_batches[-1]))] = {
                 "batches": seen_batches, "groups": rec, "eng": eng, "plan": eng._plan.value, "opt": optimizer,
-                "group": int(getattr(self, "REPLAY_GROUP", 8)), "rows": max(int(st_[1].shape[0]) for g in rec for st_ in g[0])}
+                "group": (int(getattr(self, "REPLAY_GROUP", 8)), int(getattr(self, "REPLAY_GROUP_NEXT", 0))), "rows": max(int(st_[1].shape[0]) for g in rec for st_ in g[0])}
             # (an entry captured DURING this call was looked up before its capture: take it from the cache now)
             plans[(len(seen_batches), id(seen_batches[0]), id(seen_batches[-1]))]["groups"] = [
                 (g[0], g[1], g[2] if (g[2] is not None and g[2][1] is not None) else None) for g in rec]
@@ -661,7 +668,7 @@ class MultiModN(nn.Module):
         if not seq:
             return None
         ep = plans.get((len(seq), id(seq[0]), id(seq[-1])))
-        if ep is None or ep["opt"] is not optimizer or ep["eng"] is not self._engine or ep["group"] != int(getattr(self, "REPLAY_GROUP", 8)) \
+        if ep is None or ep["opt"] is not optimizer or ep["eng"] is not self._engine or ep["group"] != (int(getattr(self, "REPLAY_GROUP", 8)), int(getattr(self, "REPLAY_GROUP_NEXT", 0))) \
                 or len(ep["batches"]) != len(seq) or not all(map(operator.is_, seq, ep["batches"])):
             return None
         eng = self._get_engine(ep["rows"])                   # (compares every parameter's address with the plan's)

@@ -1009,7 +1009,7 @@ class MultiModN(nn.Module):
                 tmpl = ent[6]
             b, _, tmpl = eng.make_batch_keyed(list(data), target, pairs, rows[i], True, tmpl)
             if isinstance(batch, tuple) and not self.shuffle_mode:
-                if len(cache) >= _BATCH_CACHE_MAX:
+                if len(cache) >= min(_BATCH_CACHE_MAX, 2 * n + 8):   # (never more than two loaders' worth of batches kept alive)
                     cache.clear()
                 cache[id(batch)] = [batch, target, list(data), sig, pairs, rows[i], tmpl]
             eng.eval_step_collect(b, last + 1, out_buf[i], flag_buf[i:i + 1], accumulate=True)

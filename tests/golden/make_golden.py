@@ -156,6 +156,177 @@ CONFIGS = {
 }
 
 
+# ---- per-sample extension (BASELINE configs[4]): the reference defines per-sample sequences / NaN rows only at
+# batch size 1 (multimodn.py:518-523, :167-171; pipelines/titanic/titanic_missingness_pipeline.py:35 runs exactly that).
+# These runs feed the reference ONE sample per batch - its own sequence row, its own NaN rows - with an optimizer proxy that
+# snapshots the gradients and does NOT step, so that every sample sees the same weights: the per-sample values and their
+# means over the N samples are what oracle.per_sample_step and the HIP per-sample step must reproduce for the N-row batch.
+PER_SAMPLE_B1 = {
+    "per_sample_b1_mlp": dict(F=[6, 6, 6], H=(8, 8), S=16, D=2, N=32, pen=(1.0, 0.5), act="relu", p_missing=0.3),
+    "per_sample_b1_mimic": dict(F=[6, 6, 6], H=(8,), S=16, D=2, N=32, pen=(1.0, 0.5), act="relu", p_missing=0.3,
+                                enc_kinds=["mimic"] * 3, dropout=0.2, dec=[("mlp", (6,)), ("mlp", (6,))]),
+}
+
+
+class SnapshotOnlyProxy:
+    """zero_grad() is real, step() only snapshots the gradients: the weights never move."""
+
+    def __init__(self, model):
+        self.model = model
+        self.grads = []
+
+    def zero_grad(self):
+        for p in self.model.parameters():
+            p.grad = None
+
+    def step(self):
+        self.grads.append({n: (None if p.grad is None else p.grad.detach().numpy().copy())
+                           for n, p in self.model.named_parameters()})
+
+
+def build_reference_model(cfg):
+    S, D = cfg["S"], cfg["D"]
+    kinds = cfg.get("enc_kinds", ["mlp"] * len(cfg["F"]))
+    encoders = [MLPEncoder(S, f, tuple(cfg["H"]), ACTS[cfg["act"]]) if k == "mlp" else
+                MIMIC_MLPEncoder(S, f, tuple(cfg["H"]), dropout=cfg.get("dropout", 0.0), activation=ACTS[cfg["act"]])
+                for f, k in zip(cfg["F"], kinds)]
+    decoders = [LogisticDecoder(S) if k == "class" else MLPDecoder(S, tuple(h), 2)
+                for k, h in cfg.get("dec", [("class", ())] * D)]
+    return MultiModN(S, encoders, decoders, cfg["pen"][0], cfg["pen"][1], device=torch.device("cpu")), encoders
+
+
+def run_reference_b1(name, cfg, seed=0):
+    """The reference's train_epoch over N batches of ONE sample each (per-row sequence, NaN rows), weights frozen."""
+    torch.manual_seed(seed)
+    torch.set_num_threads(1)
+    E, D, N = len(cfg["F"]), cfg["D"], cfg["N"]
+    model, encoders = build_reference_model(cfg)
+    rng = np.random.default_rng(seed + 11)
+    X = [rng.standard_normal((N, f)).astype(np.float32) for f in cfg["F"]]
+    y = rng.integers(0, 2, size=(N, D)).astype(np.int64)
+    # missing not at random (SURVEY 8d, C5): a modality is missing more often when y_0 = 1; a missing modality = a NaN row
+    pm = np.where(y[:, :1] == 1, 1.5 * cfg["p_missing"], 0.5 * cfg["p_missing"])
+    miss = rng.random((N, E)) < pm
+    miss[0, :] = False                       # sample 0 has everything, sample 1 nothing at all
+    miss[1, :] = True
+    for k in range(E):
+        X[k][miss[:, k]] = np.nan
+    seq = np.stack([rng.permutation(E) for _ in range(N)]).astype(np.int64)
+    masks = {}
+    opt = SnapshotOnlyProxy(model)
+
+    def pre_hook(mod, inp):
+        mod._rng_before = torch.get_rng_state()
+
+    def make_post(e):
+        def post_hook(mod, inp, out):
+            if not mod.training or mod.p == 0:
+                return
+            after = torch.get_rng_state()
+            torch.set_rng_state(mod._rng_before)
+            mask = torch.nn.functional.dropout(torch.ones_like(inp[0]), mod.p, True)
+            assert torch.equal(torch.get_rng_state(), after)
+            assert torch.equal(out, inp[0] * mask)
+            masks[(len(opt.grads), e)] = mask.numpy().copy()
+        return post_hook
+
+    for e, enc in enumerate(encoders):
+        if isinstance(enc, MIMIC_MLPEncoder):
+            enc.layers[0].register_forward_pre_hook(pre_hook)
+            enc.layers[0].register_forward_hook(make_post(e))
+    init = {n: p.detach().numpy().copy() for n, p in model.named_parameters()}
+    loader = [([torch.from_numpy(X[k][b:b + 1]) for k in range(E)], torch.from_numpy(y[b:b + 1]),
+               torch.from_numpy(seq[b:b + 1])) for b in range(N)]
+    crit = RecordingCriterion()
+    hist = MultiModNHistory([f"t{d}" for d in range(D)])
+    losses = []
+    orig_backward = torch.Tensor.backward
+
+    def rec_backward(self, *a, **k):
+        losses.append(float(self.detach()))
+        return orig_backward(self, *a, **k)
+
+    torch.Tensor.backward = rec_backward
+    try:
+        model.train_epoch(loader, opt, crit, hist)
+    finally:
+        torch.Tensor.backward = orig_backward
+    for n, p in model.named_parameters():
+        assert np.array_equal(p.detach().numpy(), init[n]), "the weights must not move"
+    # per-sample loss cells from the criterion's call order: row 0's decoders, then every EXECUTED encoder in the sample's
+    # own order (multimodn.py:141-157,159-191); a skipped encoder leaves its row at 0
+    cells = np.zeros((N, E + 1, D))
+    executed = np.zeros((N, E), bool)
+    ci = 0
+    for b in range(N):
+        rows = [0]
+        for k, e in enumerate(seq[b]):                      # data slot k feeds encoder seq[b][k] (multimodn.py:162-163)
+            if not miss[b, k]:
+                rows.append(int(e) + 1)
+                executed[b, e] = True
+        for r in rows:
+            for d in range(D):
+                cells[b, r, d] = crit.calls[ci]
+                ci += 1
+    assert ci == len(crit.calls) and len(opt.grads) == N and len(losses) == N
+    return dict(init=init, X=X, y=y, seq=seq, miss=miss, masks=masks, cells=cells, executed=executed, losses=losses,
+                grads=opt.grads, hist=hist, model=model)
+
+
+def write_per_sample_b1(name, cfg):
+    ref = run_reference_b1(name, cfg)
+    spec = spec_of(cfg)
+    E, D, N = spec.E, spec.D, cfg["N"]
+    h = ref["hist"]
+    out = {"config_json": np.array(json.dumps(cfg)), "torch_version": np.array(torch.__version__),
+           "param_names": np.array(spec.param_names()), "y": ref["y"], "seq": ref["seq"],
+           "sample_loss": np.array(ref["losses"], np.float64), "sample_cells": ref["cells"], "executed": ref["executed"],
+           "hist/loss": np.asarray(h.loss["train"][0]), "hist/state_change": np.asarray(h.state_change_loss[0]),
+           "hist/accuracy": np.asarray(h.accuracy["train"][0]), "hist/sensitivity": np.asarray(h.sensitivity["train"][0]),
+           "hist/specificity": np.asarray(h.specificity["train"][0]),
+           "hist/balanced_accuracy": np.asarray(h.balanced_accuracy["train"][0])}
+    for n, v in ref["init"].items():
+        out[f"init/{n}"] = v
+    for k, x in enumerate(ref["X"]):
+        out[f"x{k}"] = x
+    # the batch's dropout multipliers, row b = what the reference drew for sample b (ones where the encoder did not run)
+    drop = None
+    if ref["masks"]:
+        drop = {e: np.ones((N, spec.encoders[e].n_features + spec.state_size), np.float32) for e in range(E)
+                if spec.encoders[e].kind == "mimic"}
+        for (b, e), mk in ref["masks"].items():
+            drop[e][b] = mk[0]
+        for e, m in drop.items():
+            out[f"mask{e}"] = m
+    # the mean over the samples of the reference's gradients (None = the encoder did not run for that sample = 0)
+    mean_g = {}
+    for n in spec.param_names():
+        gs = [g[n] for g in ref["grads"] if g[n] is not None]
+        mean_g[n] = (np.sum(np.stack(gs).astype(np.float64), 0) / N) if gs else None
+        if mean_g[n] is not None:
+            out[f"mean_grad/{n}"] = mean_g[n]
+    out["grad_none"] = np.array([n for n, g in mean_g.items() if g is None])
+    for b in (0, 1, 2):                                      # three samples' own gradients, for the record
+        for n, g in ref["grads"][b].items():
+            if g is not None:
+                out[f"sample{b}/grad/{n}"] = g
+    # ---- the oracle's per-sample step on the N-row batch against the reference's N batch-size-1 runs
+    r = O.per_sample_step(ref["init"], spec, ref["X"], ref["y"], ref["seq"], drop_masks=drop)
+    w = dict(cells=rel(r.err_loss, ref["cells"].sum(0) / N), hist_loss=rel(r.err_loss, out["hist/loss"]),
+             sc=rel(r.state_change, out["hist/state_change"]), loss=abs(r.loss - np.mean(ref["losses"])) / abs(np.mean(ref["losses"])),
+             grad=max(rel(r.grads[n].reshape(g.shape), g) for n, g in mean_g.items() if g is not None))
+    assert np.array_equal(r.row_counts[1:], ref["executed"].sum(0)), name
+    for n, g in mean_g.items():
+        assert (g is None) == (r.grads[n] is None), (name, n)
+    er = O.aggregate_epoch(E, D, [r], [N])                  # the N-row batch as one step = the reference's N one-sample steps
+    assert np.array_equal(er.accuracy, out["hist/accuracy"]), name
+    assert np.array_equal(er.sensitivity, out["hist/sensitivity"]) and np.array_equal(er.specificity, out["hist/specificity"]), name
+    assert np.array_equal(er.balanced_accuracy, out["hist/balanced_accuracy"]), name
+    print(f"{name:20s} samples={N} oracle.per_sample_step vs reference at batch size 1: " + " ".join(f"{k}={v:.2e}" for k, v in w.items()))
+    assert w["cells"] < 2e-6 and w["hist_loss"] < 2e-6 and w["sc"] < 2e-6 and w["loss"] < 2e-6 and w["grad"] < 1e-5, w
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+
+
 def make_data(cfg, seed):
     rng = np.random.default_rng(seed)
     D, N = cfg["D"], cfg["N"]
@@ -399,6 +570,10 @@ def main():
         print(f"{name:14s} steps={n_steps:3d} oracle-vs-reference rel err: " +
               " ".join(f"{k}={v:.2e}" for k, v in w.items()))
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    for name, cfg in PER_SAMPLE_B1.items():
+        if only and name not in only:
+            continue
+        write_per_sample_b1(name, cfg)
     bad = {n: w for n, w in worst.items() if w["loss"] > 2e-6 or w["crit"] > 2e-6 or w["eval"] > 2e-6}
     assert not bad, bad
 

@@ -61,6 +61,45 @@ class Golden:
         return f"step{s}/grad_none" in self.z.files
 
 
+PER_SAMPLE_B1_NAMES = ["per_sample_b1_mlp", "per_sample_b1_mimic"]
+
+
+class PerSampleGolden:
+    """tests/golden/per_sample_b1_*.npz: the REFERENCE run with ONE sample per batch (its own encoder order, its own NaN rows,
+    weights frozen by an optimizer proxy that does not step; tests/golden/make_golden.py::run_reference_b1).  The N samples
+    as ONE N-row batch in per-sample mode must give the means of the reference's N results."""
+
+    def __init__(self, name):
+        self.z = z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.cfg = json.loads(str(z["config_json"]))
+        self.spec = spec_from_cfg(self.cfg)
+        self.N = self.cfg["N"]
+        self.xs = [z[f"x{k}"] for k in range(self.spec.E)]
+        self.y, self.seq = z["y"], z["seq"]
+        self.masks = {e: z[f"mask{e}"] for e in range(self.spec.E) if f"mask{e}" in z.files} or None
+        self.grad_none = set(str(n) for n in z["grad_none"])
+
+    def init_params(self):
+        return {n: self.z["init/" + n].copy() for n in self.spec.param_names()}
+
+    def check(self, err_loss, state_change, loss, row_counts, grads, counters=None, tol=1e-5, tolg=2e-5):
+        """A per-sample step's results against the reference's means (loss cells / state change / loss 1e-5, executed-row
+        counts exact, gradients 2e-5 of the tensor's largest element; an encoder nobody executed has no gradient)."""
+        z = self.z
+        assert rel_err(err_loss, z["sample_cells"].sum(0) / self.N) < tol
+        assert rel_err(err_loss, z["hist/loss"]) < tol               # the reference's own epoch mean over its N one-sample steps
+        assert rel_err(state_change, z["hist/state_change"]) < tol
+        assert abs(float(loss) - z["sample_loss"].mean()) / abs(z["sample_loss"].mean()) < tol
+        assert np.array_equal(np.asarray(row_counts, np.int64)[1:], z["executed"].sum(0))
+        for n in self.spec.param_names():
+            g = grads[n]
+            if n in self.grad_none:
+                assert g is None or float(np.max(np.abs(g))) == 0.0, n
+            else:
+                want = z["mean_grad/" + n]
+                assert rel_err(np.asarray(g).reshape(want.shape), want) < tolg, (n, rel_err(np.asarray(g).reshape(want.shape), want))
+
+
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     if a.size == 0:

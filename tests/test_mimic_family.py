@@ -499,6 +499,27 @@ def test_per_sample_mode_of_the_mimic_modules(lib, family, B):
             assert float(np.max(np.abs(got - g))) <= max(2e-5 * float(np.max(np.abs(g))), 2e-6 * g_all), n
 
 
+def test_per_sample_mimic_step_matches_the_reference_run_at_batch_size_one(lib):
+    """tests/golden/per_sample_b1_mimic.npz: the reference's MIMIC_MLPEncoder + MLPDecoder model fed 32 samples one per batch
+    (own encoder order, NaN rows, its recorded dropout masks, frozen weights) against the HIP per-sample step on the 32-row batch."""
+    from helpers import PerSampleGolden
+    g = PerSampleGolden("per_sample_b1_mimic")
+    model = build_torch_model(g.spec, g.init_params(), "cuda", lib)
+    model.per_sample = True
+    model.train()
+    model.dropout_mask_provider = mask_provider(g.masks)
+    eng = model._get_engine(g.N)
+    eng.epoch_reset()
+    model._run_step_per_sample(eng, [torch.from_numpy(x) for x in g.xs], torch.from_numpy(g.y), torch.from_numpy(g.seq))
+    eng.assign_grads(None)
+    torch.cuda.synchronize()
+    stats = {k: np.array(v) for k, v in eng.step_values().items()}
+    grads = {n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
+    g.check(stats["err_loss"], stats["state_change"], stats["loss"], stats["rows"], grads)
+    n = 1.0 + stats["rows"].astype(np.float64)[:, None]
+    assert np.array_equal(stats["n_correct"] / n, g.z["hist/accuracy"])
+
+
 def test_per_sample_training_of_the_mimic_modules(lib):
     """train_epoch in per-sample mode with MIMIC modules (device-drawn dropout, fused Adam): runs, the loss falls, test()
     and predict() agree with each other on the regrouped path."""

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from helpers import GOLDEN_NAMES, MIMIC_GOLDEN_NAMES, Golden, assert_within_fp32_noise, fp64_trajectory, rel_err
+from helpers import GOLDEN_NAMES, MIMIC_GOLDEN_NAMES, PER_SAMPLE_B1_NAMES, Golden, PerSampleGolden, assert_within_fp32_noise, fp64_trajectory, rel_err
 from oracle import multimodn_oracle as O
 
 
@@ -43,6 +43,29 @@ def test_oracle_reproduces_reference_run(name):
     w64 = fp64_trajectory(g)[0]                          # 2e-5 of the reference's weights, or within fp32 noise of the fp64 replay
     for n, w in g.final_params().items():
         assert_within_fp32_noise(params[n], w, w64[n], n)
+
+
+@pytest.mark.parametrize("name", PER_SAMPLE_B1_NAMES)
+def test_per_sample_oracle_reproduces_the_reference_at_batch_size_one(name):
+    """The per-sample extension pinned to a reference run: N samples fed to the reference one per batch (multimodn.py:167-171,
+    509-531 at batch size 1, as pipelines/titanic/titanic_missingness_pipeline.py:35 runs it) against oracle.per_sample_step
+    on the N-row batch - loss cells, state change, loss, executed rows, mean gradients, and the epoch's History ratios."""
+    g = PerSampleGolden(name)
+    r = O.per_sample_step(g.init_params(), g.spec, g.xs, g.y, g.seq, drop_masks=g.masks)
+    g.check(r.err_loss, r.state_change, r.loss, r.row_counts, r.grads, tol=2e-6, tolg=1e-5)
+    er = O.aggregate_epoch(g.spec.E, g.spec.D, [r], [g.N])
+    for k in ("accuracy", "sensitivity", "specificity", "balanced_accuracy"):
+        assert np.array_equal(getattr(er, k), g.z["hist/" + k]), k
+    # three samples' own gradients: the oracle at batch size 1 IS the reference's step
+    for b in (0, 1, 2):
+        rb = O.forward_backward(g.init_params(), g.spec, [x[b:b + 1] for x in g.xs], g.y[b:b + 1], g.seq[b:b + 1],
+                                drop_masks=None if g.masks is None else {e: m[b:b + 1] for e, m in g.masks.items()})
+        assert abs(rb.loss - g.z["sample_loss"][b]) / g.z["sample_loss"][b] < 2e-6
+        for n, gr in rb.grads.items():
+            key = f"sample{b}/grad/{n}"
+            assert (gr is None) == (key not in g.z.files), (b, n)
+            if gr is not None:
+                assert rel_err(gr.reshape(g.z[key].shape), g.z[key]) < 1e-5, (b, n)
 
 
 def test_fp64_oracle_agrees_with_fp32():

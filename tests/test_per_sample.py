@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import multimodn_amd as mm
-from helpers import (TIE_MARGIN, adam_well_conditioned, assert_predictions_match, assert_within_fp32_noise, auc_slack, build_torch_model,
+from helpers import (PerSampleGolden, TIE_MARGIN, adam_well_conditioned, assert_predictions_match, assert_within_fp32_noise, auc_slack, build_torch_model,
                      rel_err)
 from oracle import multimodn_oracle as O
 from oracle_engine import OracleEngine
@@ -80,6 +80,19 @@ def test_per_sample_step_matches_oracle(B, E, permute):
     model = build_torch_model(spec, params, "cuda", mm)
     stats, grads = run_step(model, xs, y, seq)
     check(stats, grads, O.per_sample_step(params, spec, xs, y, seq))
+
+
+@pytest.mark.gpu
+def test_per_sample_step_matches_the_reference_run_at_batch_size_one():
+    """tests/golden/per_sample_b1_mlp.npz: the reference fed 32 samples one per batch (own encoder order, NaN rows, frozen
+    weights); the HIP per-sample step over the same 32 rows as ONE batch must give the means of the reference's results."""
+    mm.hip.load()
+    g = PerSampleGolden("per_sample_b1_mlp")
+    model = build_torch_model(g.spec, g.init_params(), "cuda", mm)
+    stats, grads = run_step(model, g.xs, g.y, g.seq)
+    g.check(stats["err_loss"], stats["state_change"], stats["loss"], stats["rows"], grads)
+    n = 1.0 + stats["rows"].astype(np.float64)[:, None]
+    assert np.array_equal(stats["n_correct"] / n, g.z["hist/accuracy"])          # the reference's epoch accuracy, exactly
 
 
 @pytest.mark.gpu

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MMN_VERSION 107            /* 0.1.7: mmn_eval_step_ex (test(): outputs and row flag of a step collected by the call); 0.1.6: mmn_dp_rescale (uneven data-parallel shards);
+#define MMN_VERSION 108            /* 0.1.8: mmn_source_hash (a library that was not built from the sources next to it does not load); 0.1.7: mmn_eval_step_ex (test(): outputs and row flag of a step collected by the call); 0.1.6: mmn_dp_rescale (uneven data-parallel shards);
                                       0.1.5: mmn_step_opts.next_drop_* (the next step's dropout multipliers in this step's last launch), mmn_dropout_adopt;
                                       0.1.4: mmn_train_step_ex (pre-scan of the next batch, flag sets in the stats block), mmn_pack_invalidate;
                                       0.1.3: + mmn_draw_dropout; 0.1.2: MIMIC_MLPEncoder / MLPDecoder (mmn_encoder.kind, mmn_decoder.hidden, mmn_batch.drop_mask) */
@@ -187,6 +187,10 @@ size_t mmn_stats_floats(const mmn_model* m);
 typedef struct mmn_plan mmn_plan;   /* opaque host handle */
 
 int mmn_version(void);
+/* First 16 hex digits of the sha256 over the sources this library was built from (multimodn_amd/build.py::source_hash;
+ * "unknown" for a build without -DMMN_SOURCE_HASH).  The Python binding refuses a library whose hash is not that of the
+ * sources next to it: a stale build must not ship silently. */
+const char* mmn_source_hash(void);
 const char* mmn_error_string(int code);
 int mmn_last_hip_error(void);
 

@@ -17,13 +17,39 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (need ROCm)")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(OUT):
-        return True
+def source_files():
     csrc = os.path.dirname(SRC)                           # mmn_kernels.hip includes the *.inc files next to it
-    sources = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc"))]
-    newest = max(os.path.getmtime(p) for p in sources + [os.path.join(INC, "mmn_hip.h")])
-    return os.path.getmtime(OUT) < newest
+    return sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc"))) + [os.path.join(INC, "mmn_hip.h")]
+
+
+def source_hash() -> str:
+    """sha256 over the library's sources (names and contents, fixed order), first 16 hex digits: baked into the library at
+    build time (`mmn_source_hash()`), compared by `needs_build()` and by `hip.load()` - a library that was not built from
+    the sources next to it does not load (modification times say nothing on a box that received the tree by copy)."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in source_files():
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
+def built_hash(path: str = OUT):
+    """What `mmn_source_hash()` of an existing library says (None: no such library / symbol)."""
+    import ctypes
+    try:
+        lib = ctypes.CDLL(path)
+        fn = lib.mmn_source_hash
+    except (OSError, AttributeError):
+        return None
+    fn.restype = ctypes.c_char_p
+    return fn().decode()
+
+
+def needs_build() -> bool:
+    return not os.path.exists(OUT) or built_hash() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -33,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # hipcc rotated k_wgrad's sixteen accumulator tiles through v_accvgpr_read / _write pairs in every unrolled loop
     # body (reads that wait for the MFMA that produced the tile): k_wgrad 18.1 -> 17.5 us, the step -1.4 us.
     cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form",
-           f"-I{INC}", SRC, "-o", OUT]
+           f'-DMMN_SOURCE_HASH="{source_hash()}"', f"-I{INC}", SRC, "-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

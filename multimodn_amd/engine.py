@@ -353,15 +353,18 @@ class HipChainEngine:
     def begin_sequence(self, sig_checked: bool = False) -> None:
         """Start of an epoch / an entry point: the flag sets are handed out from set 0 again (so that a replayed group of
         steps meets the sets it was captured with), no pre-scan is carried over.  The chain kernels' copies of the weights
-        are rebuilt by the first step UNLESS nothing has written the parameters since this engine last left them current
-        (note_parameters_current): the version counters say so, and the storage has not moved.  (Writes that bypass the
-        counters - `p.data.add_(...)`, raw pointers - need `invalidate_weights()`; round 2 repacked at every call: one
-        launch and its boundary in front of every epoch.)"""
+        are REBUILT by the first step (one small launch per call): the reference re-reads its parameters on every call
+        (multimodn.py:139-191 run the modules themselves), so anything may have written them in between - also writers
+        torch's version counters never see (`p.data.mul_(...)`, `p.data.copy_(ema)`, raw pointers).
+        `model.trust_param_versions = True` (opt-in) skips the rebuild while nothing has written the parameters since this
+        engine last left the copies current, as far as torch's per-parameter `_version` counters, the library's own write
+        counter and the storage addresses can tell; writes that bypass those then need `invalidate_weights()`."""
         self._flag_turn = 0
         self._prescanned = None
         self._predrawn = None
         seen = getattr(self, "_versions_seen", None)
-        if seen is None or seen != self._param_versions() or \
+        trust = bool(getattr(self.model, "trust_param_versions", False))
+        if not trust or seen is None or seen != self._param_versions() or \
                 (not sig_checked and tuple(p.data_ptr() for p in self.params) != self._sig):   # (ensure() has just compared them)
             self.lib.mmn_pack_invalidate(self._plan)
         self._versions_seen = None                          # whoever runs steps next says when the copies are current again

@@ -17,7 +17,7 @@ MAX_LAYERS = 8
 MAX_DIM = 128
 ADAM_MAX_SEG = 512
 ERR_UNSUPPORTED = -2
-VERSION = 107
+VERSION = 108
 MAX_DEC_HIDDEN = 3
 ENC_MLP, ENC_MIMIC = 0, 1
 
@@ -28,7 +28,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 #: every symbol include/mmn_hip.h declares
 ABI_SYMBOLS = (
-    "mmn_version", "mmn_error_string", "mmn_last_hip_error", "mmn_stats_floats", "mmn_epoch_doubles",
+    "mmn_version", "mmn_source_hash", "mmn_error_string", "mmn_last_hip_error", "mmn_stats_floats", "mmn_epoch_doubles",
     "mmn_workspace_bytes", "mmn_plan_create", "mmn_plan_destroy", "mmn_nan_flags", "mmn_prepare",
     "mmn_nan_scan", "mmn_chain_kernel_name", "mmn_chain_fwd",
     "mmn_chain_bwd", "mmn_chain_fwd_bwd", "mmn_wgrad", "mmn_reduce", "mmn_epoch_accumulate", "mmn_train_step",
@@ -197,6 +197,13 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_dropout_reset.argtypes = [vp, vp]
     if lib.mmn_version() != VERSION:
         raise MmnError(f"{p}: ABI version {lib.mmn_version()} != expected {VERSION}; rebuild")
+    lib.mmn_source_hash.restype = C.c_char_p
+    if path is None and not os.environ.get("MMN_LIB_PATH"):    # (A/B builds of kernel variants are somebody's deliberate choice)
+        from . import build as _build
+        want, have = _build.source_hash(), lib.mmn_source_hash().decode()
+        if have != want:
+            raise MmnError(f"{p} was built from other sources (library {have}, tree {want}): run "
+                           f"`python -m multimodn_amd.build` - a stale library must not run silently")
     if path is None:
         _lib = lib
     return lib

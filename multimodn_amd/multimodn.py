@@ -147,6 +147,12 @@ class MultiModN(nn.Module):
         #: staged from the host (the reference pipelines train with 16-32 rows: host-bound otherwise)
         self.replay_steps = True
         self.REPLAY_MAX_ROWS = 256
+        #: False (default): every train_epoch / test / predict / get_states call rebuilds the kernels' fragment-order copies
+        #: of the weights from the parameters, as the reference re-reads its parameters on every call - one small launch per
+        #: call.  True: skip that while torch's `_version` counters, the library's write counter and the storage addresses
+        #: say nobody wrote the parameters since the last call; writers those cannot see (`p.data.mul_(..)`, raw pointers)
+        #: must then call `model._engine.invalidate_weights()` themselves.
+        self.trust_param_versions = False
 
     # nn.Module pickling: the engine holds raw device handles and is rebuilt on demand
     def __getstate__(self):

@@ -147,6 +147,57 @@ def test_replay_survives_optimizer_load_state_dict():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("family", ["classic", "mimic_p0"])
+def test_writes_through_data_between_calls_are_seen(family):
+    """Writers torch's version counters never see (`p.data.mul_()`, `p.data.copy_(ema)`) between two train_epoch calls: the
+    reference re-reads its parameters on every call, so the next call must train on the written values - also when the
+    call is a whole-call replay of captured groups.  The same writes applied through the counted path (`with no_grad():
+    p.mul_()`) give the run to compare with, bit for bit."""
+    import multimodn_amd as lib
+    spec = _specs()[family]
+    loader = _device_loader(spec, 8, 48, seed=9)
+
+    def through_data(ep, model, opt):
+        if ep in (3, 5):                                   # (epochs 2.. are whole-call replays)
+            for p_ in model.parameters():
+                p_.data.mul_(0.5)
+
+    def counted(ep, model, opt):
+        if ep in (3, 5):
+            with torch.no_grad():
+                for p_ in model.parameters():
+                    p_.mul_(0.5)
+    a = _train(lib, spec, loader, 7, mid=through_data)
+    b = _train(lib, spec, loader, 7, mid=counted)
+    _same(a, b)
+    plain = _train(lib, spec, loader, 7)
+    assert not np.array_equal(a[0], plain[0])              # (the writes did change the training)
+
+
+@pytest.mark.gpu
+def test_trusting_the_version_counters_is_opt_in_and_bitwise_the_same_training():
+    """model.trust_param_versions = True skips the per-call rebuild of the kernels' weight copies while nobody wrote the
+    parameters: bitwise the same training as the default, and counted writes are still seen."""
+    import multimodn_amd as lib
+    spec = _specs()["classic"]
+    loader = _device_loader(spec, 8, 48, seed=9)
+
+    def trust(ep, model, opt):
+        model.trust_param_versions = True
+        if ep == 4:
+            with torch.no_grad():
+                for p_ in model.parameters():
+                    p_.mul_(0.5)
+
+    def plain(ep, model, opt):
+        if ep == 4:
+            with torch.no_grad():
+                for p_ in model.parameters():
+                    p_.mul_(0.5)
+    _same(_train(lib, spec, loader, 7, mid=trust), _train(lib, spec, loader, 7, mid=plain))
+
+
+@pytest.mark.gpu
 def test_two_parameter_groups_keep_the_reference_grad_none_semantics():
     """multimodn_amd.optim.Adam with TWO parameter groups cannot be fused with the engine.  nan_policy "auto" must then
     decide the NaN skips like the reference (grad None for the skipped encoder: moments, step count and weights

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MMN_VERSION 108            /* 0.1.8: mmn_source_hash (a library that was not built from the sources next to it does not load); 0.1.7: mmn_eval_step_ex (test(): outputs and row flag of a step collected by the call); 0.1.6: mmn_dp_rescale (uneven data-parallel shards);
+#define MMN_VERSION 109            /* 0.1.9: one-shot data-parallel exchange (mmn_dp_xbuf_*, mmn_dp_oneshot_*, mmn_adam_step_accumulate_oneshot, MMN_ERR_PEER); 0.1.8: mmn_source_hash (a library that was not built from the sources next to it does not load); 0.1.7: mmn_eval_step_ex (test(): outputs and row flag of a step collected by the call); 0.1.6: mmn_dp_rescale (uneven data-parallel shards);
                                       0.1.5: mmn_step_opts.next_drop_* (the next step's dropout multipliers in this step's last launch), mmn_dropout_adopt;
                                       0.1.4: mmn_train_step_ex (pre-scan of the next batch, flag sets in the stats block), mmn_pack_invalidate;
                                       0.1.3: + mmn_draw_dropout; 0.1.2: MIMIC_MLPEncoder / MLPDecoder (mmn_encoder.kind, mmn_decoder.hidden, mmn_batch.drop_mask) */
@@ -65,7 +65,8 @@ enum {
     MMN_ERR_UNSUPPORTED = -2,  /* dims beyond MMN_MAX_* or LDS budget */
     MMN_ERR_WORKSPACE = -3,    /* workspace too small / misaligned */
     MMN_ERR_HIP = -4,          /* a HIP runtime call failed (see mmn_last_hip_error) */
-    MMN_ERR_SEQUENCE = -5      /* encoder sequence invalid (repeat / out of range) */
+    MMN_ERR_SEQUENCE = -5,     /* encoder sequence invalid (repeat / out of range) */
+    MMN_ERR_PEER = -6          /* one-shot data-parallel exchange: a peer's data did not arrive within the wait's bound */
 };
 
 /* One nn.Linear: weight [out_dim, in_dim] row-major, bias [out_dim]; gw/gb receive the grads.
@@ -363,6 +364,28 @@ int mmn_adam_step(const mmn_adam* d, void* stream);
  * mmn_epoch_accumulate. */
 int mmn_adam_step_accumulate(mmn_plan* p, const mmn_adam* d, float err_penalty, float state_change_penalty_x001,
                              void* stream);
+
+/* One-shot data-parallel exchange fused with that tail (opt-in; the default data-parallel step is ONE RCCL all-reduce of
+ * [grads | stats] followed by mmn_adam_step_accumulate).  Every rank owns an exchange buffer that all peer PROCESSES map
+ * (hipIpc; peer access over xGMI): mmn_dp_xbuf_bytes(plan) bytes from mmn_dp_xbuf_alloc, whose 64-byte handle the caller
+ * hands to the peers (any transport: torch.distributed's object collectives), who map it with mmn_dp_xbuf_open.
+ * mmn_dp_oneshot_attach(plan, world, rank, xbufs, spin_ms): xbufs[r] = rank r's buffer as THIS process sees it (its own
+ * allocation at xbufs[rank]); world <= 8 (one node).  mmn_adam_step_accumulate_oneshot then replaces the all-reduce AND
+ * mmn_adam_step_accumulate: one launch that publishes this rank's [grads | stats] chunk by chunk, waits for the same
+ * chunks of the peers (bounded: spin_ms per chunk), adds all ranks' chunks in rank order - bitwise the same sums on every
+ * rank -, leaves them in [grads | stats] and applies Adam + the epoch accumulation.  Requires the fusable Adam layout
+ * (mmn_adam_fusable) and the same number of such calls on every rank (the step number is a device-side counter: the
+ * call may sit in a captured graph).  When a wait runs out, the workgroup leaves its parameters untouched and raises the
+ * error word: mmn_dp_oneshot_error (no synchronisation: a host-mapped word) and every later call return MMN_ERR_PEER.
+ * Reference: none - the reference is single-device (multimodn/multimodn.py:79-80). */
+size_t mmn_dp_xbuf_bytes(const mmn_plan* p);
+int mmn_dp_xbuf_alloc(size_t bytes, void** dev_ptr, void* handle64);
+int mmn_dp_xbuf_open(const void* handle64, void** dev_ptr);
+int mmn_dp_xbuf_close(void* dev_ptr, int own);
+int mmn_dp_oneshot_attach(mmn_plan* p, int world, int rank, void* const* xbufs, int spin_ms);
+int mmn_dp_oneshot_error(mmn_plan* p);
+int mmn_adam_step_accumulate_oneshot(mmn_plan* p, const mmn_adam* d, float err_penalty, float state_change_penalty_x001,
+                                     void* stream);
 
 /* mmn_train_step with optimizer.step() fused behind the gradient sum (single GPU: no all-reduce in
  * between): the last launch forms each gradient element and immediately applies Adam to that

@@ -74,6 +74,7 @@ namespace {
 #include "mmn_prepare.inc"
 #include "mmn_chain_seq.inc"
 #include "mmn_generic.inc"
+#include "mmn_chain_mimic.inc"
 #include "mmn_chain_par.inc"
 #include "mmn_chain_8w.inc"
 #include "mmn_chain_fb9.inc"

@@ -436,7 +436,7 @@ class HipChainEngine:
     MAX_STEP_GRAPHS = 64
 
     def run_group(self, steps, nxt, err_penalty: float, sc_penalty_x001: float, optimizer, draw_dropout: bool,
-                  desc=None, reset_first: bool = False) -> bool:
+                  desc=None, reset_first: bool = False, dp_tail=None) -> bool:
         """`steps`: consecutive training steps (device NaN policy, Adam fused) as (xs, y, pairs, batch_global, hip.Batch,
         key) tuples (make_batch_keyed) whose device buffers this engine may have seen before; `nxt`: the step after them (or None) - the last
         step of the group pre-scans its batch.  The group - per step k_dropout, [k_prepare scan], chain, k_wgrad,
@@ -449,7 +449,10 @@ class HipChainEngine:
         whether the first batch arrives pre-scanned.  `reset_first`: the group is the first of an epoch and its graph
         starts with the reset of the epoch accumulators (a memset node: epoch_reset() as a call of its own costs ~10 us of
         host time in front of the call's first launch).  Returns False when the group cannot be replayed - nothing has
-        been launched, not even the reset: the caller runs it eagerly (which is also the warm-up before the capture)."""
+        been launched, not even the reset: the caller runs it eagerly (which is also the warm-up before the capture).
+        `dp_tail` (data parallel): a callable (key, fn); every step is then [local sums: chain, k_wgrad, k_reduce without
+        Adam] + fn(desc) - the exchange with the other ranks and the Adam / accumulation launch behind it (the one-shot
+        exchange kernel, or an all-reduce torch's RCCL binding captures) - and `key` joins the graph key."""
         d = desc if desc is not None else (optimizer.fused_descriptor(self) if hasattr(optimizer, "fused_descriptor") else None)
         if d is None or torch.cuda.is_current_stream_capturing() or self._step_graphs is None:
             return False
@@ -461,7 +464,8 @@ class HipChainEngine:
         entry_ready = bool(first.nan_flags and self._prescanned is first)
         entry_drawn = bool(draw_dropout and self._predrawn is first)
         hp = self.group_hp_key(err_penalty, sc_penalty_x001, optimizer, d, seed)
-        key = (tuple(st[5] for st in steps), None if nxt is None else nxt[5], entry_ready, entry_drawn, bool(reset_first)) + hp
+        key = (tuple(st[5] for st in steps), None if nxt is None else nxt[5], entry_ready, entry_drawn, bool(reset_first),
+               None if dp_tail is None else dp_tail[0]) + hp
         ent = self._step_graphs.get(key)
         if ent is None:
             if len(self._step_graphs) >= self.MAX_STEP_GRAPHS:
@@ -490,8 +494,13 @@ class HipChainEngine:
                             nb = steps[i + 1][4] if i + 1 < len(steps) else (None if nxt is None else nxt[4])
                             if draw_dropout:
                                 keep.append(self.draw_dropout_masks(b))
-                            if not self._launch_step(b, err_penalty, sc_penalty_x001, True, optimizer, nb, d,
-                                                     predraw_next=draw_dropout and nb is not None):
+                            if dp_tail is not None:         # local sums, then the exchange + Adam / accumulation
+                                self._launch_step(b, err_penalty, sc_penalty_x001, False, None, nb, None,
+                                                  predraw_next=draw_dropout and nb is not None)
+                                if not dp_tail[1](d):
+                                    raise RuntimeError("data-parallel tail refused during capture")
+                            elif not self._launch_step(b, err_penalty, sc_penalty_x001, True, optimizer, nb, d,
+                                                       predraw_next=draw_dropout and nb is not None):
                                 raise RuntimeError("fusion refused during capture")
                 torch.cuda.current_stream().wait_stream(side)
                 self._prescanned, self._predrawn = saved, saved_drawn   # nothing has run yet
@@ -708,6 +717,67 @@ class HipChainEngine:
             return False
         hip.check(self.lib.mmn_adam_step_accumulate(self._plan, C.byref(d), err_penalty, sc_penalty_x001, self._stream()),
                   "mmn_adam_step_accumulate")
+        optimizer.mark_fused_step()
+        return True
+
+    # ---- one-shot data-parallel exchange (opt-in; include/mmn_hip.h mmn_dp_oneshot_attach)
+    def attach_oneshot(self, group, world: int, rank: int, spin_ms: int = 5000) -> None:
+        """Collective over `group`: every rank allocates its exchange buffer, the 64-byte hipIpc handles travel through
+        torch.distributed's object all-gather, every rank maps the peers' buffers and hands all of them to the plan.
+        To be called again after a re-plan (the buffers are sized by the plan)."""
+        import torch.distributed as dist
+        self.detach_oneshot()
+        nbytes = int(self.lib.mmn_dp_xbuf_bytes(self._plan))
+        if nbytes == 0:
+            raise hip.MmnError("one-shot exchange: this plan has no flat gradient layout")
+        own = C.c_void_p()
+        handle = C.create_string_buffer(64)
+        hip.check(self.lib.mmn_dp_xbuf_alloc(nbytes, C.byref(own), handle), "mmn_dp_xbuf_alloc")
+        handles = [None] * world
+        dist.all_gather_object(handles, (nbytes, bytes(handle.raw)), group=group)
+        if any(h[0] != nbytes for h in handles):
+            raise hip.MmnError(f"one-shot exchange: the ranks' plans differ ({[h[0] for h in handles]} bytes)")
+        ptrs = (C.c_void_p * world)()
+        for r in range(world):
+            if r == rank:
+                ptrs[r] = own.value
+            else:
+                peer = C.c_void_p()
+                hip.check(self.lib.mmn_dp_xbuf_open(handles[r][1], C.byref(peer)), "mmn_dp_xbuf_open")
+                ptrs[r] = peer.value
+        hip.check(self.lib.mmn_dp_oneshot_attach(self._plan, world, rank, ptrs, int(spin_ms)), "mmn_dp_oneshot_attach")
+        self._oneshot = {"ptrs": [ptrs[r] for r in range(world)], "rank": rank, "plan": self._plan.value}
+        dist.barrier(group=group)                               # nobody steps before everybody has mapped everything
+
+    def detach_oneshot(self) -> None:
+        st = getattr(self, "_oneshot", None)
+        self._oneshot = None
+        if st is None:
+            return
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        for r, ptr in enumerate(st["ptrs"]):
+            self.lib.mmn_dp_xbuf_close(ptr, 1 if r == st["rank"] else 0)
+
+    def oneshot_attached(self) -> bool:
+        st = getattr(self, "_oneshot", None)
+        return st is not None and self._plan is not None and st["plan"] == self._plan.value
+
+    def oneshot_check(self) -> None:
+        """Raises once a wait of the exchange ran out (a peer died or fell minutes behind): no synchronisation, one read
+        of a host-mapped word."""
+        if getattr(self, "_oneshot", None) is not None:
+            hip.check(self.lib.mmn_dp_oneshot_error(self._plan), "one-shot data-parallel exchange")
+
+    def accumulate_and_step_oneshot(self, err_penalty: float, sc_penalty_x001: float, optimizer, desc=None) -> bool:
+        """Data-parallel tail WITHOUT a collective in front of it: exchange of [grads | stats] with the peers' mapped
+        buffers, rank-ordered sum, Adam and epoch accumulation in one launch.  Returns False (nothing launched) when
+        the optimizer cannot be fused: the caller then takes the all-reduce path."""
+        d = desc if desc is not None else (optimizer.fused_descriptor(self) if hasattr(optimizer, "fused_descriptor") else None)
+        if d is None or self.lib.mmn_adam_fusable(self._plan, C.byref(d)) != 0:
+            return False
+        hip.check(self.lib.mmn_adam_step_accumulate_oneshot(self._plan, C.byref(d), err_penalty, sc_penalty_x001, self._stream()),
+                  "mmn_adam_step_accumulate_oneshot")
         optimizer.mark_fused_step()
         return True
 

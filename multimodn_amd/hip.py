@@ -17,7 +17,7 @@ MAX_LAYERS = 8
 MAX_DIM = 128
 ADAM_MAX_SEG = 512
 ERR_UNSUPPORTED = -2
-VERSION = 108
+VERSION = 109
 MAX_DEC_HIDDEN = 3
 ENC_MLP, ENC_MIMIC = 0, 1
 
@@ -35,6 +35,8 @@ ABI_SYMBOLS = (
     "mmn_eval_step", "mmn_adam_blocks", "mmn_adam_step", "mmn_adam_step_accumulate", "mmn_train_step_adam", "mmn_reduce_adam", "mmn_regroup_rows", "mmn_regroup", "mmn_epoch_reset", "mmn_epoch_read", "mmn_debug_buffer",
     "mmn_dropout_floats", "mmn_draw_dropout", "mmn_dropout_reset", "mmn_dropout_adopt",
     "mmn_nan_flags_set", "mmn_pack_invalidate", "mmn_pack_refresh", "mmn_train_step_ex", "mmn_epoch_write", "mmn_adam_fusable", "mmn_regroup_ex", "mmn_dp_rescale", "mmn_eval_step_ex",
+    "mmn_dp_xbuf_bytes", "mmn_dp_xbuf_alloc", "mmn_dp_xbuf_open", "mmn_dp_xbuf_close", "mmn_dp_oneshot_attach",
+    "mmn_dp_oneshot_error", "mmn_adam_step_accumulate_oneshot",
 )
 
 
@@ -157,6 +159,20 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_reduce.argtypes = [vp, C.POINTER(Batch), vp]
     lib.mmn_eval_step_ex.restype = i32
     lib.mmn_eval_step_ex.argtypes = [vp, C.POINTER(Batch), i32, i32, vp, vp, vp]
+    lib.mmn_dp_xbuf_bytes.restype = C.c_size_t
+    lib.mmn_dp_xbuf_bytes.argtypes = [vp]
+    lib.mmn_dp_xbuf_alloc.restype = i32
+    lib.mmn_dp_xbuf_alloc.argtypes = [C.c_size_t, C.POINTER(vp), C.c_char_p]
+    lib.mmn_dp_xbuf_open.restype = i32
+    lib.mmn_dp_xbuf_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.mmn_dp_xbuf_close.restype = i32
+    lib.mmn_dp_xbuf_close.argtypes = [vp, i32]
+    lib.mmn_dp_oneshot_attach.restype = i32
+    lib.mmn_dp_oneshot_attach.argtypes = [vp, i32, i32, C.POINTER(vp), i32]
+    lib.mmn_dp_oneshot_error.restype = i32
+    lib.mmn_dp_oneshot_error.argtypes = [vp]
+    lib.mmn_adam_step_accumulate_oneshot.restype = i32
+    lib.mmn_adam_step_accumulate_oneshot.argtypes = [vp, C.POINTER(AdamDesc), f32, f32, vp]
     lib.mmn_dp_rescale.restype = i32
     lib.mmn_dp_rescale.argtypes = [vp, vp, C.c_int64, i32, vp]
     lib.mmn_epoch_accumulate.restype = i32

@@ -10,6 +10,7 @@ epoch.  There is no torch-op fallback for that body: without the HIP library or 
 """
 from __future__ import annotations
 
+import os
 import random
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
@@ -173,7 +174,7 @@ class MultiModN(nn.Module):
     #: global batch after the all-reduce (engine.dp_rescale)
     DP_NOMINAL_BATCH = 1 << 16
 
-    def enable_data_parallel(self, process_group=None, uneven_shards: bool = False) -> None:
+    def enable_data_parallel(self, process_group=None, uneven_shards: bool = False, oneshot: Optional[bool] = None) -> None:
         """One process per GPU: every rank feeds its shard of each global mini-batch; gradients and
         the per-step statistics are summed with ONE all-reduce (RCCL over xGMI) per step.
 
@@ -189,6 +190,13 @@ class MultiModN(nn.Module):
         self._dp_group = process_group if process_group is not None else dist.group.WORLD
         self._dp_world = dist.get_world_size(self._dp_group)
         self._dp_rank = dist.get_rank(self._dp_group)
+        # `oneshot` (default: the environment's MMN_DP_ONESHOT=1, else off): training steps with multimodn_amd.optim.Adam
+        # exchange [grads | stats] through buffers every rank's process has mapped (hipIpc; xGMI between GPUs) INSIDE the
+        # launch that applies Adam, instead of one RCCL all-reduce + that launch: no collective per step, one launch less.
+        # Even shards only, one node (<= 8 ranks).  Opt-in until a multi-GPU box has run it.
+        if oneshot is None:
+            oneshot = os.environ.get("MMN_DP_ONESHOT", "0") not in ("", "0")
+        self._dp_oneshot = bool(oneshot) and not uneven_shards and self._dp_world <= 8
 
     def _get_engine(self, batch: int):
         if self._engine is None:
@@ -314,6 +322,36 @@ class MultiModN(nn.Module):
             eng.assign_grads(None)
         return fd
 
+    def _dp_group_tail(self, eng, optimizer):
+        """(key, fn) for engine.run_group when a data-parallel step can sit in a captured group, else None: the one-shot
+        exchange (its launch is the library's own), or torch's RCCL all-reduce inside the capture (torch's NCCL binding is
+        capturable; round 4, one rank on one GPU with real RCCL launches: 62.1 us/step in captured groups of 8 steps against
+        71.0 us eager - the eager data-parallel step is host-bound; MMN_DP_GRAPH=0 keeps the steps eager)."""
+        if getattr(self, "_dp_nominal", 0) or not hasattr(eng, "run_group"):
+            return None
+        alpha, beta = float(self.err_penalty), float(self.state_change_penalty)
+        if self._oneshot_ready(eng):
+            return ("oneshot", lambda d: eng.accumulate_and_step_oneshot(alpha, beta, optimizer, desc=d))
+        if os.environ.get("MMN_DP_GRAPH", "1") not in ("", "0"):
+            import torch.distributed as dist
+            if dist.get_backend(self._dp_group) == "nccl":
+                def tail(d):
+                    dist.all_reduce(eng.reduce_buf, group=self._dp_group)
+                    return eng.accumulate_and_step(alpha, beta, optimizer, desc=d)
+                return ("rccl", tail)
+        return None
+
+    def _oneshot_ready(self, eng) -> bool:
+        """One-shot exchange requested and possible with this engine: attaches it (a collective: every rank gets here in
+        the same step, the ranks' plans being the same) the first time and after a re-plan."""
+        if not getattr(self, "_dp_oneshot", False) or not hasattr(eng, "attach_oneshot"):
+            return False
+        if not eng.oneshot_attached():
+            eng.attach_oneshot(self._dp_group, self._dp_world, self._dp_rank,
+                               spin_ms=int(os.environ.get("MMN_DP_SPIN_MS", "5000")))
+        eng.oneshot_check()
+        return True
+
     def _global_rows(self, local_rows: int) -> int:
         """The divisor of this step's means: the global batch (local rows x ranks), or the nominal batch all ranks
         agree on when shards may be uneven (enable_data_parallel)."""
@@ -373,7 +411,10 @@ class MultiModN(nn.Module):
                                         **({"desc": desc} if desc is not None else {}))
         else:
             eng.eval_step(b, accumulate=not dp)
-        if dp:
+        if dp and train and optimizer is not None and self._oneshot_ready(eng) and \
+                eng.accumulate_and_step_oneshot(alpha, beta, optimizer, **({"desc": desc} if desc is not None else {})):
+            st.stepped = True                               # exchange + rank-ordered sum + Adam + accumulation: ONE launch
+        elif dp:
             self._dp_all_reduce(eng.reduce_buf if train else eng.stats)     # THE collective of the step: grads + stats + flags
             if getattr(self, "_dp_nominal", 0):
                 eng.dp_rescale(self._dp_nominal, with_grads=train)
@@ -446,7 +487,9 @@ class MultiModN(nn.Module):
                 prov = regrouped
             keep = (keep, eng.draw_dropout_masks(b, prov))
         eng.local_step(b, alpha, beta, accumulate=not dp, optimizer=fuse, **({"desc": desc} if desc is not None else {}))
-        if dp:                                              # per-sample masks / sequences are per-row data: shards add up
+        if dp and optimizer is not None and self._oneshot_ready(eng) and eng.accumulate_and_step_oneshot(alpha, beta, optimizer):
+            pass
+        elif dp:                                            # per-sample masks / sequences are per-row data: shards add up
             self._dp_all_reduce(eng.reduce_buf)
             if getattr(self, "_dp_nominal", 0):
                 eng.dp_rescale(self._dp_nominal)
@@ -568,8 +611,12 @@ class MultiModN(nn.Module):
             # pre-scans); batches staged from the host by one (the staging ring is three deep)
             resident = not window[0].on_host
             fused_surface = mode == "device" and state["fd"] is not None
-            can_replay = (not dp and mode == "device" and getattr(self, "replay_steps", True) and not log_interval
-                          and self.dropout_mask_provider is None and hasattr(eng, "run_group") and optimizer is not None)
+            # data parallel: groups are captured too when the exchange is the one-shot kernel (nothing but this library's
+            # launches in the graph), or - MMN_DP_GRAPH=1 - with torch's all-reduce inside the capture
+            dp_tail = self._dp_group_tail(eng, optimizer) if (dp and mode == "device" and state["fd"] is not None) else None
+            can_replay = ((not dp or dp_tail is not None) and mode == "device" and getattr(self, "replay_steps", True)
+                          and not log_interval and self.dropout_mask_provider is None and hasattr(eng, "run_group")
+                          and optimizer is not None)
             group = 1
             # (sending the first step of a sequence out on its own, so that the GPU works while the first group is being
             #  ingested, was measured: 77.6 instead of 74.9 us/step over 20 steps - the group's replay then starts late)
@@ -596,10 +643,15 @@ class MultiModN(nn.Module):
                     eng.assign_grads(None)
                     state["grads_assigned"] = True
                 reset_now = bool(state.get("need_reset"))
+                if dp_tail is not None and window[0].b.nan_flags and eng._prescanned is not window[0].b:
+                    # the group's first batch has no predecessor whose exchange carried its NaN flags (first batch of an
+                    # epoch): scanned on its own and summed over the ranks now, in front of the group
+                    eng.nan_scan(window[0].b)
+                    self._dp_all_reduce(eng.flag_tail)
                 ent_now = eng.group_entry(steps, nxt, float(self.err_penalty), float(self.state_change_penalty), optimizer,
                                           bool(eng.dropout_encoders), state["fd"], reset_now)[0] if plan_ok else None
                 if eng.run_group(steps, nxt, float(self.err_penalty), float(self.state_change_penalty), optimizer,
-                                 bool(eng.dropout_encoders), state["fd"], reset_first=reset_now):
+                                 bool(eng.dropout_encoders), state["fd"], reset_first=reset_now, dp_tail=dp_tail):
                     state["need_reset"] = False
                     rec.append((steps, nxt, ent_now))
                     for _ in range(n):

@@ -159,7 +159,7 @@ def test_two_rank_dp_with_uneven_shards_equals_single_process(name, policy, tmp_
 # (batch_global divisors), the one-buffer all-reduce, the global NaN decision under both policies and
 # the one-launch data-parallel tail.
 # ------------------------------------------------------------------------------------------------
-def _gpu_worker(rank, world, port, name, policy, out_dir, uneven=False):
+def _gpu_worker(rank, world, port, name, policy, out_dir, uneven=False, oneshot=False, die_after=None):
     import torch.distributed as dist
     import multimodn_amd as mm
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -169,7 +169,7 @@ def _gpu_worker(rank, world, port, name, policy, out_dir, uneven=False):
     g = Golden(name)
     model = build_torch_model(g.spec, g.init_params(), "cuda", mm)
     model.nan_policy = policy
-    model.enable_data_parallel(uneven_shards=uneven)
+    model.enable_data_parallel(uneven_shards=uneven, oneshot=oneshot)
     calls = _count_collectives(dist)
     opt = mm.optim.Adam(list(model.parameters()), g.cfg["lr"])
     hist = mm.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
@@ -191,8 +191,23 @@ def _gpu_worker(rank, world, port, name, policy, out_dir, uneven=False):
         return torch.from_numpy(m[lo:hi])
 
     model.dropout_mask_provider = provide
-    for _ in range(g.epochs):
+    if die_after is not None and rank == 1:
+        class _Dying(list):                                 # rank 1 disappears in the MIDDLE of epoch `die_after`, in front of
+            epoch = 0                                       # its second step, without saying goodbye (status 0: the launcher
+                                                            # must hear of it from the SURVIVOR, whose exchange kernel waits)
+            def __iter__(self):
+                for i, item in enumerate(list.__iter__(self)):
+                    if _Dying.epoch == die_after and i == 1:
+                        torch.cuda.synchronize()
+                        os._exit(0)
+                    yield item
+                _Dying.epoch += 1
+        loader = _Dying(loader)
+    for ep in range(g.epochs if die_after is None else 50):
         model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+        if die_after is not None:
+            torch.cuda.synchronize()
+            model._engine.oneshot_check()
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=np.stack(hist.loss["train"]),
              acc=np.stack(hist.accuracy["train"]), sc=np.stack(hist.state_change_loss),
@@ -220,6 +235,47 @@ def test_two_rank_dp_on_one_gpu_equals_reference_golden(name, policy, tmp_path):
     w64 = fp64_trajectory(g)[0]                          # 2e-5 of the reference's weights, or within fp32 noise of the fp64 replay
     for n, w in g.final_params().items():
         assert_within_fp32_noise(r0["p/" + n], w, w64[n], n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,policy", [("seq_perm", "device"), ("nan_skip", "device"), ("c2_split", "device"), ("mimic_drop", "device")])
+def test_oneshot_exchange_equals_the_collective_path(name, policy, tmp_path):
+    """MMN_DP_ONESHOT (opt-in): two PROCESSES sharing the box's one GPU map each other's exchange buffers (hipIpc) and sum
+    [grads | stats] inside the launch that applies Adam - no collective per step.  With two ranks a + b is the all-reduce's
+    sum exactly: History and trained weights must be BIT-EQUAL to the run over torch.distributed's all-reduce, and the
+    all-reduce count drops to the one per epoch that carries the first batch's NaN flags."""
+    a, b = tmp_path / "coll", tmp_path / "shot"
+    a.mkdir(); b.mkdir()
+    mp.spawn(_gpu_worker, args=(2, _free_port(), name, policy, str(a)), nprocs=2, join=True)
+    mp.spawn(_gpu_worker, args=(2, _free_port(), name, policy, str(b), False, True), nprocs=2, join=True)
+    c0, s0, s1 = np.load(a / "rank0.npz"), np.load(b / "rank0.npz"), np.load(b / "rank1.npz")
+    for k in c0.files:
+        if k != "collectives":
+            assert np.array_equal(c0[k], s0[k]), k            # one-shot == all-reduce path, bit for bit
+            assert np.array_equal(s0[k], s1[k]), k            # replicas stay bit-identical
+    n_ar, n_other, n_steps, n_epochs = (int(v) for v in s0["collectives"])
+    assert n_ar == n_epochs and n_steps > n_epochs            # no all-reduce per step any more
+
+
+@pytest.mark.gpu
+def test_oneshot_exchange_ends_with_an_error_when_a_peer_dies(tmp_path):
+    """A peer process disappears between two epochs: the survivor's next exchange waits MMN_DP_SPIN_MS (bounded spin in the
+    kernel), raises the error word, and the next call fails with MMN_ERR_PEER - a non-zero exit within seconds, no hang."""
+    import subprocess
+    import sys
+    import time
+    code = (
+        "import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch.multiprocessing as mp, test_dp_gloo as t\n"
+        "if __name__ == '__main__':\n"
+        "    mp.spawn(t._gpu_worker, args=(2, t._free_port(), 'c2_split', 'device', %r, False, True, 2), nprocs=2, join=True)\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path))
+    env = dict(os.environ, MMN_DP_SPIN_MS="500")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0
+    assert time.time() - t0 < 120
+    assert "one-shot" in out.stderr or "peer" in out.stderr.lower(), out.stderr[-1500:]
 
 
 @pytest.mark.gpu

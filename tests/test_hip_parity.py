@@ -261,6 +261,43 @@ def test_full_size_c3_five_adam_steps_within_fp32_noise(lib):
     print(f"compared {compared} tensors, {len(flipped)} crossed a relu kink: {sorted(flipped)}")
 
 
+@pytest.mark.parametrize("which", ["c1", "c2"])
+def test_titanic_configs_at_their_stated_sizes(lib, which):
+    """BASELINE.json configs[0] / configs[1] at the sizes they state, through the public train_epoch: C1 = the Titanic MLP
+    pipeline's shape (pipelines/titanic/titanic_mlp_pipeline.py:63-74: 570 training rows, batch 32 -> 17 full batches and
+    one of 26 rows, E = 1, F = 6, H = (5, 5), S = 32, D = 1, Adam 0.01, penalties 0.7 / 0.3) for one whole epoch = 18 Adam
+    steps; C2 = two encoders over the [3, 2] feature split (titanic_partitioned_pipeline.py:26-27), S = 64, D = 2, batch 512,
+    5 Adam steps.  Against the numpy oracle's train_epoch on the same batches: History loss / state change 1e-5, the
+    count ratios equal wherever the float64 replay has no near-tie, trained weights within fp32 noise of the float64
+    trajectory (assert_within_fp32_noise)."""
+    if which == "c1":
+        spec = O.ModelSpec(32, [O.EncoderSpec(6, (5, 5), O.ACT_RELU)], 1, 0.7, 0.3)
+        rows, B, lr = 570, 32, 0.01
+    else:
+        spec = O.ModelSpec(64, [O.EncoderSpec(3, (5, 5), O.ACT_RELU), O.EncoderSpec(2, (5, 5), O.ACT_RELU)], 2, 0.7, 0.3)
+        rows, B, lr = 5 * 512, 512, 0.01
+    params = O.init_params(spec, 3)
+    batches = O.synthetic_batches(spec, rows, B, seed=17)
+    assert len(batches) == (18 if which == "c1" else 5) and len(batches[-1][1]) == (26 if which == "c1" else 512)
+    model = build_torch_model(spec, params, "cuda", lib)
+    opt = lib.optim.Adam(model.parameters(), lr=lr)
+    hist = lib.MultiModNHistory([f"t{d}" for d in range(spec.D)])
+    loader = [([torch.from_numpy(x) for x in xs], torch.from_numpy(y)) for xs, y in batches]
+    model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+    torch.cuda.synchronize()
+    p32 = {n: np.asarray(v, np.float32).copy() for n, v in params.items()}
+    p64 = {n: np.asarray(v, np.float64) for n, v in params.items()}
+    e32 = O.train_epoch(p32, spec, batches, O.Adam(lr))
+    e64 = O.train_epoch(p64, spec, batches, O.Adam(lr), dtype=np.float64)
+    assert rel_err(hist.loss["train"][0], e64.loss) < 1e-5 and rel_err(hist.loss["train"][0], e32.loss) < 1e-5
+    assert rel_err(hist.state_change_loss[0], e64.state_change) < 1e-5
+    if np.array_equal(e32.accuracy, e64.accuracy):          # (no prediction sits on a tie: the counts are exact)
+        for k in ("accuracy", "sensitivity", "specificity", "balanced_accuracy"):
+            assert np.array_equal(getattr(hist, k)["train"][0], getattr(e32, k)), k
+    for n, p in model.named_parameters():
+        assert_within_fp32_noise(p.detach().cpu().numpy(), p32[n], p64[n], (which, n))
+
+
 def test_shard_linearity_full_size(lib):
     """Size-independent property used by data parallelism: with batch_global fixed, the reduce
     buffer of the full batch equals the sum of the shards' buffers (grads and statistics)."""

@@ -43,16 +43,18 @@ def run_step(model, batch, masks=None, batch_global=None, nan_policy="host"):
     return stats, grads, executed
 
 
-@pytest.mark.parametrize("form", ["split", "batched", "fast", "sequential"])
+@pytest.mark.parametrize("form", ["split", "split_genf2", "batched", "fast", "sequential"])
 @pytest.mark.parametrize("rt", ["1", "2"])
 @pytest.mark.parametrize("name", MIMIC_GOLDEN_NAMES)
 def test_first_step_matches_reference_golden(lib, name, rt, form, monkeypatch):
     """Both forms of the generic tier (k_genf_* where the model is eligible, k_gen_* otherwise or when forced) and
-    both tile heights."""
+    both tile heights.  "split": the default - at the MIMIC pipelines' encoder shape (mimic_c3_small) the chain is
+    k_mfwd / k_mbwd; "split_genf2": the same split with k_genf2_fwd / k_genf2_bwd kept as the chain (MMN_MC=0)."""
     monkeypatch.setenv("MMN_RT", rt)
     monkeypatch.setenv("MMN_GEN_FAST", "0" if form == "sequential" else "1")
-    monkeypatch.setenv("MMN_GEN_BATCHED", "1" if form in ("batched", "split") else "0")   # decoders of all grid rows at once (16-row tiles)
-    monkeypatch.setenv("MMN_GEN_SPLIT", "1" if form == "split" else "0")        # ... in a launch of their own (k_dec_fb)
+    monkeypatch.setenv("MMN_GEN_BATCHED", "1" if form in ("batched", "split", "split_genf2") else "0")   # decoders of all grid rows at once (16-row tiles)
+    monkeypatch.setenv("MMN_GEN_SPLIT", "1" if form in ("split", "split_genf2") else "0")        # ... in a launch of their own (k_dec_fb)
+    monkeypatch.setenv("MMN_MC", "0" if form == "split_genf2" else "1")
     g = Golden(name)
     model = build_torch_model(g.spec, g.init_params(), "cuda", lib)
     stats, grads, _ = run_step(model, g.batch(0), g.step_masks(0))

@@ -8,9 +8,13 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AS1 __attribute__((address_space(1)))
 
+// rot (round 4): every workgroup walks the SAME shared block, but piece p is read as p ^ ((blockIdx.x >> 3) & rot): the
+// workgroups that share an XCD (round-robin placement: blocks b, b + 8, ...) ask for DIFFERENT kilobytes at any one time
+// instead of all for the same one (same L2 channel).
 template <int NL>   // loads in flight per lane
-__global__ __launch_bounds__(256) void k_fetch(const float* buf, int kb_per_wave, int distinct, long long* out, float* sink) {
+__global__ __launch_bounds__(256) void k_fetch(const float* buf, int kb_per_wave, int distinct, long long* out, float* sink, int rot = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rx = (blockIdx.x >> 3) & rot;
     const float* base = buf + (size_t)(distinct ? blockIdx.x : 0) * kb_per_wave * 4 * 256 + (size_t)wave * kb_per_wave * 256 + lane * 4;
     __syncthreads();
     const long long t0 = wall_clock64();
@@ -18,7 +22,7 @@ __global__ __launch_bounds__(256) void k_fetch(const float* buf, int kb_per_wave
     for (int k = 0; k < kb_per_wave; k += NL) {
         f32x4 v[NL];
 #pragma unroll
-        for (int j = 0; j < NL; ++j) v[j] = *(const AS1 f32x4*)(base + (size_t)(k + j) * 256);
+        for (int j = 0; j < NL; ++j) v[j] = *(const AS1 f32x4*)(base + (size_t)((k + j) ^ rx) * 256);
 #pragma unroll
         for (int j = 0; j < NL; ++j) acc += v[j];
     }
@@ -48,6 +52,17 @@ int main() {
         std::sort(h.begin(), h.end());
         const double us_med = h[grid / 2] / 100.0, us_max = h[grid - 1] / 100.0;
         printf("distinct=%d fresh=%d KB/WG=%3d : median %.2f us (%.1f GB/s per CU), max %.2f us\n", distinct, fresh, kbw * 4,
+               us_med, kbw * 4 * 1024 / us_med / 1e3, us_max);
+    }
+    // shared block, rotated piece order per workgroup (rot = 7: eight orders, 31: thirty-two) against the same order
+    for (int rot : {0, 7, 31})
+    for (int kbw : {24, 96}) {
+        for (int rep = 0; rep < 3; ++rep) k_fetch<8><<<grid, 256>>>(buf, kbw, 0, out, sink, rot);
+        hipDeviceSynchronize();
+        hipMemcpy(h.data(), out, grid * sizeof(long long), hipMemcpyDeviceToHost);
+        std::sort(h.begin(), h.end());
+        const double us_med = h[grid / 2] / 100.0, us_max = h[grid - 1] / 100.0;
+        printf("shared, 8 in flight, rot=%2d KB/WG=%3d : median %.2f us (%.1f GB/s per CU), max %.2f us\n", rot, kbw * 4,
                us_med, kbw * 4 * 1024 / us_med / 1e3, us_max);
     }
     return 0;

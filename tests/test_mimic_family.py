@@ -265,10 +265,15 @@ def test_kernel_names_and_forms(lib, monkeypatch):
     eng = fast._get_engine(64)
     b = eng.make_batch([torch.zeros(64, 64, device="cuda") for _ in range(4)], torch.zeros(64, 3, dtype=torch.int64, device="cuda"),
                        [(k, k) for k in range(4)])
-    assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 0) == b"k_genf2_fwd"      # decoders batched over the grid rows
-    assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 1) == b"k_genf2_bwd"     # and their gradients ahead of the reverse chain
+    assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 0) == b"k_mfwd"          # the MIMIC pipelines' encoder shape: the 8-wave chain
+    assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 1) == b"k_mbwd"          # kernels with every operand in registers (round 4)
     assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 2) == b""
     assert eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(b), 3) == b"k_dec_fb"        # the decoders' own launch (split form)
+    wide = O.ModelSpec(128, [O.EncoderSpec(64, (64, 32), O.ACT_RELU, kind="mimic", dropout=0.2) for _ in range(4)], 3, 1.0, 0.3,
+                       decoders=[O.DecoderSpec("mlp", (32, 32)) for _ in range(3)])       # a 64-wide hidden layer: outside k_mfwd's shapes
+    eng1 = build_torch_model(wide, O.init_params(wide, 0), "cuda", lib)._get_engine(64)
+    assert eng1.lib.mmn_chain_kernel_name(eng1._plan, C.byref(b), 0) in (b"k_genf2_fwd", b"k_genf_fwd")   # round 2 / 3's fast forms
+    assert eng1.lib.mmn_chain_kernel_name(eng1._plan, C.byref(b), 1) in (b"k_genf2_bwd", b"k_genf_bwd")
     g = Golden("mimic_mixed")                               # one MLPEncoder among the MIMIC ones: sequential form
     mixed = build_torch_model(g.spec, g.init_params(), "cuda", lib)
     eng2 = mixed._get_engine(16)
@@ -625,5 +630,5 @@ def test_sweep_ran_both_forms():
     """The sweep above must have exercised both forms of the generic tier (it runs before this test)."""
     if sum(SWEEP_FORMS.values()) < 48:
         pytest.skip("sweep not run in this session")
-    assert SWEEP_FORMS["k_genf_fwd"] + SWEEP_FORMS["k_genf2_fwd"] >= 8 and SWEEP_FORMS["k_gen_fwd"] >= 8, dict(SWEEP_FORMS)
-    assert SWEEP_FORMS["k_genf2_bwd"] >= 16 and SWEEP_FORMS["k_genf_bwd"] >= 4, dict(SWEEP_FORMS)
+    assert SWEEP_FORMS["k_genf_fwd"] + SWEEP_FORMS["k_genf2_fwd"] + SWEEP_FORMS["k_mfwd"] >= 8 and SWEEP_FORMS["k_gen_fwd"] >= 8, dict(SWEEP_FORMS)
+    assert SWEEP_FORMS["k_genf2_bwd"] + SWEEP_FORMS["k_mbwd"] >= 16 and SWEEP_FORMS["k_genf_bwd"] >= 4, dict(SWEEP_FORMS)

@@ -752,7 +752,7 @@ def main():
     achieved = fl[dominant] * B / (avg_us[dominant] * 1e-6) / 1e12
     traffic, mfma_busy = None, None
     try:                                                      # HBM bytes per launch / matrix-pipe busy % from the committed PMC passes
-        tag = {"c3": "r03_final", "mimic": "r03_mimic", "c5": "r03_c5"}.get(args.workload)
+        tag = {"c3": "r04_final", "mimic": "r04_mimic", "c5": "r04_c5"}.get(args.workload)
         if tag and B == wl["B"]:                             # the passes were made on this workload at this batch
             pmc = json.load(open(os.path.join(REPO, "profiles", f"{tag}_pmc_traffic.json")))
             traffic = pmc["kernels"].get(dominant, {}).get("hbm_bytes_per_launch")
@@ -763,9 +763,10 @@ def main():
     roofline = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "mfma_busy_pct_pmc": mfma_busy,
+                "traffic_source": (f"profiles/{tag}_pmc_traffic.json, profiles/{tag}_pmc_util.json (builder-run: separate rocprofv3 "
+                                   "--pmc passes of this command on another box, committed; NOT measured in this run)") if traffic else None,
                 "traffic_note": "HBM bytes per launch of the dominant kernel = (2*FETCH_SIZE + WRITE_SIZE)*1024 and its "
-                                "SQ_VALU_MFMA_BUSY_CYCLES share from profiles/r03_final_pmc_traffic.json / _pmc_util.json "
-                                "(mimic workload: r03_mimic_*), separate rocprofv3 --pmc passes",
+                                "SQ_VALU_MFMA_BUSY_CYCLES share; achieved / frac / avg_launch_us ARE measured in this run (HIP events)",
                 "avg_launch_us": avg_us, "flops_per_sample": fl,
                 "algorithmic_flops_per_launch": fl[dominant] * B,
                 "step_frac_of_fp32_roof": value / world * sum(fl.values()) / (FP32_MFMA_PEAK_TFLOPS * 1e12),
@@ -774,7 +775,8 @@ def main():
     if args.optimizer != "hip":
         opt_text = "torch.optim.Adam(fused, capturable)"
     elif dp:
-        opt_text = "multimodn_amd.optim.Adam in the launch behind the all-reduce (k_adam_accumulate)"
+        opt_text = ("multimodn_amd.optim.Adam inside the one-shot exchange launch (k_adam_accumulate_oneshot)" if getattr(model, "_dp_oneshot", False)
+                    else "multimodn_amd.optim.Adam in the launch behind the all-reduce (k_adam_accumulate)")
     else:
         opt_text = "multimodn_amd.optim.Adam fused into k_reduce"
     out = {
@@ -786,7 +788,7 @@ def main():
                    "optimizer": opt_text,
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
                    "step_path": "MultiModN._train_steps (the batch loop of MultiModN.train_epoch)",
-                   "launch": f"hipGraph replay ({group} steps per graph)" if replayed else "eager",
+                   "launch": f"hipGraph replay ({max(group, int(getattr(model, 'REPLAY_GROUP', 8))) if dp else group} steps per graph)" if replayed else "eager",
                    # counted around every torch.distributed collective of the timed region (n steps + 1 for the sequence's
                    # first batch, whose NaN flags have no predecessor to ride with)
                    "collectives_per_step": (n_coll["all_reduce"] + n_coll["other"]) / args.steps if dp else 0,

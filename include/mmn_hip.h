@@ -22,14 +22,14 @@
  *     int64 targets; deterministic (no float atomics: fixed-order two-stage reductions).
  *
  * Environment (diagnostics and tests only; read ONCE per mmn_plan_create, never needed in production):
- *   MMN_FUSED=0 / MMN_FAST8=0 / MMN_PAR=0   step down the kernel tiers (fused 8-wave -> 8-wave pair -> 4-wave parallel ->
- *                                           sequential); MMN_RT=1|2 forces 16- / 32-row tiles of the sequential tiers
+ *   MMN_FUSED=0 / MMN_FAST8=0               step down the kernel tiers (fused 8-wave k_fb9 / k_fb8 -> 8-wave pair k_fwd8 + k_bwd8 ->
+ *                                           sequential k_chain_*); MMN_FB8_LEAN=0: k_fb8 also for the shapes k_fb9 takes
  *   MMN_GENERIC=1                           run MLPEncoder / ClassDecoder models on the generic tier's kernels too
  *   MMN_GEN_FAST=0 / MMN_DEC_LDS=0          generic tier: sequential form only / decoder operands from global memory
  *   MMN_WGRAD_ROWS=n                        rows per k_wgrad row-range split (default 512)
- *   MMN_SIDE_SCAN=1                         the pre-scan of the next batch on a side stream beside the chain kernel (measured slower
- *                                           inside replayed hipGraph groups: off by default); MMN_FB9=0 / MMN_FB9_FULLK=0: k_fb8 instead of
- *                                           k_fb9 / k_fb9 with run-time trip counts
+ *   MMN_FB9=0 / MMN_FB9_FULLK=0             k_fb8 instead of k_fb9 / k_fb9 with run-time trip counts
+ *   MMN_GEN_BATCHED=0 / MMN_GEN_SPLIT=0 / MMN_MC=0   generic tier: sequential form / decoders inside the chain kernels / k_genf2_* as
+ *                                           the chain where k_mfwd / k_mbwd would run
  *   MMN_STAMPS=1                            phase timestamps of one workgroup (mmn_debug_buffer kind 3; tools/stamps*.py)
  *   MMN_VERBOSE=1                           plan summary on stderr
  */
@@ -232,10 +232,11 @@ int mmn_prepare(mmn_plan* p, const mmn_batch* b, int want_grads, void* stream);
 int mmn_nan_scan(mmn_plan* p, const mmn_batch* b, void* stream);
 
 /* Which device kernel mmn_chain_fwd (backward = 0) / mmn_chain_bwd (backward = 1) launches for this
- * plan and batch: "k_fwd8"/"k_bwd8" (8-wave tier for MIMIC-like shapes), "k_chain_fwd_par"/
- * "k_chain_bwd_par" (4-wave parallel-phase tier), "k_chain_fwd"/"k_chain_bwd" (any MLPEncoder /
- * ClassDecoder shape) or "k_gen_fwd"/"k_gen_bwd" (models with a MIMIC_MLPEncoder or an MLPDecoder).  For
- * matching rocprof rows.  backward = 2 asks for the fused forward+backward kernel ("k_fb8" or ""). */
+ * plan and batch: "k_fwd8"/"k_bwd8" (8-wave tier for MIMIC-like shapes), "k_chain_fwd"/"k_chain_bwd" (any MLPEncoder /
+ * ClassDecoder shape); models with a MIMIC_MLPEncoder or an MLPDecoder: "k_mfwd"/"k_mbwd" (the MIMIC pipelines' shape),
+ * "k_genf2_fwd"/"k_genf2_bwd" (other all-MIMIC models), "k_gen_fwd"/"k_gen_bwd" (anything else).  For matching rocprof
+ * rows.  backward = 2 asks for the fused forward+backward kernel ("k_fb9", "k_fb8" or ""), 3 for the decoders' own
+ * launch ("k_dec_fb" or ""). */
 const char* mmn_chain_kernel_name(mmn_plan* p, const mmn_batch* b, int backward);
 
 /* Forward chain, one launch: init-state broadcast (state.py:29-32), every executed encoder

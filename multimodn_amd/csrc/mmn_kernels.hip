@@ -6,17 +6,19 @@
 // Launch structure of one training step (reference: multimodn/multimodn.py:137-204):
 //   k_prepare          any(isnan(x_k)) per data slot (:168) + repack of every weight matrix the
 //                      chain kernels multiply by into MFMA-fragment order (forward W, backward W^T)
-//   k_fb8<TILED>       FUSED forward + reverse chain of one 16-row tile, 8 waves (shapes like the
-//                      MIMIC config, E <= 4): init broadcast, hidden MLPs, state updates, state-change
-//                      partials, all D decoders on all E+1 states, CE-over-sigmoid, argmax, confusion
-//                      counts, then grads wrt states / pre-activations; TILED = per-sample mode
-//     k_fwd8 + k_bwd8  the same math as two 8-wave kernels (E <= 8; also the forward-only path)
-//     k_chain_*_par    4-wave parallel-phase kernels (dims that fit LDS)
-//     k_chain_fwd/bwd  sequential form, any shape, 16- or 32-row tiles
-//     k_genf_fwd/bwd   generic tier, fast form: MIMIC_MLPEncoder (state enters the FIRST layer, activation on
-//                      every layer, dropout multipliers from mmn_batch.drop_mask) + MLPDecoder heads; decoder
-//                      operands / biases / item tables in LDS, descriptor as kernel argument
-//     k_gen_fwd/bwd    generic tier, sequential form: any mix of encoder / decoder kinds and shapes
+//   k_fb9<TILED, ..>   FUSED forward + reverse chain of one 16-row tile, 8 waves (E <= 4, n_features <= 64, hidden <= 32): init
+//                      broadcast, hidden MLPs, state updates with the step's operands resident in registers, state-change
+//                      partials, all D decoders on all E+1 states (K-split), CE-over-sigmoid, argmax, confusion counts,
+//                      then grads wrt states / pre-activations; TILED = per-sample mode
+//     k_fb8            the same as one kernel for wider shapes (n_features <= 128, h width <= 64), pair-per-encoder phases
+//     k_fwd8 + k_bwd8  the same math as two 8-wave kernels (E <= 8)
+//     k_chain_fwd/bwd  sequential form, any shape
+//   MIMIC pipelines' modules (MIMIC_MLPEncoder: state enters the FIRST layer, activation on every layer, dropout
+//   multipliers from mmn_batch.drop_mask; MLPDecoder heads):
+//     k_mfwd + k_dec_fb + k_mbwd   the pipelines' shape class: 8-wave chain kernels with every operand in registers
+//                      (mmn_chain_mimic.inc), the decoders' forward + loss + backward in a launch of their own
+//     k_genf2_fwd/bwd  other all-MIMIC models (weights by LDS-DMA, descriptor as kernel argument)
+//     k_gen_fwd/bwd    sequential form: any mix of encoder / decoder kinds and shapes, and per-sample mode
 //   k_wgrad            grouped split-K "A^T B" GEMM: weight, bias and init-state grads as
 //                      flat-gradient-shaped partial slabs
 //   k_reduce           fixed-order slab reduction -> grads (+ Adam on the element just summed, :204);
@@ -27,9 +29,10 @@
 //                      executed sequence (mmn_regroup)
 // ONE translation unit, split by section into the *.inc files included below (in this order): mmn_plan.inc (plan
 // structs, device helpers), mmn_prepare.inc (k_prepare), mmn_chain_seq.inc (sequential chain kernels),
-// mmn_generic.inc (generic tier: sequential and fast form), mmn_chain_par.inc (4-wave parallel kernels),
-// mmn_chain_8w.inc (k_fwd8, k_bwd8, k_fb8), mmn_wgrad.inc, mmn_per_sample.inc (k_ps_*), mmn_adam_reduce.inc
-// (k_adam, k_reduce), mmn_host.inc (layout, plan, C ABI).
+// mmn_generic.inc (generic tier: sequential and batched forms, k_dec_fb), mmn_chain_mimic.inc (k_mfwd, k_mbwd),
+// mmn_chain_par.inc (helpers of the retired 4-wave tier), mmn_chain_8w.inc (k_fwd8, k_bwd8, k_fb8), mmn_chain_fb9.inc
+// (k_fb9), mmn_wgrad.inc, mmn_per_sample.inc (k_ps_*), mmn_adam_reduce.inc (k_adam, k_reduce, the one-shot data-parallel
+// tail), mmn_host.inc (layout, plan, C ABI).  35 kernels, none with scratch memory (profiles/r04_kernel_resources.txt).
 //
 // Data layout in HBM (all fp32 row-major, B = batch rows):
 //   states[e][B][S]     output state of encoder e          hid[e][l][B][H_l]  hidden activations

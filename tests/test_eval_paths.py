@@ -138,7 +138,7 @@ def test_last_epoch_returns_test_results():
 
 # ------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["fused8", "par16", "seq16"])
+@pytest.mark.parametrize("mode", ["fused8", "fast8", "seq16"])
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_hip_eval_entry_points_match_reference_golden(name, mode, monkeypatch):
     from test_hip_parity import set_mode

@@ -119,10 +119,6 @@ def test_prescan_skips_what_the_reference_skips(family):          #  encoder it 
         _same(host, got)
         if replay:
             assert sum(1 for v in got[4]._engine._step_graphs.values() if v[1] is not None) >= 1
-        # the same with the scan of batch t+1 on the library's side stream beside the chain kernel (fork / join edges,
-        # eager and inside captured groups; off by default because it measured slower: MMN_SIDE_SCAN)
-        got = _train(lib, spec, loader, 3, replay=replay, policy="device", env={"MMN_SIDE_SCAN": "1"})
-        _same(host, got)
     # rows of the skipped encoders: loss 0 in the batches that skipped them -> smaller epoch mean than the clean rows
     assert np.isfinite(host[0]).all()
 

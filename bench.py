@@ -11,7 +11,7 @@ chain kernels' weight copies and the NaN scan of the NEXT batch fused in [N>1: r
 ONE RCCL all-reduce of grads + stats + NaN flags, then loss/epoch accumulation + Adam in one launch].
 
 Other workloads (never what the driver reads): --workload c1|c2 (Titanic-shaped), c5 (per-sample missing modalities), c5m (the same with the MIMIC modules),
-mimic (the MIMIC pipelines' own modules, MIMIC_MLPEncoder + MLPDecoder, on the generic tier's batched-decoder kernels k_genf2_fwd / k_genf2_bwd).
+mimic (the MIMIC pipelines' own modules, MIMIC_MLPEncoder + MLPDecoder, on the chain kernels k_mfwd / k_mbwd with the batched decoders of k_dec_fb).
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]      (N>1 without a launcher: it starts its own N ranks)
          N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -51,7 +51,7 @@ WORKLOADS = {
                   text="SURVEY 8f #1, the MIMIC pipelines' own modules at the MIMIC shape: 4 x MIMIC_MLPEncoder(64 features + "
                        "state 128 -> 32 -> 32 -> 128, relu on every layer, dropout 0.2 on cat[x, state], masks drawn on the "
                        "device inside the step) and 3 x MLPDecoder(128 -> 32 -> 32 -> 2), batch 4096 per GPU, Adam lr 1e-3, "
-                       "penalties 1.0/0.3; generic tier: chain kernels k_genf2_fwd / k_genf2_bwd, decoders in k_dec_fb"),
+                       "penalties 1.0/0.3; chain kernels k_mfwd / k_mbwd, decoders in k_dec_fb"),
     "c5m": dict(S=128, F=[64] * 4, H=(32, 32), D=3, B=4096, lr=1e-3, pen=(1.0, 0.3), per_sample=True, family="mimic",
                 dec_hidden=(32, 32), dropout=0.2,
                 text="BASELINE configs[4] with the modules the reference's MNAR pipeline builds (MIMIC_MLPEncoder + MLPDecoder, "
@@ -236,7 +236,12 @@ def cpu_match(O, mm, w, device, batch_size, steps=3):
                                       # the same distances as root mean squares over ALL compared weights (a max is one outlier)
                                       "rms": {"hip": (ss_hip / max(n_el, 1)) ** 0.5, "cpu_fp32_oracle": (ss_cpu / max(n_el, 1)) ** 0.5,
                                               "ratio": (ss_hip / ss_cpu) ** 0.5 if ss_cpu > 0 else 0.0}},
-            "ok": bool(worst < 1e-5 and (mimic or not failed)),
+            # the gate (exit code 4): loss cells within 1e-5; trained weights - MLPEncoder family: no tensor further from the
+            # float64 trajectory than 4x the fp32 oracle is, over at least 12 tensors without a relu-kink flip (the tests' floor);
+            # MIMIC modules (no hidden activations to look for kink flips in): the RMS distance over all weights within 4x
+            "ok": bool(worst < 1e-5 and ((not failed and compared >= min(12, len(params))) if not mimic
+                                         else (ss_cpu > 0 and (ss_hip / ss_cpu) ** 0.5 <= 4.0))),
+            "ok_rule": "loss 1e-5; weights: per-tensor 4x rule over >= 12 tensors (MIMIC modules: RMS ratio <= 4)",
             "steps": steps, "batch": batch_size,
             "against": "numpy fp32 oracle (oracle/multimodn_oracle.py), itself pinned to the reference by tests/golden; "
                        "fp64 = the same oracle in float64"}

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MMN_VERSION 109            /* 0.1.9: one-shot data-parallel exchange (mmn_dp_xbuf_*, mmn_dp_oneshot_*, mmn_adam_step_accumulate_oneshot, MMN_ERR_PEER); 0.1.8: mmn_source_hash (a library that was not built from the sources next to it does not load); 0.1.7: mmn_eval_step_ex (test(): outputs and row flag of a step collected by the call); 0.1.6: mmn_dp_rescale (uneven data-parallel shards);
+#define MMN_VERSION 110            /* 0.1.10: mmn_regroup_multi (the batches of a captured per-sample group regrouped by one set of launches); 0.1.9: one-shot data-parallel exchange (mmn_dp_xbuf_*, mmn_dp_oneshot_*, mmn_adam_step_accumulate_oneshot, MMN_ERR_PEER); 0.1.8: mmn_source_hash (a library that was not built from the sources next to it does not load); 0.1.7: mmn_eval_step_ex (test(): outputs and row flag of a step collected by the call); 0.1.6: mmn_dp_rescale (uneven data-parallel shards);
                                       0.1.5: mmn_step_opts.next_drop_* (the next step's dropout multipliers in this step's last launch), mmn_dropout_adopt;
                                       0.1.4: mmn_train_step_ex (pre-scan of the next batch, flag sets in the stats block), mmn_pack_invalidate;
                                       0.1.3: + mmn_draw_dropout; 0.1.2: MIMIC_MLPEncoder / MLPDecoder (mmn_encoder.kind, mmn_decoder.hidden, mmn_batch.drop_mask) */
@@ -257,10 +257,14 @@ int mmn_chain_bwd(mmn_plan* p, const mmn_batch* b, float state_change_penalty_x0
 int mmn_chain_fwd_bwd(mmn_plan* p, const mmn_batch* b, float err_penalty, float state_change_penalty_x001,
                       void* stream);
 
-/* Weight/bias/init-state gradients as split-K partial slabs (the other half of :203). */
+/* Weight/bias/init-state gradients as split-K partial slabs (the other half of :203).
+ * ORDER: mmn_wgrad and mmn_reduce take "which state rows exist this step" and "which row fed encoder e" from tables the
+ * chain kernel of THIS batch left in the workspace (its tile 0), not from b's own sequence and NaN flags: they are only
+ * correct right behind mmn_chain_fwd_bwd (or mmn_chain_fwd + mmn_chain_bwd) of the same batch on the same stream, with
+ * no chain launch of another batch - a forward-only step included - in between.  mmn_train_step keeps that order. */
 int mmn_wgrad(mmn_plan* p, const mmn_batch* b, void* stream);
 
-/* Fixed-order reduction of slabs -> gw/gb/g_init_state and of per-tile partials -> stats. */
+/* Fixed-order reduction of slabs -> gw/gb/g_init_state and of per-tile partials -> stats (ORDER: see mmn_wgrad). */
 int mmn_reduce(mmn_plan* p, const mmn_batch* b, void* stream);
 
 /* Loss combination (multimodn.py:194-202) and epoch accumulators (multimodn.py:206-212) from
@@ -322,6 +326,12 @@ int mmn_regroup(mmn_plan* p, const mmn_batch* in, const int64_t* seq, mmn_batch*
  * of the plan's workspace, so the regrouping of the NEXT batch may run on another stream while this plan's step runs.
  * scratch + 2 * batch is the "source row of every position" table (mmn_debug_buffer kind 5 for the plan's scratch). */
 int mmn_regroup_ex(mmn_plan* p, const mmn_batch* in, const int64_t* seq, mmn_batch* out, int32_t* scratch, void* stream);
+/* n <= 8 batches regrouped by ONE set of four launches (ABI 110): what a captured group of per-sample steps runs in front of
+ * its first step.  ins / seqs / outs / scratches: host arrays of n pointers with mmn_regroup_ex's meaning per batch
+ * (seqs or seqs[j] may be NULL; scratches is required for n > 1, each int32[2 * batch + rows]).  One multi-batch call of
+ * a plan in flight at a time (its histograms live in the plan). */
+int mmn_regroup_multi(mmn_plan* p, int n, const mmn_batch* const* ins, const int64_t* const* seqs, mmn_batch* const* outs,
+                      int32_t* const* scratches, void* stream);
 
 /* Forward-only step for test()/predict()/get_states() (multimodn.py:255-492): fwd + reduce
  * (+ accumulate).  Leaves the state rows and the decoder outputs of every grid row in the workspace

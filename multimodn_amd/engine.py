@@ -668,6 +668,127 @@ class HipChainEngine:
         ev.record(side)
         return b, (xs_p, y_p, tile_rows, tile_seq, seq, xs, y, scratch), ev, template
 
+    def run_group_per_sample(self, items, err_penalty: float, sc_penalty_x001: float, optimizer, desc, draw_dropout: bool) -> bool:
+        """run_group for per-sample mode.  `items`: consecutive device-resident mini-batches (xs, y, seq or None,
+        batch_global) whose buffers come back every epoch.  On its second sighting the group is captured into ONE hipGraph:
+        ONE set of four regrouping launches for all its batches (mmn_regroup_multi, every batch into a buffer set of its
+        own), then per batch the dropout draw and the step (chain, k_wgrad, k_reduce + Adam).  (`MMN_PS_GRAPH_FORK=1`: the
+        regrouping of every batch as launches of its own on a graph branch beside the steps - measured: the cross-queue
+        hand-off of a two-branch graph costs ~120 us per group, c5 88 instead of 77 us per step.)  Eager per-sample steps are host-bound (the loop's
+        Python and ~10 launches per step); a replayed group is one submission for len(items) steps.  Returns False when the
+        group cannot be replayed - nothing has been launched: the caller runs the steps eagerly."""
+        import os
+        if desc is None or self._step_graphs is None or torch.cuda.is_current_stream_capturing() or self._torch_regroup:
+            return False
+        E, dev = self.E, self.device
+        feats = [int(enc.n_features) for enc in self.model.encoders]
+        sizes = []
+        for xs, y, seq, bg in items:
+            B = int(y.shape[0])
+            rows = int(self.lib.mmn_regroup_rows(B, E)) if len(xs) == E and E <= 4 else 0
+            if rows <= 0 or (seq is not None and len(set(feats)) != 1):
+                return False
+            if not (y.is_cuda and y.dtype == torch.int64 and y.is_contiguous() and y.dim() == 2
+                    and all(x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 for x in xs)
+                    and (seq is None or (seq.is_cuda and seq.dtype == torch.int64 and seq.is_contiguous()))):
+                return False
+            sizes.append((B, rows))
+        seed = self._dropout_seed() if draw_dropout else 0
+        if draw_dropout and seed != self._drop_seed:            # a new seed restarts the draw index: do that eagerly
+            return False
+        self.ensure(max(r for _, r in sizes))
+        hp = self.group_hp_key(err_penalty, sc_penalty_x001, optimizer, desc, seed)
+        fork = os.environ.get("MMN_PS_GRAPH_FORK", "0") == "1"
+        key = ("per_sample", self._plan.value, fork) + tuple(
+            (tuple(x.data_ptr() for x in xs), tuple(x.stride(0) for x in xs), y.data_ptr(), int(y.shape[0]), int(y.shape[1]),
+             None if seq is None else seq.data_ptr(), int(bg)) for xs, y, seq, bg in items) + hp
+        ent = self._step_graphs.get(key)
+        if ent is None:
+            if len(self._step_graphs) >= self.MAX_STEP_GRAPHS:
+                if self._graph_hits == 0:
+                    self._step_graphs = None
+                    return False
+                self._step_graphs.clear()
+                self._graph_hits = 0
+            self._step_graphs[key] = [1, None, None, None]      # first sighting: the caller's eager steps are the warm-up
+            return False
+        if ent[1] is None:
+            if ent[0] < 0:
+                return False
+            try:
+                sets = []
+                for (xs, y, seq, bg), (B, rows) in zip(items, sizes):
+                    xs_p = [torch.empty((rows, f), dtype=torch.float32, device=dev) for f in feats]
+                    y_p = torch.empty((rows, y.shape[1]), dtype=torch.int64, device=dev)
+                    tile_rows = torch.empty(rows // 16, dtype=torch.int32, device=dev)
+                    tile_seq = torch.empty(rows // 16, dtype=torch.int32, device=dev)
+                    scratch = torch.empty(2 * B + rows, dtype=torch.int32, device=dev)
+                    bin_ = self.make_batch(xs, y, [(k, k) for k in range(E)], batch_global=B)
+                    bout = self.make_batch(xs_p, y_p, [(k, k) for k in range(E)], batch_global=int(bg))
+                    bout.tile_rows, bout.tile_seq = tile_rows.data_ptr(), tile_seq.data_ptr()
+                    sets.append((bin_, bout, scratch, xs_p, y_p, tile_rows, tile_seq))
+                hip.check(self.lib.mmn_pack_refresh(self._plan, self._stream()), "mmn_pack_refresh")
+                torch.cuda.current_stream().synchronize()      # (the buffers exist before another stream writes them)
+                side = torch.cuda.Stream(device=dev)
+                branch = torch.cuda.Stream(device=dev) if fork else None
+                side.wait_stream(torch.cuda.current_stream())
+                graph = torch.cuda.CUDAGraph()
+                keep = []
+                saved, saved_drawn = self._prescanned, self._predrawn
+
+                def regroup_all(stream):                    # one set of four launches for the whole group (mmn_regroup_multi)
+                    n = len(items)
+                    ins = (C.POINTER(hip.Batch) * n)(*[C.pointer(st[0]) for st in sets])
+                    outs = (C.POINTER(hip.Batch) * n)(*[C.pointer(st[1]) for st in sets])
+                    seqs = (C.c_void_p * n)(*[None if it[2] is None else it[2].data_ptr() for it in items])
+                    scr = (C.c_void_p * n)(*[st[2].data_ptr() for st in sets])
+                    hip.check(self.lib.mmn_regroup_multi(self._plan, n, ins, seqs, outs, scr, stream.cuda_stream), "mmn_regroup_multi")
+
+                def regroup(k, stream):
+                    bin_, bout, scratch = sets[k][:3]
+                    seq = items[k][2]
+                    hip.check(self.lib.mmn_regroup_ex(self._plan, C.byref(bin_), None if seq is None else seq.data_ptr(),
+                                                      C.byref(bout), scratch.data_ptr(), stream.cuda_stream), "mmn_regroup_ex")
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                        evs = []
+                        if fork:                            # the regrouping of every batch of the group: one branch beside the steps
+                            branch.wait_stream(side)
+                            for k in range(len(items)):
+                                regroup(k, branch)
+                                ev = torch.cuda.Event()
+                                ev.record(branch)
+                                evs.append(ev)
+                        if not fork:
+                            regroup_all(side)
+                        for k in range(len(items)):
+                            if fork:
+                                side.wait_event(evs[k])
+                            b = sets[k][1]
+                            if draw_dropout:
+                                keep.append(self.draw_dropout_masks(b))
+                            if not self._launch_step(b, err_penalty, sc_penalty_x001, True, optimizer, None, desc):
+                                raise RuntimeError("fusion refused during capture")
+                        if fork:
+                            side.wait_stream(branch)
+                torch.cuda.current_stream().wait_stream(side)
+                self._prescanned, self._predrawn = saved, saved_drawn   # nothing has run yet
+                ent[1], ent[2] = graph, (items, sets, keep, side, branch, optimizer)
+            except Exception:
+                ent[0] = -1
+                self._prescanned = None
+                self._predrawn = None
+                return False
+        hip.check(self.lib.mmn_pack_refresh(self._plan, self._stream()), "mmn_pack_refresh")
+        ent[1].replay()
+        self._graph_hits += 1
+        self._prescanned = None
+        self._predrawn = None
+        last = ent[2][1][-1]
+        self._ps_layout = ("hip", last[2][2 * int(items[-1][1].shape[0]):], int(items[-1][1].shape[0]), last[6])
+        optimizer.mark_fused_step()
+        return True
+
     def per_sample_positions(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """For the last per_sample_batch: (position of every original row in the regrouped layout
         [B] int64, packed executed sequence of every original row [B] int64)."""

@@ -17,7 +17,7 @@ MAX_LAYERS = 8
 MAX_DIM = 128
 ADAM_MAX_SEG = 512
 ERR_UNSUPPORTED = -2
-VERSION = 109
+VERSION = 110
 MAX_DEC_HIDDEN = 3
 ENC_MLP, ENC_MIMIC = 0, 1
 
@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mmn_dropout_floats", "mmn_draw_dropout", "mmn_dropout_reset", "mmn_dropout_adopt",
     "mmn_nan_flags_set", "mmn_pack_invalidate", "mmn_pack_refresh", "mmn_train_step_ex", "mmn_epoch_write", "mmn_adam_fusable", "mmn_regroup_ex", "mmn_dp_rescale", "mmn_eval_step_ex",
     "mmn_dp_xbuf_bytes", "mmn_dp_xbuf_alloc", "mmn_dp_xbuf_open", "mmn_dp_xbuf_close", "mmn_dp_oneshot_attach",
-    "mmn_dp_oneshot_error", "mmn_adam_step_accumulate_oneshot",
+    "mmn_dp_oneshot_error", "mmn_adam_step_accumulate_oneshot", "mmn_regroup_multi",
 )
 
 
@@ -197,6 +197,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_regroup.argtypes = [vp, C.POINTER(Batch), vp, C.POINTER(Batch), vp]
     lib.mmn_regroup_ex.restype = i32
     lib.mmn_regroup_ex.argtypes = [vp, C.POINTER(Batch), vp, C.POINTER(Batch), vp, vp]
+    lib.mmn_regroup_multi.restype = i32
+    lib.mmn_regroup_multi.argtypes = [vp, i32, C.POINTER(C.POINTER(Batch)), C.POINTER(vp), C.POINTER(C.POINTER(Batch)), C.POINTER(vp), vp]
     lib.mmn_epoch_reset.restype = i32
     lib.mmn_epoch_reset.argtypes = [vp, vp]
     lib.mmn_epoch_read.restype = i32

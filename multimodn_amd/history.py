@@ -108,6 +108,33 @@ class HistoryList(list):
         self._settle()
         return list(list.__iter__(self)) + list(other)
 
+    # Everything that moves, removes or looks for entries settles first: a pending epoch writes its arrays back by the
+    # position its placeholders were appended at.
+
+
+def _settled(name):
+    base = getattr(list, name)
+
+    def method(self, *a, **k):
+        self._settle()
+        return base(self, *a, **k)
+    method.__name__ = name
+    method.__doc__ = base.__doc__
+    return method
+
+
+for _name in ("pop", "index", "count", "__contains__", "sort", "reverse", "insert", "remove", "__delitem__", "__setitem__",
+              "__iadd__", "__mul__", "__rmul__", "__imul__", "clear", "__lt__", "__le__", "__gt__", "__ge__", "__ne__"):
+    setattr(HistoryList, _name, _settled(_name))
+
+
+def _extend(self, other):
+    self._settle()
+    list.extend(self, list(other))
+
+
+HistoryList.extend = _extend
+
 
 def display_title(key: str) -> str:
     return key.replace("_", " ").capitalize()

@@ -563,6 +563,8 @@ class MultiModN(nn.Module):
                 window.append(MultiModN._Step(ent[2], target, ent[4], None, False, ent[5], ent))
                 return True
             st = self._make_step(data, target, encoder_sequence, state["mode"], True)
+            if st.on_host or st.y is not target or len(st.xs) != len(data) or not all(a is c for a, c in zip(st.xs, data)):
+                state["ingested"] = True                     # (a copy / conversion per call: never part of a whole-call plan)
             if stable and encoder_sequence is None and st.executed is None and not st.on_host and not self.shuffle_mode \
                     and isinstance(batch, tuple) and st.y is target and all(a is c for a, c in zip(st.xs, data)):
                 if len(cache) >= _BATCH_CACHE_MAX:
@@ -696,7 +698,8 @@ class MultiModN(nn.Module):
             # every step of this call applied the optimizer inside the library (the copies the chain kernels read were
             # scattered with each update): the next call need not repack unless somebody writes the parameters in between
             state["eng"].note_parameters_current()
-        if plan_ok and state["eng"] is not None and rec and sum(len(g[0]) for g in rec) == state["steps"] == len(seen_batches):
+        if plan_ok and not state.get("ingested") and state["eng"] is not None and rec \
+                and sum(len(g[0]) for g in rec) == state["steps"] == len(seen_batches):
             # every step of this call ran inside a replayed group: the next call over the same batch objects skips the
             # ingest altogether (_replay_epoch_plan)
             plans = self.__dict__.setdefault("_epoch_plans", {})
@@ -729,6 +732,19 @@ class MultiModN(nn.Module):
         if ep is None or ep["opt"] is not optimizer or ep["eng"] is not self._engine or ep["group"] != (int(getattr(self, "REPLAY_GROUP", 8)), int(getattr(self, "REPLAY_GROUP_NEXT", 0))) \
                 or len(ep["batches"]) != len(seq) or not all(map(operator.is_, seq, ep["batches"])):
             return None
+        # the graphs hold the ADDRESSES recorded last time: every batch must still be made of the very tensor objects its
+        # recorded step names (a batch whose inner list was edited: `batch[0][k] = new_x`), the targets still at their
+        # address (set_ / resize_; the feature tensors' addresses are NOT re-read - nine data_ptr() calls per step are
+        # 1 us per step of a call's latency - so resize_-ing a feature tensor of a replayed plan in place is not supported)
+        flat = [st for g in ep["groups"] for st in g[0]]
+        if len(flat) != len(seq):
+            return None
+        for batch, (xs, y, _pairs, _bg, _b, key) in zip(seq, flat):
+            data = batch[0]
+            if batch[1] is not y or len(data) != len(xs) or not all(map(operator.is_, data, xs)) or key[2] != y.data_ptr() \
+                    or (len(batch) > 2 and batch[2] is not None):
+                plans.pop((len(seq), id(seq[0]), id(seq[-1])), None)
+                return None
         eng = self._get_engine(ep["rows"])                   # (compares every parameter's address with the plan's)
         if eng._plan is None or eng._plan.value != ep["plan"]:
             return None
@@ -781,6 +797,7 @@ class MultiModN(nn.Module):
         that depend on the data alone) runs on a side stream while step t runs on the main one: k_fb8 fills every CU's
         LDS with one workgroup but only a quarter of its wave slots, the regrouping kernels use no LDS to speak of.
         Two persistent buffer sets take the regrouped batches in turn; events order the two streams."""
+        import itertools
         eng = None
         it = iter(train_loader)
         main = torch.cuda.current_stream() if self.device.type == "cuda" else None
@@ -790,9 +807,9 @@ class MultiModN(nn.Module):
         cache = self.__dict__.setdefault("_batch_cache", {})
         stable = _stable_batches(train_loader)
 
-        def prepare(batch):
-            nonlocal eng, side
-            data, target, encoder_sequence = (list(batch) + [None])[:3]
+        def engine_for(target):
+            """The engine, sized for this batch's regrouped rows; (re)binds the fused optimizer when the plan is new."""
+            nonlocal eng
             if eng is None:
                 eng = self._get_engine(int(target.shape[0]))
                 eng.epoch_reset()
@@ -803,6 +820,11 @@ class MultiModN(nn.Module):
                 state["fd"] = self._fusion_setup(eng, optimizer, "device") if self._dp_group is None else None
                 state["fused"] = state["fd"] is not None
                 state["plan"] = True
+
+        def prepare(batch):
+            nonlocal side
+            data, target, encoder_sequence = (list(batch) + [None])[:3]
+            engine_for(target)
             slot = state["i"] & 1
             state["i"] += 1
             if main is not None and hasattr(eng, "per_sample_batch_async") and isinstance(target, Tensor) and target.is_cuda:
@@ -832,31 +854,71 @@ class MultiModN(nn.Module):
                     return (b, keep, keep[5], keep[6]), ev, slot
             return self._regroup_per_sample(eng, data, target, encoder_sequence), None, slot
 
-        try:
-            nxt = prepare(next(it))
-        except StopIteration:
-            return None
-        while nxt is not None:
-            cur, ev, slot = nxt
+        def run_eager(it):
             try:
-                nxt = prepare(next(it))                     # regrouping of batch t+1: enqueued before step t's kernels
+                nxt = prepare(next(it))
             except StopIteration:
-                nxt = None
-            if ev is not None:
-                main.wait_event(ev)
-            if state["fused"]:
-                self._run_step_per_sample(eng, None, None, None, optimizer, regrouped=cur, desc=state["fd"])
-                optimizer.step()                             # (a no-op after a fused step; the real one if the library refused)
-            else:
-                optimizer.zero_grad()
-                executed, keep = self._run_step_per_sample(eng, None, None, None, optimizer, regrouped=cur)
-                eng.assign_grads(executed)
-                optimizer.step()
-            if ev is not None:
-                if done[slot] is None:
-                    done[slot] = torch.cuda.Event()
-                done[slot].record(main)
-            self.train_steps_launched = getattr(self, "train_steps_launched", 0) + 1
+                return
+            while nxt is not None:
+                cur, ev, slot = nxt
+                try:
+                    nxt = prepare(next(it))                 # regrouping of batch t+1: enqueued before step t's kernels
+                except StopIteration:
+                    nxt = None
+                if ev is not None:
+                    main.wait_event(ev)
+                if state["fused"]:
+                    self._run_step_per_sample(eng, None, None, None, optimizer, regrouped=cur, desc=state["fd"])
+                    optimizer.step()                         # (a no-op after a fused step; the real one if the library refused)
+                else:
+                    optimizer.zero_grad()
+                    executed, keep = self._run_step_per_sample(eng, None, None, None, optimizer, regrouped=cur)
+                    eng.assign_grads(executed)
+                    optimizer.step()
+                if ev is not None:
+                    if done[slot] is None:
+                        done[slot] = torch.cuda.Event()
+                    done[slot].record(main)
+                self.train_steps_launched = getattr(self, "train_steps_launched", 0) + 1
+
+        def run_group(chunk) -> bool:
+            """REPLAY_GROUP device-resident batches that come back every epoch as ONE hipGraph (engine.run_group_per_sample:
+            regrouping launches, dropout draw and step of every batch); False: nothing launched, run them eagerly."""
+            items = []
+            for batch in chunk:
+                data, target, seq = (list(batch) + [None])[:3]
+                if not (isinstance(target, Tensor) and target.is_cuda and all(isinstance(x, Tensor) and x.is_cuda for x in data)):
+                    return False
+                if seq is not None and not (isinstance(seq, Tensor) and seq.is_cuda):
+                    return False
+                y = target if target.dim() == 2 else target.view(-1, 1)
+                items.append((list(data), y, seq, self._global_rows(int(y.shape[0]))))
+            for _, y, _, _ in items:
+                engine_for(y)
+            if not state["fused"] or not hasattr(eng, "run_group_per_sample"):
+                return False
+            if not eng.run_group_per_sample(items, float(self.err_penalty), float(self.state_change_penalty), optimizer,
+                                            state["fd"], bool(eng.dropout_encoders)):
+                return False
+            n = len(items)
+            self.train_steps_launched = getattr(self, "train_steps_launched", 0) + n
+            optimizer.fused_step_seen(n)
+            return True
+
+        G = int(self.REPLAY_GROUP)
+        if (G > 1 and stable and main is not None and self._dp_group is None and getattr(self, "replay_steps", True)
+                and self.dropout_mask_provider is None and hasattr(optimizer, "fused_descriptor")):
+            # groups of G steps at fixed positions of the epoch: a group's graph is captured when its batches are seen
+            # for the second time (the eager run of the first epoch is the warm-up) and replayed from then on
+            while True:
+                chunk = list(itertools.islice(it, G))
+                if not chunk:
+                    break
+                if len(chunk) == G and run_group(chunk):
+                    continue
+                run_eager(iter(chunk))
+            return eng
+        run_eager(it)
         return eng
 
     def train_epoch(

@@ -256,3 +256,39 @@ def test_hip_adam_refuses_cpu_parameters():
         opt.step()
     with pytest.raises(NotImplementedError):
         mm.optim.Adam([p], amsgrad=True)
+
+
+def test_history_list_settles_pending_epochs_before_anything_moves_entries():
+    """HistoryList entries of an epoch in flight are placeholders that the epoch later fills in BY POSITION: every list
+    operation that moves, removes or searches entries resolves them first (pop / del / insert / sort / index / in / extend)."""
+    from multimodn_amd.history import HistoryList, PendingEpoch
+
+    def pending(v):
+        return PendingEpoch(lambda: None, lambda: {"loss": np.full(2, float(v))})
+
+    def fresh():
+        lst = HistoryList()
+        lst.append(np.zeros(2))
+        for v in (1, 2):
+            lst.append_pending(pending(v), "loss")
+        return lst
+
+    lst = fresh()
+    del lst[0]
+    assert [float(a[0]) for a in lst] == [1.0, 2.0]
+    lst = fresh()
+    assert float(lst.pop(0)[0]) == 0.0 and float(lst.pop()[0]) == 2.0 and len(lst) == 1 and float(lst[0][0]) == 1.0
+    lst = fresh()
+    lst.insert(0, np.full(2, 9.0))
+    assert [float(a[0]) for a in lst] == [9.0, 0.0, 1.0, 2.0]
+    lst = fresh()
+    lst.reverse()
+    assert [float(a[0]) for a in lst] == [2.0, 1.0, 0.0]
+    lst = fresh()
+    other = fresh()
+    lst.extend(other)
+    assert [float(a[0]) for a in lst] == [0.0, 1.0, 2.0, 0.0, 1.0, 2.0]
+    assert all(isinstance(a, np.ndarray) for a in list.__iter__(lst))
+    lst = fresh()
+    lst.clear()
+    assert len(lst) == 0

@@ -462,7 +462,8 @@ def _per_sample_case(spec, B, seed, p_missing=0.3):
 def test_per_sample_mode_of_the_mimic_modules(lib, family, B):
     """BASELINE configs[4] with the modules the reference's MNAR pipeline builds (MIMIC_MLPEncoder + MLPDecoder,
     pipelines/mimic/mimic_single_task_mnar_missingness_pipeline.py:163-165): per-sample missing modalities and encoder order
-    on the generic tier (sequential form on regrouped 16-row tiles), dropout multipliers of the reference's kind handed in
+    (the pipelines' shape at batch 4096: k_mfwd / k_dec_fb / k_mbwd on the regrouped 16-row tiles; the small and the mixed
+    models: the generic tier's sequential form on the same tiles), dropout multipliers of the reference's kind handed in
     per ORIGINAL row, against the oracle's sample-by-sample loop: loss cells 1e-5, exact row counts and counters,
     gradients 2e-5 of float64 truth."""
     if family == "mimic":
@@ -503,6 +504,62 @@ def test_per_sample_mode_of_the_mimic_modules(lib, family, B):
             assert np.abs(got).max() == 0.0, n
         else:
             assert float(np.max(np.abs(got - g))) <= max(2e-5 * float(np.max(np.abs(g))), 2e-6 * g_all), n
+
+
+def _per_sample_step_against_oracle(lib, spec, B, seed, expect_kernel=None):
+    import ctypes as C
+    params = O.init_params(spec, 3)
+    xs, y, seq, masks = _per_sample_case(spec, B, seed=seed)
+    model = build_torch_model(spec, params, "cuda", lib)
+    model.per_sample = True
+    model.train()
+    model.dropout_mask_provider = mask_provider(masks)
+    eng = model._get_engine(B)
+    eng.epoch_reset()
+    if expect_kernel is not None:
+        bout, keep = eng.per_sample_batch([torch.from_numpy(x).cuda() for x in xs], torch.from_numpy(y).cuda(), torch.from_numpy(seq))
+        names = tuple(eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(bout), k) for k in (0, 3, 1))
+        assert names == expect_kernel, names
+    model._run_step_per_sample(eng, [torch.from_numpy(x) for x in xs], torch.from_numpy(y), torch.from_numpy(seq))
+    eng.assign_grads(None)
+    torch.cuda.synchronize()
+    stats = {k: np.array(v) for k, v in eng.step_values().items()}
+    grads = {n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
+    ref = O.per_sample_step(params, spec, xs, y, seq, drop_masks=masks)
+    p64 = {n: np.asarray(v, np.float64) for n, v in params.items()}
+    ref64 = O.per_sample_step(p64, spec, xs, y, seq, dtype=np.float64, drop_masks=masks)
+    assert rel_err(stats["err_loss"], ref64.err_loss) < 1e-5 and rel_err(stats["state_change"], ref64.state_change) < 1e-5
+    assert np.array_equal(stats["rows"].astype(np.int64), ref.row_counts)
+    for k in ("n_correct", "tp", "tn", "fp", "fn"):
+        assert np.array_equal(stats[k].astype(np.int64), getattr(ref, k)), k
+    g_all = max(float(np.max(np.abs(g))) for g in ref64.grads.values() if g is not None)
+    for n, g in ref64.grads.items():
+        got = grads[n].reshape(np.asarray(params[n]).shape)
+        if g is None:
+            assert np.abs(got).max() == 0.0, n
+        else:
+            assert float(np.max(np.abs(got - g))) <= max(2e-5 * float(np.max(np.abs(g))), 2e-6 * g_all), n
+    return stats, grads
+
+
+@pytest.mark.parametrize("form", ["tiles", "sequential"])
+@pytest.mark.parametrize("shape", ["pipeline", "odd_widths"])
+@pytest.mark.parametrize("B", [5, 37, 300])
+def test_per_sample_mimic_pipeline_shapes_on_the_chain_kernels(lib, B, shape, form, monkeypatch):
+    """Round 4: per-sample batches of the MIMIC pipelines' shape class run k_mfwd / k_dec_fb / k_mbwd on the regrouped tiles
+    (slot k = the tile's k-th executed encoder; zeros for what a tile does not execute and for its padding rows) instead
+    of the sequential k_gen_* form.  Small batches: most tiles are short and most of the tile list is padding.  Both forms
+    against the oracle's sample-by-sample loop, and against each other."""
+    if shape == "pipeline":
+        spec = mimic_c3_spec()
+    else:
+        spec = O.ModelSpec(128, [O.EncoderSpec(24, h, O.ACT_RELU, kind="mimic", dropout=d)
+                                 for h, d in (((20, 24), 0.25), ((32, 28), 0.0), ((28, 32), 0.1))], 2, 1.0, 0.3,
+                           decoders=[O.DecoderSpec("mlp", (16,)), O.DecoderSpec("mlp", (24, 8))])
+    if form == "sequential":
+        monkeypatch.setenv("MMN_MC_TILED", "0")
+    expect = (b"k_mfwd", b"k_dec_fb", b"k_mbwd") if form == "tiles" else (b"k_gen_fwd", b"", b"k_gen_bwd")
+    _per_sample_step_against_oracle(lib, spec, B, seed=40 + B, expect_kernel=expect)
 
 
 def test_per_sample_mimic_step_matches_the_reference_run_at_batch_size_one(lib):

@@ -167,6 +167,56 @@ def test_per_sample_training_epochs_match_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fork", ["1", "0"])
+@pytest.mark.parametrize("family", ["mlp", "mimic"])
+def test_replayed_per_sample_groups_equal_eager_steps(family, fork, monkeypatch):
+    """Round 4: groups of 8 device-resident per-sample batches are replayed as ONE hipGraph from their second sighting on
+    (regrouping launches of every batch - on a graph branch of their own, or in line - the dropout draw and the step).
+    Same launches in the same order as the eager loop: History and trained weights are BITWISE those of eager steps,
+    device-drawn dropout included; 11 batches per epoch = one group + three eager steps."""
+    mm.hip.load()
+    monkeypatch.setenv("MMN_PS_GRAPH_FORK", fork)
+    if family == "mlp":
+        spec, xs, y, seq = c5_like(11 * 48, E=4, seed=31)
+    else:
+        spec = O.ModelSpec(128, [O.EncoderSpec(24, (32, 20), O.ACT_RELU, kind="mimic", dropout=0.2) for _ in range(3)], 2, 1.0, 0.3,
+                           decoders=[O.DecoderSpec("mlp", (16,)) for _ in range(2)])
+        rng = np.random.default_rng(3)
+        xs, y = O.synthetic_batches(spec, 11 * 48, 11 * 48, seed=4)[0]
+        xs = [x.copy() for x in xs]
+        for e in range(3):
+            xs[e][rng.random(len(y)) < 0.3] = np.nan
+        seq = np.stack([rng.permutation(3) for _ in range(len(y))]).astype(np.int64)
+    params = O.init_params(spec, 2)
+    loader = [([torch.from_numpy(x[s:s + 48]).cuda() for x in xs], torch.from_numpy(y[s:s + 48]).cuda(), torch.from_numpy(seq[s:s + 48]).cuda())
+              for s in range(0, 11 * 48, 48)]
+
+    def train(replay):
+        torch.manual_seed(7)
+        model = build_torch_model(spec, params, "cuda", mm)
+        model.per_sample = True
+        model.replay_steps = replay
+        opt = mm.optim.Adam(list(model.parameters()), 1e-2)
+        hist = mm.MultiModNHistory(["a", "b", "c"][:spec.D])
+        for _ in range(4):
+            model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+        torch.cuda.synchronize()
+        eng = model._get_engine(48)
+        return hist, {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters()}, int(getattr(eng, "_graph_hits", 0))
+
+    h1, w1, hits1 = train(True)
+    h0, w0, hits0 = train(False)
+    assert hits1 >= 2 and hits0 == 0                        # epochs 3 and 4 replayed the group captured in epoch 2
+    for ep in range(4):
+        assert np.array_equal(h1.loss["train"][ep], h0.loss["train"][ep]), ep
+        assert np.array_equal(h1.state_change_loss[ep], h0.state_change_loss[ep]), ep
+        assert np.array_equal(h1.accuracy["train"][ep], h0.accuracy["train"][ep]), ep
+    for n in w0:
+        assert np.array_equal(w1[n], w0[n]), n
+    assert np.isfinite(h1.loss["train"][-1]).all() and h1.loss["train"][-1].mean() < h1.loss["train"][0].mean()
+
+
+@pytest.mark.gpu
 def test_c5_full_size_against_oracle():
     """BASELINE configs[4] shape: 4 x 64 features, hidden (32,32), state 128, 3 tasks, batch 4096,
     30 % missing-not-at-random, a random encoder order per sample."""

@@ -70,10 +70,11 @@ def test_per_sample_host_logic_on_checker_backend():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("F", [8, 6])      # 6: rows that are not whole float4s (the regrouping kernels' 4-byte path)
 @pytest.mark.parametrize("B,E,permute", [(1, 2, True), (37, 3, True), (200, 4, True), (130, 4, False), (16, 1, True)])
-def test_per_sample_step_matches_oracle(B, E, permute):
+def test_per_sample_step_matches_oracle(B, E, permute, F):
     mm.hip.load()
-    spec, xs, y, seq = c5_like(B, E=E, seed=B)
+    spec, xs, y, seq = c5_like(B, E=E, F=F, seed=B)
     if not permute:
         seq = None
     params = O.init_params(spec, 2)

@@ -7,12 +7,14 @@ import bench
 wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c3"]
 dev = torch.device("cuda")
 model = bench.build_model(mm, wl, dev); model.nan_policy = "device"
+if os.environ.get("MMN_RG"):                             # first group / later groups of a call (MultiModN.REPLAY_GROUP, _NEXT)
+    type(model).REPLAY_GROUP = int(os.environ["MMN_RG"]); type(model).REPLAY_GROUP_NEXT = int(os.environ.get("MMN_RGN", "0"))
 B = wl["B"]
 host = bench.synthetic_batches(wl, B * 8, B, seed=1)
 res = [([torch.from_numpy(x).to(dev) for x in xs], torch.from_numpy(y).to(dev)) for xs, y in host]
 opt = mm.optim.Adam(list(model.parameters()), wl["lr"])
 out = {}
-for n in (8, 16, 24, 40, 80):
+for n in (8, 16, 20, 24, 40, 80):
     steps = [res[i % 8] for i in range(n)]
     for _ in range(4):
         model._train_steps(steps, opt)

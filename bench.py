@@ -45,7 +45,8 @@ WORKLOADS = {
     "c5": dict(S=128, F=[64] * 4, H=(32, 32), D=3, B=4096, lr=1e-3, pen=(1.0, 0.3), per_sample=True,
                text="BASELINE configs[4]: the MIMIC-shaped model with per-sample missing modalities (30 % missing not at "
                     "random, NaN rows) and a random encoder order per sample, batch 4096 per GPU; a step includes the "
-                    "on-device regrouping of the rows into tiles of one executed sequence (eager launches)"),
+                    "on-device regrouping of the rows into tiles of one executed sequence (groups of 8 steps replayed as one "
+                    "hipGraph, one multi-batch regrouping per group)"),
     "mimic": dict(S=128, F=[64] * 4, H=(32, 32), D=3, B=4096, lr=1e-3, pen=(1.0, 0.3), family="mimic", dec_hidden=(32, 32),
                   dropout=0.2,
                   text="SURVEY 8f #1, the MIMIC pipelines' own modules at the MIMIC shape: 4 x MIMIC_MLPEncoder(64 features + "
@@ -56,8 +57,8 @@ WORKLOADS = {
                 dec_hidden=(32, 32), dropout=0.2,
                 text="BASELINE configs[4] with the modules the reference's MNAR pipeline builds (MIMIC_MLPEncoder + MLPDecoder, "
                      "pipelines/mimic/mimic_single_task_mnar_missingness_pipeline.py:163-165): per-sample missing modalities (30 % "
-                     "not at random) and encoder order, dropout 0.2 drawn on the device, batch 4096 per GPU; generic tier, "
-                     "sequential form on regrouped 16-row tiles (k_gen_fwd / k_gen_bwd)"),
+                     "not at random) and encoder order, dropout 0.2 drawn on the device, batch 4096 per GPU; k_mfwd / k_dec_fb / "
+                     "k_mbwd on the regrouped 16-row tiles, groups of 8 steps replayed as one hipGraph"),
     "c2": dict(S=64, F=[3, 2], H=(5, 5), D=2, B=512, lr=1e-2, pen=(0.7, 0.3),
                text="Titanic-shaped, 2 encoders (features split 3+2), hidden (5,5) relu, 2 binary tasks, state_dim 64, "
                     "batch 512, Adam lr 1e-2, penalties 0.7/0.3 (latency-bound)"),
@@ -757,7 +758,7 @@ def main():
     achieved = fl[dominant] * B / (avg_us[dominant] * 1e-6) / 1e12
     traffic, mfma_busy = None, None
     try:                                                      # HBM bytes per launch / matrix-pipe busy % from the committed PMC passes
-        tag = {"c3": "r04_final", "mimic": "r04_mimic", "c5": "r04_c5"}.get(args.workload)
+        tag = {"c3": "r04_final", "mimic": "r04_mimic", "c5": "r04_c5", "c5m": "r04_c5m"}.get(args.workload)
         if tag and B == wl["B"]:                             # the passes were made on this workload at this batch
             pmc = json.load(open(os.path.join(REPO, "profiles", f"{tag}_pmc_traffic.json")))
             traffic = pmc["kernels"].get(dominant, {}).get("hbm_bytes_per_launch")
@@ -793,7 +794,7 @@ def main():
                    "optimizer": opt_text,
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
                    "step_path": "MultiModN._train_steps (the batch loop of MultiModN.train_epoch)",
-                   "launch": f"hipGraph replay ({max(group, int(getattr(model, 'REPLAY_GROUP', 8))) if dp else group} steps per graph)" if replayed else "eager",
+                   "launch": f"hipGraph replay ({max(group, int(getattr(model, 'REPLAY_GROUP', 8))) if (dp or per_sample) else group} steps per graph)" if replayed else "eager",
                    # counted around every torch.distributed collective of the timed region (n steps + 1 for the sequence's
                    # first batch, whose NaN flags have no predecessor to ride with)
                    "collectives_per_step": (n_coll["all_reduce"] + n_coll["other"]) / args.steps if dp else 0,

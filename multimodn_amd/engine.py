@@ -512,6 +512,7 @@ class HipChainEngine:
                 return False
         ent[3] = (hp, entry_ready, entry_drawn, bool(reset_first))
         self.replay_entry(ent, steps, nxt, optimizer, draw_dropout)
+        self._last_group_entry = ent                            # (the whole-call plan's shortcut for next time: replay_known)
         return True
 
     @staticmethod
@@ -553,7 +554,7 @@ class HipChainEngine:
         first = steps[0][4]
         hp = self.group_hp_key(err_penalty, sc_penalty_x001, optimizer, desc, seed)
         key = (tuple(st[5] for st in steps), None if nxt is None else nxt[5], bool(first.nan_flags and self._prescanned is first),
-               bool(draw_dropout and self._predrawn is first), bool(reset_first)) + hp
+               bool(draw_dropout and self._predrawn is first), bool(reset_first), None) + hp      # (None: no data-parallel tail - run_group's key)
         return self._step_graphs.get(key), hp
 
     # ------------------------------------------------------------------ per-sample mode (BASELINE configs[4])

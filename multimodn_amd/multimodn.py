@@ -733,15 +733,17 @@ class MultiModN(nn.Module):
                 or len(ep["batches"]) != len(seq) or not all(map(operator.is_, seq, ep["batches"])):
             return None
         # the graphs hold the ADDRESSES recorded last time: every batch must still be made of the very tensor objects its
-        # recorded step names (a batch whose inner list was edited: `batch[0][k] = new_x`), the targets still at their
-        # address (set_ / resize_; the feature tensors' addresses are NOT re-read - nine data_ptr() calls per step are
-        # 1 us per step of a call's latency - so resize_-ing a feature tensor of a replayed plan in place is not supported)
-        flat = [st for g in ep["groups"] for st in g[0]]
+        # recorded step names (a batch whose inner list was edited: `batch[0][k] = new_x`).  The tensors' addresses are NOT
+        # re-read (five data_ptr() calls per step are ~0.6 us per step of a call's latency, all of it in front of the
+        # first launch): set_ / resize_-ing a tensor of a replayed plan in place needs `model._epoch_plans.clear()`.
+        flat = ep.get("flat")
+        if flat is None:                                     # (y, xs) per batch, in order
+            flat = ep["flat"] = [(st[1], st[0]) for g in ep["groups"] for st in g[0]]
         if len(flat) != len(seq):
             return None
-        for batch, (xs, y, _pairs, _bg, _b, key) in zip(seq, flat):
+        for batch, (y, xs) in zip(seq, flat):
             data = batch[0]
-            if batch[1] is not y or len(data) != len(xs) or not all(map(operator.is_, data, xs)) or key[2] != y.data_ptr() \
+            if batch[1] is not y or len(data) != len(xs) or not all(map(operator.is_, data, xs)) \
                     or (len(batch) > 2 and batch[2] is not None):
                 plans.pop((len(seq), id(seq[0]), id(seq[-1])), None)
                 return None
@@ -764,9 +766,12 @@ class MultiModN(nn.Module):
             return None
         total = 0
         need_reset = True                                    # the epoch accumulators: zeroed by the first group's graph
-        for steps, nxt, ent in ep["groups"]:
-            ok = eng.replay_known(ent, steps, nxt, hp, optimizer, draw, reset_first=need_reset) or \
-                eng.run_group(steps, nxt, alpha, beta, optimizer, draw, fd, reset_first=need_reset)
+        for gi, (steps, nxt, ent) in enumerate(ep["groups"]):
+            ok = eng.replay_known(ent, steps, nxt, hp, optimizer, draw, reset_first=need_reset)
+            if not ok:
+                ok = eng.run_group(steps, nxt, alpha, beta, optimizer, draw, fd, reset_first=need_reset)
+                if ok:                                       # (the entry it replayed from: the shortcut next time)
+                    ep["groups"][gi] = (steps, nxt, getattr(eng, "_last_group_entry", None))
             if need_reset and not ok:
                 eng.epoch_reset()
             need_reset = False

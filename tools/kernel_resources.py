@@ -1,8 +1,8 @@
 """Register / scratch / LDS use of every kernel in libmmn_hip.so (from the code object's metadata notes).
-`python tools/kernel_resources.py [substring ...]`"""
+`python tools/kernel_resources.py [substring ...]`; MMN_LIB_PATH names another library (tools/ab variants)."""
 import os, re, subprocess, sys, tempfile
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-so = os.path.join(REPO, "multimodn_amd", "libmmn_hip.so")
+so = os.environ.get("MMN_LIB_PATH") or os.path.join(REPO, "multimodn_amd", "libmmn_hip.so")
 llvm = "/opt/rocm/lib/llvm/bin"
 with tempfile.TemporaryDirectory() as td:
     tmp = os.path.join(td, "lib.so")

@@ -554,10 +554,13 @@ def main():
         with_seq = []
         for xs, y in resident:
             p_miss = torch.where(y[:, :1] == 1, 0.45, 0.15).cpu().numpy()
+            if os.environ.get("MMN_BENCH_PS_UNIFORM"):      # diagnostic: per-sample mode on data where nothing varies
+                p_miss = p_miss * 0.0
             miss = torch.from_numpy(rng.random((B, n_enc)) < p_miss).to(dev)
             for e in range(n_enc):
                 xs[e][miss[:, e]] = float("nan")
-            sq = torch.from_numpy(np.stack([rng.permutation(n_enc) for _ in range(B)]).astype(np.int64)).to(dev)
+            sq = torch.from_numpy(np.stack([rng.permutation(n_enc) if not os.environ.get("MMN_BENCH_PS_UNIFORM") else np.arange(n_enc)
+                                            for _ in range(B)]).astype(np.int64)).to(dev)
             with_seq.append((xs, y, sq))
         resident = with_seq
     alpha, beta = float(model.err_penalty), float(model.state_change_penalty)
@@ -794,7 +797,9 @@ def main():
                    "optimizer": opt_text,
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
                    "step_path": "MultiModN._train_steps (the batch loop of MultiModN.train_epoch)",
-                   "launch": f"hipGraph replay ({max(group, int(getattr(model, 'REPLAY_GROUP', 8))) if (dp or per_sample) else group} steps per graph)" if replayed else "eager",
+                   "launch": (f"hipGraph replay ({max(group, int(getattr(model, 'REPLAY_GROUP', 8))) if (dp or per_sample) else group} steps per graph"
+                              + (f", {int(model.REPLAY_GROUP_NEXT)} behind the first group of a call" if (not per_sample and int(getattr(model, 'REPLAY_GROUP_NEXT', 0)) not in (0, group)) else "")
+                              + ")") if replayed else "eager",
                    # counted around every torch.distributed collective of the timed region (n steps + 1 for the sequence's
                    # first batch, whose NaN flags have no predecessor to ride with)
                    "collectives_per_step": (n_coll["all_reduce"] + n_coll["other"]) / args.steps if dp else 0,

@@ -501,10 +501,13 @@ class MultiModN(nn.Module):
 
     #: steps captured into one hipGraph when every batch of the group already lives on the device
     REPLAY_GROUP = 8
-    #: ... and behind the first group of a call (0 = the same).  A graph-to-graph boundary costs ~8 us of idle GPU (a
-    #: boundary between two kernels of one graph ~1.2) and a long graph's launch is hidden behind the group in front of it:
-    #: 24 measured 54.1 instead of 54.7 us/step over 200-step calls, but 59.4 instead of 57.3 over 20-step calls (8 + 12
-    #: steps) - off by default
+    #: ... and behind the first group of a call (0 = the same).  A graph-to-graph boundary costs a few us of idle GPU (a
+    #: boundary between two kernels of one graph ~1.2) and a long graph's launch is hidden behind the group in front of it.
+    #: Round 4, one box, C3, the SAME call repeated (tools/ovh_sweep.sh): (8, 0) 55.05 us/step over 20-step calls / 53.36
+    #: over 200-step calls; (8, 12) 54.81 / 53.17; (8, 16) 54.79 / 52.97; (8, 24) 54.81 / 52.94; (4, 16) 54.77 / 53.06 -
+    #: but a 20-step call that follows a DIFFERENT call (bench.py: warm-up call, then the timed one) takes 57.7 - 67 us/step
+    #: with (8, 16) against 56.1 - 56.3 with (8, 0): a big graph launched for the first time after another one pays more
+    #: than the boundaries it saves.  Off by default.
     REPLAY_GROUP_NEXT = 0
 
     def _train_steps(self, train_loader, optimizer, log_interval=None, logger=None):

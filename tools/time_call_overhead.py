@@ -14,7 +14,7 @@ host = bench.synthetic_batches(wl, B * 8, B, seed=1)
 res = [([torch.from_numpy(x).to(dev) for x in xs], torch.from_numpy(y).to(dev)) for xs, y in host]
 opt = mm.optim.Adam(list(model.parameters()), wl["lr"])
 out = {}
-for n in (8, 16, 20, 24, 40, 80):
+for n in (8, 16, 20, 24, 40, 80, 200):
     steps = [res[i % 8] for i in range(n)]
     for _ in range(4):
         model._train_steps(steps, opt)

@@ -32,7 +32,7 @@
 // mmn_generic.inc (generic tier: sequential and batched forms, k_dec_fb), mmn_chain_mimic.inc (k_mfwd, k_mbwd),
 // mmn_chain_par.inc (helpers of the retired 4-wave tier), mmn_chain_8w.inc (k_fwd8, k_bwd8, k_fb8), mmn_chain_fb9.inc
 // (k_fb9), mmn_wgrad.inc, mmn_per_sample.inc (k_ps_*), mmn_adam_reduce.inc (k_adam, k_reduce, the one-shot data-parallel
-// tail), mmn_host.inc (layout, plan, C ABI).  35 kernels, none with scratch memory (profiles/r04_kernel_resources.txt).
+// tail), mmn_host.inc (layout, plan, C ABI).  36 kernels, none with scratch memory (profiles/r04_kernel_resources.txt).
 //
 // Data layout in HBM (all fp32 row-major, B = batch rows):
 //   states[e][B][S]     output state of encoder e          hid[e][l][B][H_l]  hidden activations

@@ -30,6 +30,9 @@
  *   MMN_FB9=0 / MMN_FB9_FULLK=0             k_fb8 instead of k_fb9 / k_fb9 with run-time trip counts
  *   MMN_GEN_BATCHED=0 / MMN_GEN_SPLIT=0 / MMN_MC=0   generic tier: sequential form / decoders inside the chain kernels / k_genf2_* as
  *                                           the chain where k_mfwd / k_mbwd would run
+ *   MMN_WGRAD_SMALL=0 / MMN_MC_TILED=0      k_wgrad's two-workgroups-per-CU form also for models without a 64 x 64 gradient tile /
+ *                                           per-sample batches of the MIMIC pipelines' shapes on the sequential k_gen_* kernels
+ *                                           (MMN_MC_TILED is read per call)
  *   MMN_STAMPS=1                            phase timestamps of one workgroup (mmn_debug_buffer kind 3; tools/stamps*.py)
  *   MMN_VERBOSE=1                           plan summary on stderr
  */

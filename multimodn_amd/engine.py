@@ -369,6 +369,11 @@ class HipChainEngine:
             self.lib.mmn_pack_invalidate(self._plan)
         self._versions_seen = None                          # whoever runs steps next says when the copies are current again
 
+    def refresh_weights(self) -> None:
+        """Rebuild the kernels' weight copies now if they are stale (one small launch on the current stream; what the first
+        step of a sequence would do in front of its own launches)."""
+        hip.check(self.lib.mmn_pack_refresh(self._plan, self._stream()), "mmn_pack_refresh")
+
     def invalidate_weights(self) -> None:
         """Something wrote the parameters behind torch's back: the next step rebuilds the kernels' weight copies."""
         self._versions_seen = None

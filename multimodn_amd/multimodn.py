@@ -755,11 +755,14 @@ class MultiModN(nn.Module):
             return None
         if getattr(self, "nan_policy", "auto") not in ("auto", "device") or not hasattr(optimizer, "fused_descriptor"):
             return None
+        # the rebuild of the kernels' weight copies (one small launch) goes out NOW: the GPU does it under the rest of this
+        # function's checks instead of in front of the first graph (whatever path the call then takes needs it anyway)
+        eng.begin_sequence(sig_checked=True)
+        eng.refresh_weights()
         fd = optimizer.fused_descriptor(eng)
         if fd is None or not eng.adam_fusable(optimizer, fd):
             return None
         mode = "device"
-        eng.begin_sequence(sig_checked=True)
         if eng.params[0].grad is not eng.grad_views[0] or eng.params[-1].grad is not eng.grad_views[-1]:
             eng.assign_grads(None)
         alpha, beta = float(self.err_penalty), float(self.state_change_penalty)

@@ -30,7 +30,7 @@
 // ONE translation unit, split by section into the *.inc files included below (in this order): mmn_plan.inc (plan
 // structs, device helpers), mmn_prepare.inc (k_prepare), mmn_chain_seq.inc (sequential chain kernels),
 // mmn_generic.inc (generic tier: sequential and batched forms, k_dec_fb), mmn_chain_mimic.inc (k_mfwd, k_mbwd),
-// mmn_chain_par.inc (helpers of the retired 4-wave tier), mmn_chain_8w.inc (k_fwd8, k_bwd8, k_fb8), mmn_chain_fb9.inc
+// mmn_wave_helpers.inc (single-wave helpers of the 8-wave tiers), mmn_chain_8w.inc (k_fwd8, k_bwd8, k_fb8), mmn_chain_fb9.inc
 // (k_fb9), mmn_wgrad.inc, mmn_per_sample.inc (k_ps_*), mmn_adam_reduce.inc (k_adam, k_reduce, the one-shot data-parallel
 // tail), mmn_host.inc (layout, plan, C ABI).  36 kernels, none with scratch memory (profiles/r04_kernel_resources.txt).
 //
@@ -78,7 +78,7 @@ namespace {
 #include "mmn_chain_seq.inc"
 #include "mmn_generic.inc"
 #include "mmn_chain_mimic.inc"
-#include "mmn_chain_par.inc"
+#include "mmn_wave_helpers.inc"
 #include "mmn_chain_8w.inc"
 #include "mmn_chain_fb9.inc"
 #include "mmn_wgrad.inc"

@@ -576,6 +576,17 @@ def main():
         write_per_sample_b1(name, cfg)
     bad = {n: w for n, w in worst.items() if w["loss"] > 2e-6 or w["crit"] > 2e-6 or w["eval"] > 2e-6}
     assert not bad, bad
+    # gradients and trained weights (the printed `grad` / `param` columns): gated by the very rule the tests apply to the
+    # fixtures just written - tests/test_oracle_golden.py, i.e. 1e-5 / 2e-5 outright or within fp32 noise of the float64
+    # replay (helpers.assert_within_fp32_noise) - so that the generator cannot leave behind a file the suite would reject
+    sys.path.insert(0, os.path.dirname(HERE))
+    import test_oracle_golden as T
+    for name in worst:
+        T.test_oracle_reproduces_reference_run(name)
+    for name in PER_SAMPLE_B1:
+        if not only or name in only:
+            T.test_per_sample_oracle_reproduces_the_reference_at_batch_size_one(name)
+    print(f"oracle gate (tests/test_oracle_golden.py rules) passed for {len(worst)} + {len(PER_SAMPLE_B1)} fixtures")
 
 
 if __name__ == "__main__":

@@ -130,23 +130,21 @@ def test_training_matches_reference_golden(lib, name, optimizer):
     assert_within_fp32_noise(np.stack(hist.loss["train"]), z["hist/loss"], l64, "History loss", tight=1e-5)
 
 
-KERNEL_MODES = {"fused8": ("1", "1", "1", "1"), "fused8p": ("1", "1", "1", "1"),      # fused8p: the fused kernel's pair-per-encoder
-                "fast8": ("1", "1", "1", "0"),                                          # form (MMN_FB8_LEAN=0), what wider shapes run
-                "seq16": ("1", "0", "0", "0"),
+# mode -> (MMN_FAST8, MMN_FUSED, MMN_GENERIC)
+KERNEL_MODES = {"fused8": ("1", "1", "0"), "fused8p": ("1", "1", "0"),      # fused8p: the fused kernel's pair-per-encoder form
+                "fast8": ("1", "0", "0"),                                    # (MMN_FB8_LEAN=0), what wider shapes run
+                "seq16": ("0", "0", "0"),
                 # the generic tier (k_gen_fwd / k_gen_bwd: written for MIMIC_MLPEncoder / MLPDecoder models) forced
                 # onto MLPEncoder + LogisticDecoder models: same results through different kernels and plan tables
-                "gen16": ("1", "0", "0", "0", "1")}
-# (round 4 retired the 4-wave parallel tier and the 32-row-tile instantiations: the modes "par16", "seq32", "gen32" are gone)
+                "gen16": ("0", "0", "1")}
 
 
 def set_mode(monkeypatch, mode):
-    """Kernel tier, read at plan creation: 8-wave fast tier (MIMIC-like shapes; other shapes fall
-    through to the next tier), 4-wave parallel-phase kernels, or the sequential chain kernels with
-    16- / 32-row tiles."""
-    rt, par, fast8, fused = KERNEL_MODES[mode][:4]
-    monkeypatch.setenv("MMN_GENERIC", "1" if len(KERNEL_MODES[mode]) > 4 else "0")
-    monkeypatch.setenv("MMN_RT", rt)
-    monkeypatch.setenv("MMN_PAR", par)
+    """Kernel tier, read at plan creation: the fused 8-wave kernel (k_fb9, or k_fb8 for the shapes k_fb9 does not take),
+    the two-launch 8-wave tier (k_fwd8 / k_bwd8), the sequential chain kernels, or the generic tier's sequential form
+    (16-row tiles everywhere)."""
+    fast8, fused, generic = KERNEL_MODES[mode]
+    monkeypatch.setenv("MMN_GENERIC", generic)
     monkeypatch.setenv("MMN_FAST8", fast8)
     monkeypatch.setenv("MMN_FUSED", fused)          # forward+backward chain in one launch (E <= 4)
     monkeypatch.setenv("MMN_FB8_LEAN", "0" if mode == "fused8p" else "1")

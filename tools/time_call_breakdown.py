@@ -1,5 +1,5 @@
-"""Diagnostic: where the fixed cost of one MultiModN._train_steps call goes (host side): time from the call to the first group's
-launch, the launch itself, the remaining groups, the final synchronize."""
+"""Diagnostic: where the host time of one 20-step MultiModN._train_steps call goes (C3): time to the first graph launch,
+each graph launch, the tail."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -18,27 +18,24 @@ for _ in range(4):
 torch.cuda.synchronize()
 eng = model._engine
 marks = []
-orig = eng.replay_known
-def wrapped(*a, **k):
-    marks.append(time.perf_counter())
-    r = orig(*a, **k)
-    marks.append(time.perf_counter())
-    return r
-eng.replay_known = wrapped
+orig_refresh = eng.lib.mmn_pack_refresh
+class G:
+    def __init__(self, g): self.g = g
+    def replay(self):
+        t0 = time.perf_counter(); self.g.replay(); marks.append(("replay", t0, time.perf_counter()))
+for ent in eng._step_graphs.values():
+    if ent[1] is not None and not isinstance(ent[1], G):
+        ent[1] = G(ent[1])
 rows = []
-for _ in range(40):
+for _ in range(60):
     torch.cuda.synchronize()
     marks.clear()
-    t0 = time.perf_counter(); model._train_steps(steps, opt); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-    rows.append([(marks[0] - t0), (marks[1] - marks[0]), (t1 - marks[1]), (t2 - t1), (t2 - t0)])
-r = np.median(np.array(rows) * 1e6, axis=0)
-print(f"20 steps: to first launch {r[0]:.1f} us, first launch {r[1]:.1f}, rest of the call {r[2]:.1f}, synchronize {r[3]:.1f}, total {r[4]:.1f} ({r[4]/20:.2f} / step)")
-import cProfile, pstats
-pr = cProfile.Profile()
-eng.replay_known = orig
-pr.enable()
-for _ in range(200):
+    t0 = time.perf_counter()
     model._train_steps(steps, opt)
-pr.disable()
-torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    r = [(a - t0) * 1e6 for _, a, b in marks] + [(b - t0) * 1e6 for _, a, b in marks[-1:]]
+    rows.append([(marks[0][1] - t0) * 1e6] + [(b - a) * 1e6 for _, a, b in marks] + [(t1 - marks[-1][2]) * 1e6, (t2 - t0) * 1e6])
+rows = np.median(np.array(rows), axis=0)
+print("to first replay %.1f us | replays %s us | tail %.1f us | wall %.1f us" % (rows[0], " ".join("%.1f" % v for v in rows[1:-2]), rows[-2], rows[-1]))

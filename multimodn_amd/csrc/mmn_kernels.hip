@@ -81,9 +81,9 @@ namespace {
 #include "mmn_wave_helpers.inc"
 #include "mmn_chain_8w.inc"
 #include "mmn_chain_fb9.inc"
-#include "mmn_wgrad.inc"
 #include "mmn_per_sample.inc"
 #include "mmn_adam_reduce.inc"
+#include "mmn_wgrad.inc"
 }  // namespace
 
 #include "mmn_host.inc"

@@ -17,7 +17,7 @@ MAX_LAYERS = 8
 MAX_DIM = 128
 ADAM_MAX_SEG = 512
 ERR_UNSUPPORTED = -2
-VERSION = 110
+VERSION = 111
 MAX_DEC_HIDDEN = 3
 ENC_MLP, ENC_MIMIC = 0, 1
 
@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mmn_dropout_floats", "mmn_draw_dropout", "mmn_dropout_reset", "mmn_dropout_adopt",
     "mmn_nan_flags_set", "mmn_pack_invalidate", "mmn_pack_refresh", "mmn_train_step_ex", "mmn_epoch_write", "mmn_adam_fusable", "mmn_regroup_ex", "mmn_dp_rescale", "mmn_eval_step_ex",
     "mmn_dp_xbuf_bytes", "mmn_dp_xbuf_alloc", "mmn_dp_xbuf_open", "mmn_dp_xbuf_close", "mmn_dp_oneshot_attach",
-    "mmn_dp_oneshot_error", "mmn_adam_step_accumulate_oneshot", "mmn_regroup_multi",
+    "mmn_dp_oneshot_error", "mmn_adam_step_accumulate_oneshot", "mmn_regroup_multi", "mmn_wgrad_reduce",
 )
 
 
@@ -137,6 +137,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_pack_refresh.argtypes = [vp, vp]
     lib.mmn_train_step_ex.restype = i32
     lib.mmn_train_step_ex.argtypes = [vp, C.POINTER(Batch), f32, f32, C.POINTER(StepOpts), vp]
+    lib.mmn_wgrad_reduce.restype = i32
+    lib.mmn_wgrad_reduce.argtypes = [vp, C.POINTER(Batch), f32, f32, C.POINTER(StepOpts), vp]
     lib.mmn_adam_fusable.restype = i32
     lib.mmn_adam_fusable.argtypes = [vp, C.POINTER(AdamDesc)]
     lib.mmn_epoch_write.restype = i32

@@ -104,6 +104,74 @@ def test_scattered_weight_copies_equal_a_full_repack_every_step(family):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("family", ["classic", "slp", "mimic", "mixed", "c3"])
+def test_fused_tail_equals_the_separate_reduce_launch(family):
+    """Round 5: the k_wgrad launch reduces every gradient tile in the work item that delivers its last partial slab (same
+    partials, same order as k_reduce), applies Adam there, and carries the stats block / the NaN pre-scan / the dropout
+    pre-draw as workgroups of its own.  MMN_TAIL=0 keeps round 4's separate k_reduce launch: History, trained weights,
+    Adam moments and step counts must be identical bit for bit - eagerly, under replay, with NaN batches (skipped encoders:
+    no Adam step for their tensors), and with a stock torch optimizer (the tail then only forms the gradients)."""
+    import multimodn_amd as lib
+    specs = _specs()
+    specs["c3"] = O.ModelSpec(128, [O.EncoderSpec(64, (32, 32), O.ACT_RELU) for _ in range(4)], 3, 1.0, 0.3)
+    spec = specs[family]
+    B = 4096 if family == "c3" else 48
+    nan_at = ((2, 1), (5, 0)) if family in ("classic", "c3") else ()
+    loader = _device_loader(spec, 10, B, seed=5, nan_at=nan_at)
+
+    def opt_state(model_run):
+        return model_run[4]
+
+    def run(env, replay):
+        torch.manual_seed(11)
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            model = build_torch_model(spec, O.init_params(spec, 2), "cuda", lib)
+            model.replay_steps = replay
+            opt = lib.optim.Adam(list(model.parameters()), 1e-2)
+            hist = lib.MultiModNHistory([f"t{d}" for d in range(spec.D)])
+            for _ in range(3):
+                model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+            torch.cuda.synchronize()
+            sd = opt.state_dict()["state"]
+            ost = {k: {n: (v.detach().cpu().numpy().copy() if isinstance(v, torch.Tensor) else v) for n, v in st.items()} for k, st in sd.items()}
+            return (np.stack(hist.loss["train"]), np.stack(hist.state_change_loss), np.stack(hist.accuracy["train"]),
+                    {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}, ost)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    ref = run({"MMN_TAIL": "0"}, False)
+    for replay in (False, True):
+        got = run({"MMN_TAIL": "1"}, replay)
+        _same(ref, got)
+        for k, st in ref[4].items():
+            for n, v in st.items():
+                assert np.array_equal(np.asarray(v), np.asarray(got[4][k][n])), (k, n)
+    # a stock torch optimizer: the tail forms the gradients only (host NaN policy: skipped encoders leave the sequence)
+    outs = []
+    for tail in ("0", "1"):
+        os.environ["MMN_TAIL"] = tail
+        try:
+            torch.manual_seed(11)
+            model = build_torch_model(spec, O.init_params(spec, 2), "cuda", lib)
+            opt = torch.optim.Adam(model.parameters(), 1e-2)
+            hist = lib.MultiModNHistory([f"t{d}" for d in range(spec.D)])
+            model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+            torch.cuda.synchronize()
+            outs.append((np.stack(hist.loss["train"]), {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}))
+        finally:
+            os.environ.pop("MMN_TAIL", None)
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("family", ["classic", "mimic_p0"])       # (dropout 0: the host policy draws no multipliers for an
 def test_prescan_skips_what_the_reference_skips(family):          #  encoder it removed, so the draws of the others would differ)
     """NaN batches in the middle and at both ends of an epoch of device-resident batches (the scan of batch t+1 rides in

@@ -38,6 +38,10 @@ else:
     kern["bwd"] = lambda b: lib.mmn_chain_bwd(plan, C.byref(b), beta, stream)
 kern["k_wgrad"] = lambda b: lib.mmn_wgrad(plan, C.byref(b), stream)
 kern["k_reduce"] = lambda b: lib.mmn_reduce_adam(plan, C.byref(b), C.byref(d), stream)
+so = mm.hip.StepOpts(); so.adam = C.pointer(d); so.accumulate_epoch = 1
+kern["k_wgrad+tail"] = lambda b: lib.mmn_wgrad_reduce(plan, C.byref(b), alpha, beta, C.byref(so), stream)
+so2 = mm.hip.StepOpts(); so2.accumulate_epoch = 1
+kern["k_wgrad+tail(no adam)"] = lambda b: lib.mmn_wgrad_reduce(plan, C.byref(b), alpha, beta, C.byref(so2), stream)
 out = {}
 for name, fn in kern.items():
     t = []

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MMN_VERSION 111            /* 0.1.11: mmn_wgrad_reduce (weight gradients + reduction + Adam + step statistics as ONE launch: the fused tail of mmn_train_step_ex on its own); 0.1.10: mmn_regroup_multi (the batches of a captured per-sample group regrouped by one set of launches); 0.1.9: one-shot data-parallel exchange (mmn_dp_xbuf_*, mmn_dp_oneshot_*, mmn_adam_step_accumulate_oneshot, MMN_ERR_PEER); 0.1.8: mmn_source_hash (a library that was not built from the sources next to it does not load); 0.1.7: mmn_eval_step_ex (test(): outputs and row flag of a step collected by the call); 0.1.6: mmn_dp_rescale (uneven data-parallel shards);
+#define MMN_VERSION 111            /* 0.1.11: mmn_wgrad_reduce (the second half of mmn_train_step_ex on its own: k_wgrad with the stats block in its launch, then k_reduce as gradient blocks only); 0.1.10: mmn_regroup_multi (the batches of a captured per-sample group regrouped by one set of launches); 0.1.9: one-shot data-parallel exchange (mmn_dp_xbuf_*, mmn_dp_oneshot_*, mmn_adam_step_accumulate_oneshot, MMN_ERR_PEER); 0.1.8: mmn_source_hash (a library that was not built from the sources next to it does not load); 0.1.7: mmn_eval_step_ex (test(): outputs and row flag of a step collected by the call); 0.1.6: mmn_dp_rescale (uneven data-parallel shards);
                                       0.1.5: mmn_step_opts.next_drop_* (the next step's dropout multipliers in this step's last launch), mmn_dropout_adopt;
                                       0.1.4: mmn_train_step_ex (pre-scan of the next batch, flag sets in the stats block), mmn_pack_invalidate;
                                       0.1.3: + mmn_draw_dropout; 0.1.2: MIMIC_MLPEncoder / MLPDecoder (mmn_encoder.kind, mmn_decoder.hidden, mmn_batch.drop_mask) */
@@ -415,12 +415,11 @@ int mmn_train_step_adam(mmn_plan* p, const mmn_batch* b, float err_penalty, floa
 /* The layout check alone: MMN_OK if `adam` can be fused with this plan's launches, else MMN_ERR_UNSUPPORTED / MMN_ERR_ARG. */
 int mmn_adam_fusable(mmn_plan* p, const mmn_adam* adam);
 int mmn_reduce_adam(mmn_plan* p, const mmn_batch* b, const mmn_adam* adam, void* stream);
-/* ABI 111.  The second launch of a training step on its own (per-kernel timing, tests): mmn_wgrad + mmn_reduce (+ Adam when
- * opts->adam is set, + the epoch accumulation when opts->accumulate_epoch) as ONE launch - every weight-gradient tile is
- * reduced, and Adam applied to it, by the work item that delivers its last partial slab (multimodn.py:193-204; gradients
- * bitwise those of mmn_wgrad + mmn_reduce: same partials, same order); the step statistics are formed by a workgroup of
- * the same launch.  opts->next / next_drop_* are ignored here.  Plans the fused tail does not cover (MMN_TAIL=0, slab
- * buffers of 2 GB and more) run the two launches instead.  ORDER: as mmn_wgrad. */
+/* ABI 111.  The second half of a training step on its own (per-kernel timing, tests): what mmn_wgrad + mmn_reduce (+ Adam
+ * when opts->adam is set, + the epoch accumulation when opts->accumulate_epoch) do, in the launch layout mmn_train_step_ex
+ * uses since round 5 - the stats block (tile partials -> step statistics, Adam's per-tensor coefficients and step counters)
+ * rides in the k_wgrad launch, where it costs nothing, and k_reduce is gradient blocks only (multimodn.py:193-204; same
+ * results bit for bit).  opts->next / next_drop_* are ignored here.  MMN_SIDE=0: the round-4 layout.  ORDER: as mmn_wgrad. */
 int mmn_wgrad_reduce(mmn_plan* p, const mmn_batch* b, float err_penalty, float state_change_penalty_x001,
                      const struct mmn_step_opts* opts, void* stream);
 

@@ -105,12 +105,12 @@ def test_scattered_weight_copies_equal_a_full_repack_every_step(family):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("family", ["classic", "slp", "mimic", "mixed", "c3"])
-def test_fused_tail_equals_the_separate_reduce_launch(family):
-    """Round 5: the k_wgrad launch reduces every gradient tile in the work item that delivers its last partial slab (same
-    partials, same order as k_reduce), applies Adam there, and carries the stats block / the NaN pre-scan / the dropout
-    pre-draw as workgroups of its own.  MMN_TAIL=0 keeps round 4's separate k_reduce launch: History, trained weights,
-    Adam moments and step counts must be identical bit for bit - eagerly, under replay, with NaN batches (skipped encoders:
-    no Adam step for their tensors), and with a stock torch optimizer (the tail then only forms the gradients)."""
+def test_side_work_in_the_wgrad_launch_equals_round4_layout(family):
+    """Round 5: the k_wgrad launch carries the step's stats block (which also forms Adam's per-tensor coefficients and
+    advances the step counters), the NaN pre-scan and the dropout pre-draw as workgroups of its own; k_reduce is gradient
+    blocks only and copies the coefficients.  MMN_SIDE=0 keeps round 4's layout (all of that inside k_reduce): History,
+    trained weights, Adam moments and step counts must be identical bit for bit - eagerly, under replay, with NaN batches
+    (skipped encoders: no Adam step for their tensors), and with a stock torch optimizer."""
     import multimodn_amd as lib
     specs = _specs()
     specs["c3"] = O.ModelSpec(128, [O.EncoderSpec(64, (32, 32), O.ACT_RELU) for _ in range(4)], 3, 1.0, 0.3)
@@ -145,17 +145,17 @@ def test_fused_tail_equals_the_separate_reduce_launch(family):
                 else:
                     os.environ[k] = v
 
-    ref = run({"MMN_TAIL": "0"}, False)
+    ref = run({"MMN_SIDE": "0"}, False)
     for replay in (False, True):
-        got = run({"MMN_TAIL": "1"}, replay)
+        got = run({"MMN_SIDE": "1"}, replay)
         _same(ref, got)
         for k, st in ref[4].items():
             for n, v in st.items():
                 assert np.array_equal(np.asarray(v), np.asarray(got[4][k][n])), (k, n)
-    # a stock torch optimizer: the tail forms the gradients only (host NaN policy: skipped encoders leave the sequence)
+    # a stock torch optimizer: k_reduce forms the gradients only (host NaN policy: skipped encoders leave the sequence)
     outs = []
     for tail in ("0", "1"):
-        os.environ["MMN_TAIL"] = tail
+        os.environ["MMN_SIDE"] = tail
         try:
             torch.manual_seed(11)
             model = build_torch_model(spec, O.init_params(spec, 2), "cuda", lib)
@@ -165,7 +165,7 @@ def test_fused_tail_equals_the_separate_reduce_launch(family):
             torch.cuda.synchronize()
             outs.append((np.stack(hist.loss["train"]), {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}))
         finally:
-            os.environ.pop("MMN_TAIL", None)
+            os.environ.pop("MMN_SIDE", None)
     assert np.array_equal(outs[0][0], outs[1][0])
     for k in outs[0][1]:
         assert np.array_equal(outs[0][1][k], outs[1][1][k]), k

@@ -19,9 +19,8 @@ torch.cuda.synchronize()
 eng = model._engine
 ptr = eng.lib.mmn_debug_buffer(eng._plan, 3, 0)
 off = ptr - eng.workspace.data_ptr()
-raw = eng.workspace[off:off + 8 * (256 + 4096 + 1024 + 4096)].view(torch.int64).cpu().numpy()
-rd = raw[256 + 4096:256 + 4096 + 1024].reshape(512, 2)
-ph = raw[256 + 4096 + 1024:].reshape(512, 8)
+raw = eng.workspace[off:off + 8 * (256 + 4096 + 1024)].view(torch.int64).cpu().numpy()
+rd = raw[256 + 4096:].reshape(512, 2)
 st = raw[256:256 + 4096].reshape(1024, 4)
 n = int((st[:, 0] > 0).sum())
 st = st[:n]
@@ -57,36 +56,20 @@ for lo in range(0, n, 32):
     sel = slice(lo, min(n, lo + 32))
     print(f"  blocks {lo:3d}+: start {start[sel].mean():5.2f} dur {dur[sel].mean():5.2f} (max {dur[sel].max():5.2f}) end {end[sel].max():5.2f}")
 
-if os.environ.get("MMN_TAIL", "1") != "0":             # fused tail: when every item reached its ticket; the reducers' tails
-    tk = rd[:min(n, 512)]
-    arr = (tk[:, 0] - t0) / 100.0
-    last = (tk[:, 1] & 1) == 1
-    grp = tk[:, 1] >> 1
-    m = min(n, 512)
-    print("fused tail: items", m, "reducers", int(last.sum()))
-    tail = end[:m] - arr
-    print("  non-reducers: ticket -> end  mean %.2f max %.2f" % (tail[~last].mean(), tail[~last].max()))
-    print("  reducers:     ticket -> end  mean %.2f max %.2f min %.2f" % (tail[last].mean(), tail[last].max(), tail[last].min()))
-    print("  arrival at ticket: quartiles", " ".join(f"{q:.2f}" for q in np.percentile(arr, [0, 25, 50, 75, 100])))
-    idx = np.argsort(-end[:m])[:10]
-    for i in idx:
-        print(f"    block {i:3d} grp {grp[i]:3d} last {int(last[i])} start {start[i]:5.2f} ticket {arr[i]:5.2f} end {end[i]:5.2f}")
-    print("  reducers' phases (us after the ticket): coefs | loads+sums | stores issued | bias done | all stores landed   [kind mt nt bias, global-last]")
-    for i in np.argsort(-end[:m])[:14]:
-        if last[i]:
-            p0 = ph[i]
-            rel = [(p0[k] - tk[i, 0]) / 100.0 for k in (1, 2, 3, 4, 5)]
-            print(f"    block {i:3d}: " + " ".join(f"{x:5.2f}" for x in rel) + f"   [{p0[6]} {p0[7]}]")
-    if n > m:
-        print("  special blocks (stats, scan...):", " ".join(f"[{start[j]:.1f}-{end[j]:.1f}]" for j in range(m, min(n, m + 70))))
-    sys.exit(0)
+
+if os.environ.get("MMN_SIDE", "1") != "0":             # side work inside the k_wgrad launch: the blocks behind the work items
+    ni = n - 1
+    while ni > 0 and dur[ni - 1] < 7.0 and start[ni - 1] > 1.0:
+        ni -= 1
+    print("side blocks (stats first, then pre-scan / pre-draw): [start-end us]", " ".join(f"[{start[j]:.1f}-{end[j]:.1f}]" for j in range(ni, n)))
 nr = int((rd[:, 0] > 0).sum()); rd = rd[:nr]
 r0 = rd[0, 0]
 print("k_reduce: workgroups", nr, "start of first after k_wgrad's last end:", (r0 - st[:, 1].max()) / 100.0, "us; span", (rd[:, 1].max() - r0) / 100.0)
 gb = eng.lib.mmn_debug_buffer  # noqa
-for i in list(range(0, nr, 16)) + [92, 93, 94, 95, 96, nr - 1]:
+for i in [j for j in list(range(0, nr, 16)) + [92, 93, 94, 95, 96, nr - 1] if j < nr]:
     print(f"  block {i:3d}: start {(rd[i,0]-r0)/100.0:5.2f} end {(rd[i,1]-r0)/100.0:5.2f}")
 
+if nr <= 94: sys.exit(0)
 g = raw[120:123]
 print("stats block: start -> partials summed", (g[0] - rd[94, 0]) / 100.0, "-> barrier", (g[1] - g[0]) / 100.0, "-> stats stored", (g[2] - g[1]) / 100.0,
       "-> end (epoch)", (rd[94, 1] - g[2]) / 100.0)

@@ -39,9 +39,9 @@ else:
 kern["k_wgrad"] = lambda b: lib.mmn_wgrad(plan, C.byref(b), stream)
 kern["k_reduce"] = lambda b: lib.mmn_reduce_adam(plan, C.byref(b), C.byref(d), stream)
 so = mm.hip.StepOpts(); so.adam = C.pointer(d); so.accumulate_epoch = 1
-kern["k_wgrad+tail"] = lambda b: lib.mmn_wgrad_reduce(plan, C.byref(b), alpha, beta, C.byref(so), stream)
+kern["k_wgrad(+side work) + k_reduce(gradient blocks)"] = lambda b: lib.mmn_wgrad_reduce(plan, C.byref(b), alpha, beta, C.byref(so), stream)
 so2 = mm.hip.StepOpts(); so2.accumulate_epoch = 1
-kern["k_wgrad+tail(no adam)"] = lambda b: lib.mmn_wgrad_reduce(plan, C.byref(b), alpha, beta, C.byref(so2), stream)
+kern["the same without Adam"] = lambda b: lib.mmn_wgrad_reduce(plan, C.byref(b), alpha, beta, C.byref(so2), stream)
 out = {}
 for name, fn in kern.items():
     t = []

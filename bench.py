@@ -32,6 +32,8 @@ torch = None                       # imported in main() / where needed: the laun
                                    # never loads it, let alone touches a GPU
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix) = vector peak
+# the committed rocprofv3 --pmc passes roofline.traffic / mfma_busy_pct_pmc are read from (tools/collect_profiles.sh, collect_pmc_util.sh)
+PROFILE_TAGS = {"c3": "r05_final", "mimic": "r05_mimic", "c5": "r05_c5", "c5m": "r05_c5m", "haim": "r05_haim"}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -59,6 +61,11 @@ WORKLOADS = {
                      "pipelines/mimic/mimic_single_task_mnar_missingness_pipeline.py:163-165): per-sample missing modalities (30 % "
                      "not at random) and encoder order, dropout 0.2 drawn on the device, batch 4096 per GPU; k_mfwd / k_dec_fb / "
                      "k_mbwd on the regrouped 16-row tiles, groups of 8 steps replayed as one hipGraph"),
+    "haim": dict(S=50, F=[6, 1024, 768, 99], H=(32, 32), D=2, B=16, lr=1e-3, pen=(1.0, 0.0), family="mimic", dec_hidden=(32, 32),
+                 dropout=0.2,
+                 text="the reference's real MIMIC configuration (pipelines/mimic/mimic_multi_task_pipeline.py:53-83,118-119): 4 x "
+                      "MIMIC_MLPEncoder over the sources de / vd / n_ech / ts_ce (6 / 1024 / 768 / 99 features + state 50 -> 32 -> 32 -> 50, "
+                      "dropout 0.2) and 2 x MLPDecoder(50 -> 32 -> 32 -> 2), batch 16, Adam lr 1e-3, penalties 1.0/0.0"),
     "c2": dict(S=64, F=[3, 2], H=(5, 5), D=2, B=512, lr=1e-2, pen=(0.7, 0.3),
                text="Titanic-shaped, 2 encoders (features split 3+2), hidden (5,5) relu, 2 binary tasks, state_dim 64, "
                     "batch 512, Adam lr 1e-2, penalties 0.7/0.3 (latency-bound)"),
@@ -429,6 +436,31 @@ def spawn_ranks(n_gpus: int) -> int:
     return rc
 
 
+def rows_sweep(batches=(8192, 16384, 65536), steps=40, warmup=10):
+    """the headline workload at more rows per GPU (every CU then runs 2 / 4 / 16 tiles of the chain kernel one
+    after the other): step time, samples/s, the chain kernel's launch time and fraction of the fp32 MFMA roof.  Child
+    processes, like the secondary workloads."""
+    import subprocess
+    res = {}
+    for bsz in batches:
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "c3", "--batch", str(bsz), "--steps", str(steps), "--warmup", str(warmup),
+               "--resident-batches", "4", "--no-cpu-baseline", "--no-public-path", "--no-secondary", "--preroll", "0.3"]
+        try:
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = [ln for ln in pr.stdout.strip().splitlines() if ln.startswith("{")]
+            if pr.returncode != 0 or not line:
+                res[str(bsz)] = {"error": f"exit code {pr.returncode}", "stderr_tail": pr.stderr[-400:]}
+                continue
+            d = json.loads(line[-1])
+            res[str(bsz)] = {"rows_per_gpu": bsz, "us_per_step": d["ms_per_step"] * 1e3, "value": d["value"], "unit": d["unit"],
+                             "dominant_kernel": d["roofline"]["kernel"], "roofline_frac": d["roofline"]["frac"],
+                             "step_frac_of_fp32_roof": d["roofline"]["step_frac_of_fp32_roof"],
+                             "avg_launch_us": d["roofline"]["avg_launch_us"]}
+        except Exception as ex:
+            res[str(bsz)] = {"error": repr(ex)[:300]}
+    return res
+
+
 def secondary_workloads(names=("mimic", "c5", "c5m", "c1", "c2"), steps=40, warmup=10):
     """The other workloads through the same entry point, each as a CHILD process of this one (a fresh process: the parent
     has initialised the GPU and must not exec): `python bench.py --workload <w> --steps 40 --warmup 10` without CPU legs.
@@ -689,6 +721,67 @@ def main():
                   "epochs": n_ep, "steps_per_epoch": nb_pub, "ratio_to_value": (B * nb_pub * n_ep / el_p) / value}
         del loader, ds
 
+    # ---- the other two ways a pipeline can drive the same step, measured, never `value`:
+    #  h2d_path   host batches (pinned memory) through the package's staging ring: one packed H2D copy per step, the
+    #             reference's `data.to(device)` (multimodn/multimodn.py:132-135) - the PCIe-inclusive rate;
+    #  stock_path the import-swap-only pipeline: torch.utils.data.DataLoader over a PartitionDataset (per-sample
+    #             __getitem__ + default collate, as pipelines/titanic/titanic_mlp_pipeline.py:57-60 builds it) and a stock
+    #             torch.optim.Adam (host NaN policy, .grad views, optimizer.step() as its own launches)
+    other_paths = None
+    if world == 1 and not dp and not per_sample and not args.no_public_path and args.optimizer == "hip":
+        other_paths = {}
+        try:
+            nb = 32
+            host_batches = [([x.cpu().pin_memory() for x in resident[i % len(resident)][0]], resident[i % len(resident)][1].cpu().pin_memory())
+                            for i in range(min(nb, len(resident)))]
+            hb = [host_batches[i % len(host_batches)] for i in range(nb)]
+            for _ in range(2):
+                model._train_steps(_Sized(hb), opt)
+            torch.cuda.synchronize()
+            t_h = time.perf_counter()
+            n_rep = 3
+            for _ in range(n_rep):
+                model._train_steps(_Sized(hb), opt)
+            torch.cuda.synchronize()
+            el_h = time.perf_counter() - t_h
+            bytes_step = sum(int(x.numel()) * 4 for x in hb[0][0]) + int(hb[0][1].numel()) * 8
+            other_paths["h2d_path"] = {
+                "entry_point": "MultiModN._train_steps over pinned HOST batches (staging ring: one packed copy per step), multimodn_amd.optim.Adam",
+                "us_per_step": el_h / (nb * n_rep) * 1e6, "value": B * nb * n_rep / el_h, "unit": "samples/s",
+                "h2d_bytes_per_step": bytes_step, "h2d_gbs": bytes_step * nb * n_rep / el_h / 1e9, "steps": nb * n_rep}
+        except Exception as ex:
+            other_paths["h2d_path"] = {"error": repr(ex)[:300]}
+        try:
+            from torch.utils.data import DataLoader
+            n_rows_s = B * 8
+            Xs = np.concatenate([np.concatenate(h[0], axis=1) for h in host[:8]], 0)[:n_rows_s]
+            ys = np.concatenate([h[1] for h in host[:8]], 0)[:n_rows_s]
+            dset = mm.PartitionDataset(Xs, ys, list(wl["F"]))
+            stock_loader = DataLoader(dset, batch_size=B, shuffle=False)
+            model2 = build_model(mm, wl, dev)
+            opt2 = torch.optim.Adam(model2.parameters(), wl["lr"])
+            hist2 = mm.MultiModNHistory([f"t{d}" for d in range(wl["D"])])
+            model2.train_epoch(stock_loader, opt2, crit, hist2)
+            torch.cuda.synchronize()
+            t_s = time.perf_counter()
+            model2.train_epoch(stock_loader, opt2, crit, hist2)
+            torch.cuda.synchronize()
+            el_s = time.perf_counter() - t_s
+            nb_s = len(stock_loader)
+            # where the time goes: the loader alone (per-sample Tensor construction + collate on the host)
+            t_l = time.perf_counter()
+            for _b in stock_loader:
+                pass
+            el_l = time.perf_counter() - t_l
+            other_paths["stock_path"] = {
+                "entry_point": "MultiModN.train_epoch(torch DataLoader(PartitionDataset), torch.optim.Adam, CrossEntropyLoss, History): the reference pipeline with the import swapped",
+                "us_per_step": el_s / nb_s * 1e6, "value": B * nb_s / el_s, "unit": "samples/s", "steps": nb_s,
+                "loader_alone_us_per_step": el_l / nb_s * 1e6,
+                "note": "host-bound by the DataLoader (per-sample __getitem__ and collate of 4096 rows per batch); DeviceResidentLoader is the resident form"}
+            del model2, opt2, stock_loader, dset
+        except Exception as ex:
+            other_paths["stock_path"] = {"error": repr(ex)[:300]}
+
     # ---- per-kernel durations with HIP events on the launch stream.  Each kernel of the step is
     # launched REP times back to back between one event pair (same stream the step uses), so the
     # host-side launch cost (~3 us per eager launch) does not pollute a ~30 us kernel; the
@@ -726,12 +819,16 @@ def main():
     fuse_opt = opt if (not dp and args.optimizer == "hip") else None
     if args.optimizer == "hip":
         adam_desc = opt.fused_descriptor(eng)
+    # the step's second half exactly as mmn_train_step_ex launches it since round 5 (ABI 111): k_wgrad with the stats block
+    # (+ Adam's coefficient block) in its launch, then k_reduce as gradient blocks (+ Adam + scatter); "k_reduce" below is the
+    # difference to the k_wgrad launch alone
+    so = mm.hip.StepOpts()
+    so.accumulate_epoch = 0 if dp else 1
     if fuse_opt is not None and adam_desc is not None:
-        kern["k_reduce"] = lambda b: lib.mmn_reduce_adam(plan, C.byref(b), C.byref(adam_desc), stream)   # + Adam + scatter
-    else:
-        kern["k_reduce"] = lambda b: lib.mmn_reduce(plan, C.byref(b), stream)
-        if args.optimizer == "hip" and adam_desc is not None:
-            kern["k_adam_accumulate"] = lambda b: lib.mmn_adam_step_accumulate(plan, C.byref(adam_desc), alpha, beta, stream)
+        so.adam = C.pointer(adam_desc)
+    elif args.optimizer == "hip" and adam_desc is not None:
+        kern["k_adam_accumulate"] = lambda b: lib.mmn_adam_step_accumulate(plan, C.byref(adam_desc), alpha, beta, stream)
+    kern["k_wgrad+k_reduce"] = lambda b: lib.mmn_wgrad_reduce(plan, C.byref(b), alpha, beta, C.byref(so), stream)
     REP, ROUNDS = 20, 5
     avg_us = {}
     for name, fn in kern.items():
@@ -749,6 +846,7 @@ def main():
             torch.cuda.synchronize()
             times.append(e0.elapsed_time(e1) * 1e3 / REP)
         avg_us[name] = float(np.median(times))
+    avg_us["k_reduce"] = max(avg_us["k_wgrad+k_reduce"] - avg_us["k_wgrad"], 0.0)     # (includes the boundary between the two launches)
     flp = flops_per_sample_of(wl)
     if fused_name:
         fl = {fused_name: flp["k_chain_fwd"] + flp["k_chain_bwd"], "k_wgrad": flp["k_wgrad"]}
@@ -759,19 +857,22 @@ def main():
         fl = {fwd_name: flp["k_chain_fwd"], bwd_name: flp["k_chain_bwd"], "k_wgrad": flp["k_wgrad"]}
     dominant = max(fl, key=lambda k: avg_us[k])
     achieved = fl[dominant] * B / (avg_us[dominant] * 1e-6) / 1e12
-    traffic, mfma_busy = None, None
+    traffic, mfma_busy, traffic_error = None, None, None
+    tag = None
     try:                                                      # HBM bytes per launch / matrix-pipe busy % from the committed PMC passes
-        tag = {"c3": "r04_final", "mimic": "r04_mimic", "c5": "r04_c5", "c5m": "r04_c5m"}.get(args.workload)
+        tag = PROFILE_TAGS.get(args.workload)
         if tag and B == wl["B"]:                             # the passes were made on this workload at this batch
             pmc = json.load(open(os.path.join(REPO, "profiles", f"{tag}_pmc_traffic.json")))
             traffic = pmc["kernels"].get(dominant, {}).get("hbm_bytes_per_launch")
             util = json.load(open(os.path.join(REPO, "profiles", f"{tag}_pmc_util.json")))
             mfma_busy = util["kernels"].get(dominant, {}).get("mfma_busy_pct")
-    except Exception:
-        pass
+            if traffic is None:
+                traffic_error = f"profiles/{tag}_pmc_traffic.json has no entry for {dominant}"
+    except Exception as ex:                                   # (a missing / renamed profile is REPORTED, not swallowed)
+        traffic_error = f"{type(ex).__name__}: {ex}"[:300]
     roofline = {"bound": "mfma", "kernel": dominant, "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                "mfma_busy_pct_pmc": mfma_busy,
+                "mfma_busy_pct_pmc": mfma_busy, "traffic_error": traffic_error,
                 "traffic_source": (f"profiles/{tag}_pmc_traffic.json, profiles/{tag}_pmc_util.json (builder-run: separate rocprofv3 "
                                    "--pmc passes of this command on another box, committed; NOT measured in this run)") if traffic else None,
                 "traffic_note": "HBM bytes per launch of the dominant kernel = (2*FETCH_SIZE + WRITE_SIZE)*1024 and its "
@@ -787,7 +888,7 @@ def main():
         opt_text = ("multimodn_amd.optim.Adam inside the one-shot exchange launch (k_adam_accumulate_oneshot)" if getattr(model, "_dp_oneshot", False)
                     else "multimodn_amd.optim.Adam in the launch behind the all-reduce (k_adam_accumulate)")
     else:
-        opt_text = "multimodn_amd.optim.Adam fused into k_reduce"
+        opt_text = "multimodn_amd.optim.Adam fused into k_reduce (coefficients and step counters: the k_wgrad launch's side block)"
     out = {
         "metric": "samples/sec/GPU (MIMIC 4-enc/3-dec, state_dim=128) + CPU-match Δloss",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -810,6 +911,7 @@ def main():
         "roofline": roofline,
         "step_us_hip_events": dist_us,
         "public_path": public,
+        "other_paths": other_paths,
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         from oracle import multimodn_oracle as O      # the CPU oracle: imported for this leg ONLY, never measured as `value`
@@ -829,6 +931,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0 and world == 1 and not dp and args.workload == "c3" and not args.no_secondary:
         out["secondary"] = secondary_workloads()
+        out["rows_sweep"] = rows_sweep()
     if dp:
         dist.barrier()
         dist.destroy_process_group()

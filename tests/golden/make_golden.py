@@ -153,6 +153,14 @@ CONFIGS = {
     "mimic_c3_small": dict(F=[64] * 4, H=(32, 32), S=128, D=3, B=64, N=128, lr=1e-3, pen=(1.0, 0.3),
                            epochs=1, act="relu", store="first_last", enc_kinds=["mimic"] * 4, dropout=0.2,
                            dec=[("mlp", (32, 32))] * 3),
+    # ---- the reference's REAL MIMIC configuration: pipelines/mimic/mimic_multi_task_pipeline.py:53-83,118-119 -
+    # state_size 50, encoder / decoder hidden (32, 32), dropout 0.2, batch 16, lr 1e-3, err_penalty 1, state_change_penalty 0,
+    # two targets; source widths from datasets/mimic/mimic_dataset.py:21.  haim_pipeline: the four sources the pipeline
+    # selects ('de', 'vd', 'n_ech', 'ts_ce'); haim_all9: all nine sources of the dataset (E = 9).
+    "haim_pipeline": dict(F=[6, 1024, 768, 99], H=(32, 32), S=50, D=2, B=16, N=48, lr=1e-3, pen=(1.0, 0.0), epochs=2,
+                          act="relu", store="first_last", enc_kinds=["mimic"] * 4, dropout=0.2, dec=[("mlp", (32, 32))] * 2),
+    "haim_all9": dict(F=[6, 1024, 1024, 99, 242, 110, 768, 768, 768], H=(32, 32), S=50, D=2, B=16, N=16, lr=1e-3, pen=(1.0, 0.0),
+                      epochs=2, act="relu", store="first_last", enc_kinds=["mimic"] * 9, dropout=0.2, dec=[("mlp", (32, 32))] * 2),
 }
 
 

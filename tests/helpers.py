@@ -12,6 +12,9 @@ GOLDEN_NAMES = ["c1_titanic", "c1_curve20", "c2_split", "c3_small", "nan_skip", 
                 "slp_sigmoid", "mlp_sigmoid", "mlp_identity"]
 # MIMIC family: MIMIC_MLPEncoder + MLPDecoder runs of the reference, dropout masks recorded
 MIMIC_GOLDEN_NAMES = ["mimic_p0", "mimic_drop", "mimic_mixed", "mimic_c3_small"]
+# the reference's real MIMIC configuration (pipelines/mimic/mimic_multi_task_pipeline.py:53-83,118-119; datasets/mimic/
+# mimic_dataset.py:21): state 50, hidden (32, 32), dropout 0.2, batch 16; the pipeline's four sources / all nine
+HAIM_GOLDEN_NAMES = ["haim_pipeline", "haim_all9"]
 
 
 def spec_from_cfg(c):

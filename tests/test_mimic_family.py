@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (MIMIC_GOLDEN_NAMES, Golden, assert_counts_match, assert_within_fp32_noise, build_torch_model,
+from helpers import (HAIM_GOLDEN_NAMES, MIMIC_GOLDEN_NAMES, Golden, assert_counts_match, assert_within_fp32_noise, build_torch_model,
                      fp64_trajectory, rel_err)
 from oracle import multimodn_oracle as O
 from test_hip_parity import check_against, lib  # noqa: F401  (fixture)
@@ -70,8 +70,28 @@ def test_first_step_matches_reference_golden(lib, name, form, monkeypatch):
     check_against(stats, grads, ref)
 
 
+@pytest.mark.parametrize("form", ["default", "sequential"])
+@pytest.mark.parametrize("name", HAIM_GOLDEN_NAMES)
+def test_haim_shape_first_step_matches_reference_golden(lib, name, form, monkeypatch):
+    """The reference's real MIMIC configuration: state 50, hidden (32, 32), dropout 0.2, batch 16, sources of
+    width [6, 1024, 768, 99] (the pipeline's four) / all nine of the dataset - through whatever kernels the plan picks for the
+    shape ("default") and through the sequential form (k_gen_*), which takes any shape."""
+    if form == "sequential":
+        monkeypatch.setenv("MMN_GEN_FAST", "0")
+    g = Golden(name)
+    model = build_torch_model(g.spec, g.init_params(), "cuda", lib)
+    stats, grads, _ = run_step(model, g.batch(0), g.step_masks(0))
+    assert rel_err(stats["loss"], g.z["step_loss"][0]) < 1e-5
+    ref_grads = g.step_grads(0)
+    for n in g.spec.param_names():
+        assert rel_err(grads[n], ref_grads[n]) < 2e-5, (n, rel_err(grads[n], ref_grads[n]))
+    b = g.batch(0)
+    ref = O.forward_backward(g.init_params(), g.spec, b[0], b[1], None, drop_masks=g.step_masks(0))
+    check_against(stats, grads, ref)
+
+
 @pytest.mark.parametrize("optimizer", ["torch", "hip"])
-@pytest.mark.parametrize("name", MIMIC_GOLDEN_NAMES)
+@pytest.mark.parametrize("name", MIMIC_GOLDEN_NAMES + HAIM_GOLDEN_NAMES)
 def test_training_matches_reference_golden(lib, name, optimizer):
     """Whole train_epoch loops through the public surface with the masks the reference drew."""
     g = Golden(name)
@@ -101,7 +121,7 @@ def test_training_matches_reference_golden(lib, name, optimizer):
         assert_within_fp32_noise(sd[n], w, w64[n], n)
 
 
-@pytest.mark.parametrize("name", MIMIC_GOLDEN_NAMES)
+@pytest.mark.parametrize("name", MIMIC_GOLDEN_NAMES + HAIM_GOLDEN_NAMES)
 def test_eval_entry_points_match_reference(lib, name):
     """test() History, predict() and get_states() on the reference's TRAINED weights (eval mode: no dropout)."""
     g = Golden(name)

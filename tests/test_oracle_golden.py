@@ -2,11 +2,11 @@
 import numpy as np
 import pytest
 
-from helpers import GOLDEN_NAMES, MIMIC_GOLDEN_NAMES, PER_SAMPLE_B1_NAMES, Golden, PerSampleGolden, assert_within_fp32_noise, fp64_trajectory, rel_err
+from helpers import GOLDEN_NAMES, HAIM_GOLDEN_NAMES, MIMIC_GOLDEN_NAMES, PER_SAMPLE_B1_NAMES, Golden, PerSampleGolden, assert_within_fp32_noise, fp64_trajectory, rel_err
 from oracle import multimodn_oracle as O
 
 
-@pytest.mark.parametrize("name", GOLDEN_NAMES + MIMIC_GOLDEN_NAMES)
+@pytest.mark.parametrize("name", GOLDEN_NAMES + MIMIC_GOLDEN_NAMES + HAIM_GOLDEN_NAMES)
 def test_oracle_reproduces_reference_run(name):
     g = Golden(name)
     params = g.init_params()

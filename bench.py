@@ -255,6 +255,62 @@ def cpu_match(O, mm, w, device, batch_size, steps=3):
                        "fp64 = the same oracle in float64"}
 
 
+def cpu_match_curve(O, mm, w, device, batch_size, epochs=3, steps=64):
+    """The loss CURVE half of "CPU-match" (VERDICT r4 #4): `epochs` x `steps` training steps through the public
+    MultiModN.train_epoch (device-resident batches, the fused Adam, hipGraph replay) against the numpy oracle's replay of the
+    same steps in float64 and, as the yardstick of what fp32 can do at all, in float32.  Reported per epoch: the largest
+    relative difference of the History loss grid and of the state-change vector to the float64 replay (HIP path / fp32 oracle),
+    and how many trained weight tensors sit further from the float64 trajectory than 4x the fp32 oracle does."""
+    import torch
+    model = build_model(mm, w, device)
+    spec = oracle_spec(O, w)
+    params = {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
+    opt = mm.optim.Adam(list(model.parameters()), w["lr"])
+    hist = mm.MultiModNHistory([f"t{d}" for d in range(w["D"])])
+    batches = synthetic_batches(w, batch_size * steps, batch_size, seed=55)
+    loader = [([torch.from_numpy(x).to(device) for x in xs], torch.from_numpy(y).to(device)) for xs, y in batches]
+    crit = torch.nn.CrossEntropyLoss()
+    for _ in range(epochs):
+        model.train_epoch(loader, opt, crit, hist)
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+    def replay(dtype):
+        p = {n: np.asarray(v, dtype).copy() for n, v in params.items()}
+        o = O.Adam(w["lr"])
+        return p, [O.train_epoch(p, spec, batches, o, dtype=dtype) for _ in range(epochs)]
+    t0 = time.perf_counter()
+    p64, e64 = replay(np.float64)
+    p32, e32 = replay(np.float32)
+    per_epoch, ok = [], True
+    for ep in range(epochs):
+        dl, dl32 = rel(hist.loss["train"][ep], e64[ep].loss), rel(e32[ep].loss, e64[ep].loss)
+        ds, ds32 = rel(hist.state_change_loss[ep], e64[ep].state_change), rel(e32[ep].state_change, e64[ep].state_change)
+        da = float(np.abs(np.asarray(hist.accuracy["train"][ep]) - e64[ep].accuracy).max())
+        per_epoch.append({"epoch": ep, "delta_loss_vs_fp64": dl, "fp32_oracle_delta_loss_vs_fp64": dl32,
+                          "delta_state_change_vs_fp64": ds, "fp32_oracle_delta_state_change_vs_fp64": ds32,
+                          "delta_accuracy_vs_fp64": da})
+        ok = ok and dl < max(1e-5, 4.0 * dl32) and ds < max(1e-5, 4.0 * ds32)
+    far, n_t = [], 0
+    for n, p in model.named_parameters():
+        n_t += 1
+        hw = p.detach().cpu().numpy().astype(np.float64)
+        if rel(hw, p32[n]) <= 2e-5:
+            continue
+        e_hip, e_cpu = float(np.abs(hw - p64[n]).max()), float(np.abs(p32[n].astype(np.float64) - p64[n]).max())
+        if e_hip > 4.0 * e_cpu:
+            far.append({"tensor": n, "ratio": e_hip / max(e_cpu, 1e-300)})
+    return {"epochs": epochs, "steps_per_epoch": steps, "batch": batch_size, "per_epoch": per_epoch,
+            "weight_tensors": n_t, "tensors_beyond_4x_fp32_noise": far,
+            "ok": bool(ok and len(far) <= n_t // 4),
+            "ok_rule": "per epoch: History loss and state change within 1e-5 of the float64 replay or within 4x the fp32 oracle's own distance; "
+                       "at most a quarter of the weight tensors further from the float64 trajectory than 4x the fp32 oracle",
+            "oracle_wall_s": round(time.perf_counter() - t0, 1)}
+
+
 def cpu_baseline(O, spec, batch_size, budget_s=15.0):
     """The numpy oracle (a port of the reference step, oracle/multimodn_oracle.py) timed on the
     host cores on a bounded sample of the same workload."""
@@ -516,6 +572,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-public-path", action="store_true", help="skip the train_epoch-over-DeviceResidentLoader leg")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--no-curve", action="store_true", help="skip cpu_match's 3 x 64-step loss curve (about a minute of oracle time)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary workloads (mimic, c5, c1, c2: child processes of 40 steps each); profiling runs use this")
     args = ap.parse_args()
@@ -927,6 +984,9 @@ def main():
         out["cpu_baseline"]["reference_style_step"] = cpu_faithful_step(O, spec, B)
         if not per_sample:
             out["cpu_match"] = cpu_match(O, mm, wl, dev, B)
+            if args.workload == "c3" and not args.no_curve:
+                out["cpu_match"]["curve"] = cpu_match_curve(O, mm, wl, dev, B)
+                out["cpu_match"]["ok"] = bool(out["cpu_match"]["ok"] and out["cpu_match"]["curve"]["ok"])
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0 and world == 1 and not dp and args.workload == "c3" and not args.no_secondary:

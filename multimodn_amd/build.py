@@ -37,15 +37,21 @@ def source_hash() -> str:
 
 
 def built_hash(path: str = OUT):
-    """What `mmn_source_hash()` of an existing library says (None: no such library / symbol)."""
-    import ctypes
-    try:
-        lib = ctypes.CDLL(path)
-        fn = lib.mmn_source_hash
-    except (OSError, AttributeError):
+    """What `mmn_source_hash()` of an existing library says (None: no such library / symbol).  Asked in a CHILD process:
+    loading a stale library here and the rebuilt one afterwards would leave two copies mapped in the building process."""
+    if not os.path.exists(path):
         return None
-    fn.restype = ctypes.c_char_p
-    return fn().decode()
+    code = ("import ctypes,sys\n"
+            "try:\n"
+            "    lib = ctypes.CDLL(sys.argv[1]); fn = lib.mmn_source_hash; fn.restype = ctypes.c_char_p; print(fn().decode())\n"
+            "except (OSError, AttributeError):\n"
+            "    print('')\n")
+    try:
+        out = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=120)
+    except (OSError, subprocess.TimeoutExpired):
+        return None
+    h = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else ""
+    return h or None
 
 
 def needs_build() -> bool:

@@ -514,11 +514,32 @@ class HipChainEngine:
                 ent[0] = -1
                 self._prescanned = None
                 self._predrawn = None
+                if dp_tail is None:
+                    return False
+            if dp_tail is not None and not self._dp_capture_agreed(dp_tail, ent):
                 return False
         ent[3] = (hp, entry_ready, entry_drawn, bool(reset_first))
         self.replay_entry(ent, steps, nxt, optimizer, draw_dropout)
         self._last_group_entry = ent                            # (the whole-call plan's shortcut for next time: replay_known)
         return True
+
+    def _dp_capture_agreed(self, dp_tail, ent) -> bool:
+        """Data parallel: replay-or-eager is decided by ALL ranks together.  A capture that failed on one rank only would
+        leave that rank launching eager collectives against its peers' replayed ones - a different number and order of
+        collectives per rank, i.e. a hang.  Every rank contributes its outcome to one MIN all-reduce (outside any capture,
+        once per group key); unless all succeeded, all drop the graph and run the group eagerly from here on."""
+        import torch.distributed as dist
+        group = dp_tail[2] if len(dp_tail) > 2 else None
+        ok_here = ent[1] is not None and ent[0] >= 0
+        flag = torch.tensor([1 if ok_here else 0], dtype=torch.int32,
+                            device=self.device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 1:
+            return True
+        ent[0], ent[1], ent[2] = -1, None, None
+        self._prescanned = None
+        self._predrawn = None
+        return False
 
     @staticmethod
     def group_hp_key(err_penalty, sc_penalty_x001, optimizer, d, seed) -> tuple:
@@ -848,33 +869,63 @@ class HipChainEngine:
         return True
 
     # ---- one-shot data-parallel exchange (opt-in; include/mmn_hip.h mmn_dp_oneshot_attach)
-    def attach_oneshot(self, group, world: int, rank: int, spin_ms: int = 5000) -> None:
+    def attach_oneshot(self, group, world: int, rank: int, spin_ms: int = 5000) -> bool:
         """Collective over `group`: every rank allocates its exchange buffer, the 64-byte hipIpc handles travel through
         torch.distributed's object all-gather, every rank maps the peers' buffers and hands all of them to the plan.
-        To be called again after a re-plan (the buffers are sized by the plan)."""
+        To be called again after a re-plan (the buffers are sized by the plan).
+        Failure-atomic across the ranks: every rank reports whether its own allocation / mapping / attach worked, and
+        unless ALL did, every rank closes what it opened and returns False (the caller then keeps the all-reduce path) -
+        no rank is left waiting at a barrier its peer never reaches.  Ranks on different hosts cannot map each other's
+        device memory: refused the same way.  Ranks on DIFFERENT devices of the node ask for fine-grained exchange buffers
+        (MMN_DP_XBUF_FINE, unless the environment says otherwise): the kernel's system-scope accesses do not depend on it,
+        but two processes on one GPU - all the tests here can build - share an L2 and could not tell."""
+        import os
+        import socket
         import torch.distributed as dist
         self.detach_oneshot()
         nbytes = int(self.lib.mmn_dp_xbuf_bytes(self._plan))
-        if nbytes == 0:
-            raise hip.MmnError("one-shot exchange: this plan has no flat gradient layout")
+        who = [None] * world
+        dist.all_gather_object(who, (socket.gethostname(), int(self.device.index if self.device.index is not None else torch.cuda.current_device())),
+                               group=group)
+        same_host = all(h[0] == who[0][0] for h in who)
+        if len({h[1] for h in who}) > 1 and "MMN_DP_XBUF_FINE" not in os.environ:
+            os.environ["MMN_DP_XBUF_FINE"] = "1"
         own = C.c_void_p()
         handle = C.create_string_buffer(64)
-        hip.check(self.lib.mmn_dp_xbuf_alloc(nbytes, C.byref(own), handle), "mmn_dp_xbuf_alloc")
+        ok = nbytes > 0 and same_host
+        if ok:
+            ok = self.lib.mmn_dp_xbuf_alloc(nbytes, C.byref(own), handle) == 0
         handles = [None] * world
-        dist.all_gather_object(handles, (nbytes, bytes(handle.raw)), group=group)
-        if any(h[0] != nbytes for h in handles):
-            raise hip.MmnError(f"one-shot exchange: the ranks' plans differ ({[h[0] for h in handles]} bytes)")
-        ptrs = (C.c_void_p * world)()
-        for r in range(world):
-            if r == rank:
-                ptrs[r] = own.value
-            else:
+        dist.all_gather_object(handles, (nbytes if ok else -1, bytes(handle.raw)), group=group)
+        opened = []
+        if ok and all(h[0] == nbytes for h in handles):
+            ptrs = (C.c_void_p * world)()
+            for r in range(world):
+                if r == rank:
+                    ptrs[r] = own.value
+                    continue
                 peer = C.c_void_p()
-                hip.check(self.lib.mmn_dp_xbuf_open(handles[r][1], C.byref(peer)), "mmn_dp_xbuf_open")
+                if self.lib.mmn_dp_xbuf_open(handles[r][1], C.byref(peer)) != 0:
+                    ok = False
+                    break
+                opened.append(peer.value)
                 ptrs[r] = peer.value
-        hip.check(self.lib.mmn_dp_oneshot_attach(self._plan, world, rank, ptrs, int(spin_ms)), "mmn_dp_oneshot_attach")
+            if ok:
+                ok = self.lib.mmn_dp_oneshot_attach(self._plan, world, rank, ptrs, int(spin_ms)) == 0
+        else:
+            ok = False
+        verdict = [None] * world
+        dist.all_gather_object(verdict, bool(ok), group=group)     # (doubles as the barrier: nobody steps before everybody has mapped everything)
+        if not all(verdict):
+            for ptr in opened:
+                self.lib.mmn_dp_xbuf_close(ptr, 0)
+            if own.value:
+                self.lib.mmn_dp_xbuf_close(own.value, 1)
+            self._oneshot = None
+            self._oneshot_refused = self._plan.value            # (do not try again for this plan)
+            return False
         self._oneshot = {"ptrs": [ptrs[r] for r in range(world)], "rank": rank, "plan": self._plan.value}
-        dist.barrier(group=group)                               # nobody steps before everybody has mapped everything
+        return True
 
     def detach_oneshot(self) -> None:
         st = getattr(self, "_oneshot", None)

@@ -323,7 +323,7 @@ class MultiModN(nn.Module):
         return fd
 
     def _dp_group_tail(self, eng, optimizer):
-        """(key, fn) for engine.run_group when a data-parallel step can sit in a captured group, else None: the one-shot
+        """(key, fn, process group) for engine.run_group when a data-parallel step can sit in a captured group, else None: the one-shot
         exchange (its launch is the library's own), or torch's RCCL all-reduce inside the capture (torch's NCCL binding is
         capturable; round 4, one rank on one GPU with real RCCL launches: 62.1 us/step in captured groups of 8 steps against
         71.0 us eager - the eager data-parallel step is host-bound; MMN_DP_GRAPH=0 keeps the steps eager)."""
@@ -331,14 +331,17 @@ class MultiModN(nn.Module):
             return None
         alpha, beta = float(self.err_penalty), float(self.state_change_penalty)
         if self._oneshot_ready(eng):
-            return ("oneshot", lambda d: eng.accumulate_and_step_oneshot(alpha, beta, optimizer, desc=d))
-        if os.environ.get("MMN_DP_GRAPH", "1") not in ("", "0"):
+            return ("oneshot", lambda d: eng.accumulate_and_step_oneshot(alpha, beta, optimizer, desc=d), self._dp_group)
+        # OPT-IN (MMN_DP_GRAPH=1) until a box with more than one GPU has run it: no test here can put two RCCL ranks on the
+        # one GPU of a box (RCCL refuses duplicate devices), so the capture of an all-reduce has only met a one-rank
+        # communicator.  The default data-parallel step is eager: the protocol the 2- and 8-rank tests verify.
+        if os.environ.get("MMN_DP_GRAPH", "0") not in ("", "0"):
             import torch.distributed as dist
             if dist.get_backend(self._dp_group) == "nccl":
                 def tail(d):
                     dist.all_reduce(eng.reduce_buf, group=self._dp_group)
                     return eng.accumulate_and_step(alpha, beta, optimizer, desc=d)
-                return ("rccl", tail)
+                return ("rccl", tail, self._dp_group)
         return None
 
     def _oneshot_ready(self, eng) -> bool:
@@ -347,8 +350,11 @@ class MultiModN(nn.Module):
         if not getattr(self, "_dp_oneshot", False) or not hasattr(eng, "attach_oneshot"):
             return False
         if not eng.oneshot_attached():
-            eng.attach_oneshot(self._dp_group, self._dp_world, self._dp_rank,
-                               spin_ms=int(os.environ.get("MMN_DP_SPIN_MS", "5000")))
+            if getattr(eng, "_oneshot_refused", None) == eng._plan.value:   # (every rank refused together: the all-reduce path)
+                return False
+            if not eng.attach_oneshot(self._dp_group, self._dp_world, self._dp_rank,
+                                      spin_ms=int(os.environ.get("MMN_DP_SPIN_MS", "5000"))):
+                return False
         eng.oneshot_check()
         return True
 

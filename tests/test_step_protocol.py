@@ -345,14 +345,16 @@ def _ps_worker(rank, world, port, device, out_dir):
     dist.destroy_process_group()
 
 
-def _check_ps(tmp_path):
+def _check_ps(tmp_path, world=2):
     from test_per_sample import c5_like
     spec, xs, y, seq = c5_like(48, seed=4)
     params = O.init_params(spec, 1)
     ref = O.per_sample_step(params, spec, xs, y, seq)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    for k in r0.files:
-        assert np.array_equal(r0[k], r1[k]), k            # replicas stay identical
+    r0 = np.load(tmp_path / "rank0.npz")
+    for r in range(1, world):
+        r1 = np.load(tmp_path / f"rank{r}.npz")
+        for k in r0.files:
+            assert np.array_equal(r0[k], r1[k]), k            # replicas stay identical
     assert rel_err(r0["loss"], ref.err_loss) < 1e-5
     assert rel_err(r0["sc"], ref.state_change) < 1e-5
     flat = np.concatenate([np.zeros(np.asarray(params[n]).size, np.float32) if ref.grads[n] is None
@@ -373,6 +375,9 @@ def test_per_sample_mode_two_ranks_cpu_checker(tmp_path):
 
 
 @pytest.mark.gpu
-def test_per_sample_mode_two_ranks_on_one_gpu(tmp_path):
-    mp.spawn(_ps_worker, args=(2, _free_port(), "cuda", str(tmp_path)), nprocs=2, join=True)
-    _check_ps(tmp_path)
+@pytest.mark.parametrize("world", [2, 8])
+def test_per_sample_mode_two_ranks_on_one_gpu(world, tmp_path):
+    """BASELINE configs[4]'s sharding (per-sample missing modalities and encoder order, rows split over the ranks): two and
+    eight processes on the one GPU of the box."""
+    mp.spawn(_ps_worker, args=(world, _free_port(), "cuda", str(tmp_path)), nprocs=world, join=True)
+    _check_ps(tmp_path, world)

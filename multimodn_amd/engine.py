@@ -80,6 +80,18 @@ def check_criterion(criterion) -> None:
             "criterion must be torch.nn.CrossEntropyLoss() (mean reduction, no class weights, no label smoothing)")
 
 
+PER_SAMPLE_SCOPE = ("per-sample mode (per-sample missing modalities / encoder order, BASELINE configs[4]) runs models of at most 4 "
+                    "encoders that are either MLPEncoder-family encoders with n_features <= 64 and hidden widths <= 32 under "
+                    "ClassDecoder / LogisticDecoder heads (the fused chain kernel's tiled form), or MIMIC_MLPEncoder / MLPDecoder "
+                    "models; this model is outside that set - there is no slower fallback behind the same surface")
+
+
+def _check_regroup(rc: int, what: str) -> None:
+    if rc == hip.ERR_UNSUPPORTED:
+        raise UnsupportedModelError(PER_SAMPLE_SCOPE)
+    hip.check(rc, what)
+
+
 class HipChainEngine:
     def __init__(self, model, max_batch: int):
         check_supported(model)
@@ -615,8 +627,8 @@ class HipChainEngine:
             # the kernels' scratch (codes, presence masks, source row of every position) is this call's own: nothing of
             # the plan's workspace is touched, so the NEXT batch can be regrouped on another stream while a step runs
             scratch = torch.empty(2 * B + rows, dtype=torch.int32, device=dev)
-            hip.check(self.lib.mmn_regroup_ex(self._plan, C.byref(bin_), None if sq is None else sq.data_ptr(),
-                                              C.byref(bout), scratch.data_ptr(), self._stream()), "mmn_regroup_ex")
+            _check_regroup(self.lib.mmn_regroup_ex(self._plan, C.byref(bin_), None if sq is None else sq.data_ptr(),
+                                                   C.byref(bout), scratch.data_ptr(), self._stream()), "mmn_regroup_ex")
             self._ps_layout = ("hip", scratch[2 * B:], B, tile_seq)
             return bout, (xs_p, y_p, tile_rows, tile_seq, sq, xs, y, scratch)
         present = torch.stack([~torch.isnan(x).any(dim=1) for x in xs], dim=1)           # [B, E] slot present
@@ -690,8 +702,8 @@ class HipChainEngine:
         xs_p, y_p, tile_rows, tile_seq, scratch, bout, ev = ent
         bin_, _, template = self.make_batch_keyed(xs, y, [(k, k) for k in range(E)], B, False, template)
         b = hip.Batch.from_buffer_copy(bout)
-        hip.check(self.lib.mmn_regroup_ex(self._plan, C.byref(bin_), None if seq is None else seq.data_ptr(),
-                                          C.byref(b), scratch.data_ptr(), side.cuda_stream), "mmn_regroup_ex")
+        _check_regroup(self.lib.mmn_regroup_ex(self._plan, C.byref(bin_), None if seq is None else seq.data_ptr(),
+                                               C.byref(b), scratch.data_ptr(), side.cuda_stream), "mmn_regroup_ex")
         ev.record(side)
         return b, (xs_p, y_p, tile_rows, tile_seq, seq, xs, y, scratch), ev, template
 

@@ -268,3 +268,25 @@ def test_per_sample_forward_only_entry_points():
     assert rel_err(got_states, states) < 1e-5
     got_pred = model.predict([torch.from_numpy(x) for x in xs], torch.from_numpy(seq))
     assert_predictions_match(got_pred, preds, marg[0], "per-sample predict()")
+
+
+@pytest.mark.gpu
+def test_per_sample_mode_refuses_shapes_outside_its_kernels_up_front():
+    """an MLPEncoder model wider than the fused kernel's tiled form takes (hidden width 48 > 32) used to pass the
+    regrouping and fail inside the step with a bare MMN_ERR_UNSUPPORTED.  It is refused where the rows would be regrouped,
+    with a message that says what per-sample mode covers - and nothing has been launched or changed by then."""
+    lib = mm
+    from multimodn_amd.engine import UnsupportedModelError
+    spec, xs, y, seq = c5_like(48, H=(48,), seed=2)
+    model = build_torch_model(spec, O.init_params(spec, 1), "cuda", lib)
+    model.per_sample = True
+    opt = lib.optim.Adam(list(model.parameters()), 1e-2)
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    loader = [([torch.from_numpy(x) for x in xs], torch.from_numpy(y), torch.from_numpy(seq))]
+    with pytest.raises(UnsupportedModelError, match="per-sample mode"):
+        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), lib.MultiModNHistory(["a", "b"]))
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    model.per_sample = False                                 # the same model trains in batch mode (whole-batch semantics)
+    clean = [([torch.from_numpy(np.nan_to_num(x)) for x in xs], torch.from_numpy(y))]
+    model.train_epoch(clean, opt, torch.nn.CrossEntropyLoss(), lib.MultiModNHistory(["a", "b"]))

@@ -103,6 +103,7 @@ class HipChainEngine:
                 f"MultiModN parameters live on {dev}; the training hot path only runs on an AMD GPU "
                 f"(torch device 'cuda' on ROCm). There is no CPU fallback.")
         self.device = dev
+        self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
         self.params: List[torch.nn.Parameter] = list(model.parameters())
         self.names: List[str] = [n for n, _ in model.named_parameters()]
         for p in self.params:
@@ -251,9 +252,14 @@ class HipChainEngine:
         return False
 
     # ------------------------------------------------------------------ per-step
-    @staticmethod
-    def _stream() -> int:
-        return torch.cuda.current_stream().cuda_stream
+    def _stream(self) -> int:
+        """torch's current stream on this engine's device as a raw handle.  (torch.cuda.current_stream() builds a Stream object
+        through four Python layers - ~2 us a call, several calls in front of a batch-loop call's first launch; the raw
+        getter is one C call.)"""
+        try:
+            return torch._C._cuda_getCurrentRawStream(self._dev_index)
+        except AttributeError:                              # (a torch build without the raw getter)
+            return torch.cuda.current_stream(self.device).cuda_stream
 
     def make_batch(self, xs: Sequence[torch.Tensor], y: torch.Tensor, pairs: Sequence[Tuple[int, int]],
                    batch_global: Optional[int] = None, device_nan_flags: bool = False) -> hip.Batch:

@@ -17,7 +17,7 @@ PMC_GROUPS=(
 )
 run_pass() {   # $1 = pass name, $2 = counters
   rocprofv3 --pmc $2 --kernel-trace --output-format csv -d "$OUT/util_$1" -o "$TAG" -- python3 "$ROOT/bench.py" \
-    --no-cpu-baseline --no-secondary --workload $WL --no-graph --steps 20 --warmup 5 > /dev/null 2> "$OUT/util_$1.err"
+    --no-cpu-baseline --no-secondary --no-public-path --workload $WL --no-graph --steps 20 --warmup 5 > /dev/null 2> "$OUT/util_$1.err"
   find "$OUT/util_$1" -name "${TAG}_counter_collection.csv" | grep -q .
 }
 i=0

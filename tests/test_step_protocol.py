@@ -146,8 +146,8 @@ def test_side_work_in_the_wgrad_launch_equals_round4_layout(family):
                     os.environ[k] = v
 
     ref = run({"MMN_SIDE": "0"}, False)
-    for replay in (False, True):
-        got = run({"MMN_SIDE": "1"}, replay)
+    for replay, cols in ((False, "1"), (True, "1"), (True, "0")):      # (MMN_STATS_COLS=0: the single stats workgroup)
+        got = run({"MMN_SIDE": "1", "MMN_STATS_COLS": cols}, replay)
         _same(ref, got)
         for k, st in ref[4].items():
             for n, v in st.items():

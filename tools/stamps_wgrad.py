@@ -5,15 +5,32 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import multimodn_amd as mm
 import bench
-wl = bench.WORKLOADS["c3"]
+wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c3"]
 model = bench.build_model(mm, wl, torch.device("cuda"))
 model.nan_policy = "device"
 B = wl["B"]
 host = bench.synthetic_batches(wl, B * 8, B, seed=1)
 res = [([torch.from_numpy(x).cuda() for x in xs], torch.from_numpy(y).cuda()) for xs, y in host]
 opt = mm.optim.Adam(list(model.parameters()), wl["lr"])
-steps = [res[i % 8] for i in range(64)]
-for _ in range(3):
+if wl.get("per_sample"):                        # bench.py's C5 data: NaN rows not at random, a random encoder order per sample
+    rng = np.random.default_rng(1)
+    n_enc = len(wl["F"])
+    ps = []
+    for xs, y in res:
+        p_miss = torch.where(y[:, :1] == 1, 0.45, 0.15).cpu().numpy()
+        miss = torch.from_numpy(rng.random((B, n_enc)) < p_miss).cuda()
+        for e in range(n_enc):
+            xs[e][miss[:, e]] = float("nan")
+        sq = torch.from_numpy(np.stack([rng.permutation(n_enc) for _ in range(B)]).astype(np.int64)).cuda()
+        ps.append((xs, y, sq))
+    model.per_sample = True
+    class _L(list): pass
+    steps = _L([ps[i % 8] for i in range(16)])
+    for _ in range(3):
+        model.train_epoch(steps, opt, torch.nn.CrossEntropyLoss())
+else:
+  steps = [res[i % 8] for i in range(64)]
+  for _ in range(3):
     model._train_steps(steps, opt)              # the real step sequence (fused Adam, pre-scan blocks, graphs)
 torch.cuda.synchronize()
 eng = model._engine
@@ -57,11 +74,13 @@ for lo in range(0, n, 32):
     print(f"  blocks {lo:3d}+: start {start[sel].mean():5.2f} dur {dur[sel].mean():5.2f} (max {dur[sel].max():5.2f}) end {end[sel].max():5.2f}")
 
 
-if os.environ.get("MMN_SIDE", "1") != "0":             # side work inside the k_wgrad launch: the blocks behind the work items
-    ni = n - 1
-    while ni > 0 and dur[ni - 1] < 7.0 and start[ni - 1] > 1.0:
-        ni -= 1
-    print("side blocks (stats first, then pre-scan / pre-draw): [start-end us]", " ".join(f"[{start[j]:.1f}-{end[j]:.1f}]" for j in range(ni, n)))
+if os.environ.get("MMN_SIDE", "1") != "0":             # the side blocks stand in front of the work items
+    R, D, E = len(wl["F"]) + 1, wl["D"], len(wl["F"])
+    cols = os.environ.get("MMN_STATS_COLS", "1") != "0" and R * D + E <= 32
+    ns = -(-(6 * R * D + E) // 32) if cols else 1
+    print("side blocks: stats (%d) [%.2f - %.2f us], Adam coefficients [%.2f - %.2f us]; last work item ends at %.2f us" %
+          (ns, start[:ns].min(), end[:ns].max(), start[ns], end[ns], end[ns + 1:].max()))
+    print("  each stats block:", " ".join("[%.2f - %.2f]" % (start[i], end[i]) for i in range(ns)))
 nr = int((rd[:, 0] > 0).sum()); rd = rd[:nr]
 r0 = rd[0, 0]
 print("k_reduce: workgroups", nr, "start of first after k_wgrad's last end:", (r0 - st[:, 1].max()) / 100.0, "us; span", (rd[:, 1].max() - r0) / 100.0)

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MMN_VERSION 111            /* 0.1.11: mmn_wgrad_reduce (the second half of mmn_train_step_ex on its own: k_wgrad with the stats block in its launch, then k_reduce as gradient blocks only); 0.1.10: mmn_regroup_multi (the batches of a captured per-sample group regrouped by one set of launches); 0.1.9: one-shot data-parallel exchange (mmn_dp_xbuf_*, mmn_dp_oneshot_*, mmn_adam_step_accumulate_oneshot, MMN_ERR_PEER); 0.1.8: mmn_source_hash (a library that was not built from the sources next to it does not load); 0.1.7: mmn_eval_step_ex (test(): outputs and row flag of a step collected by the call); 0.1.6: mmn_dp_rescale (uneven data-parallel shards);
+#define MMN_VERSION 112            /* 0.1.12: mmn_epoch_small_rows / mmn_train_epoch_small (a whole epoch of small batches as one launch); 0.1.11: mmn_wgrad_reduce (the second half of mmn_train_step_ex on its own: k_wgrad with the stats block in its launch, then k_reduce as gradient blocks only); 0.1.10: mmn_regroup_multi (the batches of a captured per-sample group regrouped by one set of launches); 0.1.9: one-shot data-parallel exchange (mmn_dp_xbuf_*, mmn_dp_oneshot_*, mmn_adam_step_accumulate_oneshot, MMN_ERR_PEER); 0.1.8: mmn_source_hash (a library that was not built from the sources next to it does not load); 0.1.7: mmn_eval_step_ex (test(): outputs and row flag of a step collected by the call); 0.1.6: mmn_dp_rescale (uneven data-parallel shards);
                                       0.1.5: mmn_step_opts.next_drop_* (the next step's dropout multipliers in this step's last launch), mmn_dropout_adopt;
                                       0.1.4: mmn_train_step_ex (pre-scan of the next batch, flag sets in the stats block), mmn_pack_invalidate;
                                       0.1.3: + mmn_draw_dropout; 0.1.2: MIMIC_MLPEncoder / MLPDecoder (mmn_encoder.kind, mmn_decoder.hidden, mmn_batch.drop_mask) */
@@ -445,6 +445,25 @@ int mmn_dropout_adopt(mmn_plan* p, mmn_batch* b, const float* drop_p, float* buf
  * mmn_epoch_read synchronises the stream.  Layout of `out` (doubles): err_sum[R*D], sc_sum[E],
  * n_correct[R*D], tp[R*D], tn[R*D], fp[R*D], fn[R*D] (the four accumulated in fp32 like the
  * reference's torch.zeros tensors, multimodn.py:112-115,209-212), rows[R], n_steps[1]. */
+/* ---- the whole batch loop of one train_epoch call in ONE launch (small models, small batches)  [round 5, ABI 112]
+ * Replaces: `for batch in train_loader: ... optimizer.step()` of multimodn/multimodn.py:117-212 as the reference's Titanic
+ * pipeline runs it (pipelines/titanic/titanic_mlp_pipeline.py:63-85: batches of 32 rows, 1,379 parameters) - one workgroup,
+ * parameters and Adam moments resident in LDS / registers, every batch's forward, loss grid, backward, weight gradients,
+ * torch.optim.Adam update and epoch sums, the next batch prefetched under the current one.
+ * mmn_epoch_small_rows: the largest batch (rows) this model can run that way, 0 = not at all (MLPEncoder + ClassDecoder
+ *   models with <= 4 encoders of <= 4 Linears whose image fits 160 KB of LDS; at most 64 rows).
+ * mmn_train_epoch_small: `batches_host` / `batches_dev` = the same n_batches descriptors in host memory (validated here)
+ *   and in device memory (read by the kernel; the caller keeps both alive until the stream has passed the launch).
+ *   Every batch: default encoder sequence (seq_data[k] = seq_enc[k] = k), batch_global = batch, no tile tables, no
+ *   dropout.  NaN batches skip their encoder as in mmn_train_step (decided inside the kernel: nan_flags is not read).
+ *   `adam`: the optimizer state in the plan's flat layout (mmn_adam_fusable), updated in place, step counters included;
+ *   adam->grads receives the LAST step's gradients.  Epoch sums accumulate onto mmn_epoch_read's doubles; the stats block
+ *   holds the last step's values.  The chain kernels' weight copies are invalidated (mmn_pack_invalidate).
+ * Errors: MMN_ERR_UNSUPPORTED (model / batch outside the scope above), MMN_ERR_ARG, MMN_ERR_HIP. */
+int mmn_epoch_small_rows(mmn_plan* p);
+int mmn_train_epoch_small(mmn_plan* p, const mmn_batch* batches_host, const mmn_batch* batches_dev, int n_batches,
+                          float err_penalty, float state_change_penalty_x001, const struct mmn_adam* adam, void* stream);
+
 size_t mmn_epoch_doubles(const mmn_model* m);
 int mmn_epoch_reset(mmn_plan* p, void* stream);
 int mmn_epoch_read(mmn_plan* p, double* out_host, void* stream);

@@ -84,6 +84,7 @@ namespace {
 #include "mmn_per_sample.inc"
 #include "mmn_adam_reduce.inc"
 #include "mmn_wgrad.inc"
+#include "mmn_epoch_small.inc"
 }  // namespace
 
 #include "mmn_host.inc"

@@ -866,6 +866,13 @@ class HipChainEngine:
         hip.check(self.lib.mmn_nan_scan(self._plan, C.byref(b), self._stream()), "mmn_nan_scan")
         self._prescanned = b
 
+    def epoch_small_rows(self) -> int:
+        """Largest batch (rows) the one-launch epoch kernel takes for this model, 0 if it does not apply (mmn_epoch_small_rows)."""
+        c = self.__dict__.get("_eps_rows")
+        if c is None or c[0] != self._plan.value:
+            c = self.__dict__["_eps_rows"] = (self._plan.value, int(self.lib.mmn_epoch_small_rows(self._plan)))
+        return c[1]
+
     def adam_fusable(self, optimizer, desc=None) -> bool:
         """True if `optimizer`'s step can ride in this engine's launches: a multimodn_amd.optim.Adam over exactly this
         model's parameters, one group, one contiguous run whose layout the library accepts.  Only then does the fused

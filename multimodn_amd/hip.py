@@ -17,7 +17,7 @@ MAX_LAYERS = 8
 MAX_DIM = 128
 ADAM_MAX_SEG = 512
 ERR_UNSUPPORTED = -2
-VERSION = 111
+VERSION = 112
 MAX_DEC_HIDDEN = 3
 ENC_MLP, ENC_MIMIC = 0, 1
 
@@ -37,6 +37,7 @@ ABI_SYMBOLS = (
     "mmn_nan_flags_set", "mmn_pack_invalidate", "mmn_pack_refresh", "mmn_train_step_ex", "mmn_epoch_write", "mmn_adam_fusable", "mmn_regroup_ex", "mmn_dp_rescale", "mmn_eval_step_ex",
     "mmn_dp_xbuf_bytes", "mmn_dp_xbuf_alloc", "mmn_dp_xbuf_open", "mmn_dp_xbuf_close", "mmn_dp_oneshot_attach",
     "mmn_dp_oneshot_error", "mmn_adam_step_accumulate_oneshot", "mmn_regroup_multi", "mmn_wgrad_reduce",
+    "mmn_epoch_small_rows", "mmn_train_epoch_small",
 )
 
 
@@ -137,6 +138,10 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_pack_refresh.argtypes = [vp, vp]
     lib.mmn_train_step_ex.restype = i32
     lib.mmn_train_step_ex.argtypes = [vp, C.POINTER(Batch), f32, f32, C.POINTER(StepOpts), vp]
+    lib.mmn_epoch_small_rows.restype = i32
+    lib.mmn_epoch_small_rows.argtypes = [vp]
+    lib.mmn_train_epoch_small.restype = i32
+    lib.mmn_train_epoch_small.argtypes = [vp, C.POINTER(Batch), vp, i32, f32, f32, C.POINTER(AdamDesc), vp]
     lib.mmn_wgrad_reduce.restype = i32
     lib.mmn_wgrad_reduce.argtypes = [vp, C.POINTER(Batch), f32, f32, C.POINTER(StepOpts), vp]
     lib.mmn_adam_fusable.restype = i32

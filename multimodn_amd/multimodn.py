@@ -21,6 +21,9 @@ from torch import Tensor
 from torch.optim import Optimizer
 from torch.utils.data import DataLoader
 
+import ctypes as C
+
+from . import hip
 from .decoders import MultiModDecoder
 from .encoders import MultiModEncoder
 from .engine import HipChainEngine, check_criterion
@@ -537,7 +540,9 @@ class MultiModN(nn.Module):
         plan_ok = stable and not dp and not log_interval and not self.shuffle_mode and getattr(self, "replay_steps", True) \
             and self.dropout_mask_provider is None and optimizer is not None
         if plan_ok:
-            done = self._replay_epoch_plan(train_loader, optimizer)
+            done = self._small_epoch(train_loader, optimizer)
+            if done is None:
+                done = self._replay_epoch_plan(train_loader, optimizer)
             if done is not None:
                 return done
         rec: List[tuple] = []                                # the groups this call replays, in order (-> _epoch_plans)
@@ -722,6 +727,79 @@ class MultiModN(nn.Module):
             plans[(len(seen_batches), id(seen_batches[0]), id(seen_batches[-1]))]["groups"] = [
                 (g[0], g[1], g[2] if (g[2] is not None and g[2][1] is not None) else None) for g in rec]
         return state["eng"], state["steps"]
+
+    def _small_epoch(self, train_loader, optimizer):
+        """The whole batch loop as ONE launch (mmn_train_epoch_small, csrc/mmn_epoch_small.inc): small MLPEncoder + ClassDecoder
+        models on device-resident batches of at most `mmn_epoch_small_rows` rows each - the reference's Titanic pipeline,
+        pipelines/titanic/titanic_mlp_pipeline.py:63-85, is the case it is built for.  Applies under the conditions of a
+        replayed plan (stable batch objects, multimodn_amd.optim.Adam over exactly this model, device NaN policy, default
+        encoder sequence, no data parallel, no logging, no dropout provider); `model.epoch_kernel = False` or
+        MMN_EPOCH_KERNEL=0 keeps the step-by-step path.  Returns (engine, steps) or None.
+        Like a replayed plan it records ADDRESSES: a batch is recognised by its objects (tuple, tensors), not re-read."""
+        import itertools
+        import operator
+        if not getattr(self, "epoch_kernel", True) or os.environ.get("MMN_EPOCH_KERNEL", "1") == "0":
+            return None
+        if getattr(self, "nan_policy", "auto") not in ("auto", "device") or not hasattr(optimizer, "fused_descriptor"):
+            return None
+        seq = train_loader if isinstance(train_loader, (list, tuple)) else list(train_loader)
+        if not seq or len(seq) > 65536:
+            return None
+        cache = self.__dict__.setdefault("_small_epochs", {})
+        key = (len(seq), id(seq[0]), id(seq[-1]))
+        ep = cache.get(key)
+        if ep is not None:
+            datas = list(map(operator.itemgetter(0), seq))
+            if not (ep["opt"] is optimizer and ep["eng"] is self._engine and all(map(operator.is_, seq, ep["batches"]))
+                    and all(map(operator.is_, map(operator.itemgetter(1), seq), ep["ys"])) and list(map(len, datas)) == ep["lens"]
+                    and all(map(operator.is_, itertools.chain.from_iterable(datas), ep["xs"]))
+                    and (max(map(len, seq)) == 2 or all(len(b_) == 2 or b_[2] is None for b_ in seq))):
+                cache.pop(key, None)
+                ep = None
+        rows = ep["rows"] if ep is not None else max(int(b_[1].shape[0]) for b_ in seq)
+        if rows > 64:
+            return None
+        eng = self._get_engine(rows)
+        if not hasattr(eng, "epoch_small_rows") or eng.epoch_small_rows() < rows:
+            return None
+        if ep is not None and (eng._plan is None or eng._plan.value != ep["plan"]):
+            cache.pop(key, None)
+            ep = None
+        eng.begin_sequence()
+        if self._nan_mode(eng, optimizer, True) != "device":
+            return None
+        fd = self._fusion_setup(eng, optimizer, "device")
+        if fd is None or fd.seg_skip:
+            return None
+        if ep is None:
+            structs, ys, xs_all, lens = [], [], [], []
+            for batch in seq:
+                data, target, encoder_sequence = (list(batch) + [None])[:3]
+                if encoder_sequence is not None or not isinstance(batch, tuple):
+                    return None
+                st = self._make_step(data, target, None, "device", True)
+                if st.on_host or st.y is not target or len(st.xs) != len(data) or not all(a is c for a, c in zip(st.xs, data)) \
+                        or st.bg != int(target.shape[0]) or [tuple(pe) for pe in st.pairs] != [(k, k) for k in range(len(self.encoders))]:
+                    return None
+                structs.append(eng.make_batch_keyed(st.xs, st.y, st.pairs, st.bg, False)[0])
+                ys.append(target); xs_all.extend(data); lens.append(len(data))
+            host = (hip.Batch * len(structs))(*structs)
+            dev = torch.from_numpy(np.frombuffer(host, dtype=np.uint8).copy()).to(self.device)
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            ep = cache[key] = {"batches": list(seq), "ys": ys, "xs": xs_all, "lens": lens, "host": host, "dev": dev, "rows": rows,
+                               "opt": optimizer, "eng": eng, "plan": eng._plan.value}
+        eng.epoch_reset()
+        rc = eng.lib.mmn_train_epoch_small(eng._plan, ep["host"], ep["dev"].data_ptr(), len(seq), float(self.err_penalty),
+                                           float(self.state_change_penalty), C.byref(fd), eng._stream())
+        if rc == hip.ERR_UNSUPPORTED:
+            cache.pop(key, None)
+            return None
+        hip.check(rc, "mmn_train_epoch_small")
+        eng._versions_seen = None                            # (the chain kernels' weight copies are stale: the library says so too)
+        optimizer.fused_step_seen(len(seq))
+        self.__dict__["train_steps_launched"] = self.__dict__.get("train_steps_launched", 0) + len(seq)
+        return eng, len(seq)
 
     def _replay_epoch_plan(self, train_loader, optimizer):
         """The whole batch loop of a call whose batch OBJECTS, optimizer and engine are those of an earlier call that ran

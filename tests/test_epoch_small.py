@@ -1,0 +1,131 @@
+"""The one-launch epoch kernel (csrc/mmn_epoch_small.inc, mmn_train_epoch_small): `for batch in loader:
+forward, loss grid, backward, optimizer.step()` of multimodn/multimodn.py:117-212 for the reference's Titanic-sized
+models (pipelines/titanic/titanic_mlp_pipeline.py:63-85) as ONE launch of one workgroup per train_epoch call.
+
+Checked against the REFERENCE's own runs (tests/golden/*.npz: History arrays and trained weights of the reference's
+train_epoch loops, same rules as test_hip_parity.py::test_training_matches_reference_golden), against the step-by-step
+HIP path on the same batches (History within 1e-5, Adam step counts equal - a NaN batch skips its encoder's tensors),
+and for what the surface promises: the path is taken only where it applies, `model.epoch_kernel = False` keeps the
+step-by-step path, `.grad` holds the last step's gradients."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import Golden, assert_counts_match, assert_within_fp32_noise, build_torch_model, fp64_trajectory, rel_err
+from oracle import multimodn_oracle as O
+from test_hip_parity import lib  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+# goldens whose model and batches the kernel takes (c2_split / c3_small: more than 4,096 parameters; seq_perm: its own encoder order)
+EPOCH_GOLDENS = ["c1_titanic", "c1_curve20", "nan_skip", "slp_sigmoid", "mlp_sigmoid", "mlp_identity"]
+
+
+def _device_loader(batches):
+    return [([torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in b[0]], torch.from_numpy(b[1]).cuda()) for b in batches]
+
+
+@pytest.mark.parametrize("name", EPOCH_GOLDENS)
+def test_epoch_kernel_matches_reference_golden(lib, name, monkeypatch):
+    monkeypatch.setenv("MMN_EPOCH_KERNEL", "1")
+    g = Golden(name)
+    model = build_torch_model(g.spec, g.init_params(), "cuda", lib)
+    opt = lib.optim.Adam(list(model.parameters()), g.cfg["lr"])
+    hist = lib.MultiModNHistory([f"t{d}" for d in range(g.spec.D)])
+    loader = _device_loader(g.batches())
+    for _ in range(g.epochs):
+        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+    torch.cuda.synchronize()
+    assert model.__dict__.get("_small_epochs"), "the one-launch epoch path did not run"
+    assert model.train_steps_launched == g.epochs * len(loader)
+    z = g.z
+    assert rel_err(np.stack(hist.loss["train"]), z["hist/loss"]) < 1e-5
+    assert rel_err(np.stack(hist.state_change_loss), z["hist/state_change"]) < 1e-5
+    assert_counts_match(hist, z, g)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    w64, l64, _ = fp64_trajectory(g)[:3]
+    for n, w in g.final_params().items():
+        assert_within_fp32_noise(sd[n], w, w64[n], n)
+    assert_within_fp32_noise(np.stack(hist.loss["train"]), z["hist/loss"], l64, "History loss", tight=1e-5)
+
+
+def _run(lib, spec, loader, epochs, use_kernel, lr=1e-2):
+    torch.manual_seed(3)
+    model = build_torch_model(spec, O.init_params(spec, 4), "cuda", lib)
+    model.epoch_kernel = use_kernel
+    opt = lib.optim.Adam(list(model.parameters()), lr)
+    hist = lib.MultiModNHistory([f"t{d}" for d in range(spec.D)])
+    for _ in range(epochs):
+        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+    torch.cuda.synchronize()
+    steps = {i: int(st["step"]) for i, st in opt.state_dict()["state"].items()}
+    grads = [p.grad.detach().cpu().numpy().copy() for p in model.parameters()]
+    return model, hist, steps, grads
+
+
+@pytest.mark.parametrize("shape", ["titanic", "two_enc", "deep"])
+def test_epoch_kernel_equals_step_path(lib, shape, monkeypatch):
+    """Same batches through both paths: 28 batches of 32 rows (the last one ragged), NaN batches in the middle that skip
+    an encoder (multimodn.py:168: no gradient, no Adam step for its tensors - their step counts stay behind)."""
+    monkeypatch.setenv("MMN_EPOCH_KERNEL", "1")
+    spec = {"titanic": O.ModelSpec(32, [O.EncoderSpec(6, (5, 5), O.ACT_RELU)], 1, 0.7, 0.3),
+            "two_enc": O.ModelSpec(24, [O.EncoderSpec(3, (5, 5), O.ACT_RELU), O.EncoderSpec(2, (7,), O.ACT_SIGMOID)], 2, 0.7, 0.3),
+            "deep": O.ModelSpec(16, [O.EncoderSpec(9, (8, 6, 4), O.ACT_RELU), O.EncoderSpec(4, (), O.ACT_IDENTITY),
+                                     O.EncoderSpec(5, (6,), O.ACT_RELU)], 3, 1.0, 1.0)}[shape]
+    B, nb = 32, 28
+    batches = O.synthetic_batches(spec, nb * B - 11, B, seed=9)        # (the last batch has 21 rows)
+    for bi, slot in ((3, 0), (9, spec.E - 1), (10, spec.E - 1), (nb - 1, 0)):
+        batches[bi][0][slot][1, 0] = np.nan
+    loader = _device_loader(batches)
+    m_k, h_k, st_k, g_k = _run(lib, spec, loader, 3, True)
+    m_s, h_s, st_s, g_s = _run(lib, spec, loader, 3, False)
+    assert m_k.__dict__.get("_small_epochs") and not m_s.__dict__.get("_small_epochs")
+    assert st_k == st_s and len(set(st_k.values())) > 1, st_k          # skipped tensors lag behind, identically
+    for a, b in ((h_k.loss["train"], h_s.loss["train"]), (h_k.state_change_loss, h_s.state_change_loss)):
+        assert rel_err(np.stack(a), np.stack(b)) < 1e-5
+    for k in ("accuracy", "sensitivity", "specificity", "balanced_accuracy"):
+        assert np.abs(np.stack(getattr(h_k, k)["train"]) - np.stack(getattr(h_s, k)["train"])).max() <= 2.0 / (nb * B)
+    # trained weights after 84 Adam steps: against the fp64 replay, no further than 4x the fp32 oracle's own replay is
+    p32 = {n: v.copy() for n, v in O.init_params(spec, 4).items()}
+    p64 = {n: np.asarray(v, np.float64) for n, v in O.init_params(spec, 4).items()}
+    o32, o64 = O.Adam(1e-2), O.Adam(1e-2)
+    for _ in range(3):
+        O.train_epoch(p32, spec, batches, o32, dtype=np.float32)
+        O.train_epoch(p64, spec, batches, o64, dtype=np.float64)
+    for n, p in m_k.named_parameters():
+        assert_within_fp32_noise(p.detach().cpu().numpy(), p32[n], p64[n], n)
+    # .grad = the last step's gradients on both paths (a skipped encoder's: whatever an earlier step left)
+    last_skips_enc0 = True
+    for (n, _), a, b in zip(m_k.named_parameters(), g_k, g_s):
+        if last_skips_enc0 and n.startswith("encoders.0."):
+            continue
+        assert np.abs(a - b).max() <= 3e-5 * max(np.abs(b).max(), 1e-6) + 2e-8, n
+
+
+def test_epoch_kernel_scope(lib, monkeypatch):
+    """Where it does not apply the step-by-step path runs, silently and with the same results contract: batches above 64
+    rows, models outside its shapes (MIMIC modules; more than 4,096 parameters), a stock torch optimizer, host batches."""
+    monkeypatch.setenv("MMN_EPOCH_KERNEL", "1")
+    small = O.ModelSpec(32, [O.EncoderSpec(6, (5, 5), O.ACT_RELU)], 1, 0.7, 0.3)
+    big = O.ModelSpec(128, [O.EncoderSpec(64, (32, 32), O.ACT_RELU) for _ in range(4)], 3, 1.0, 0.3)
+    mimic = O.ModelSpec(32, [O.EncoderSpec(6, (8,), O.ACT_RELU, kind="mimic", dropout=0.0)], 1, 1.0, 0.3,
+                        decoders=[O.DecoderSpec("mlp", (8,))])
+
+    def took(spec, B, opt_cls=None, host=False):
+        batches = O.synthetic_batches(spec, 4 * B, B, seed=2)
+        loader = _device_loader(batches) if not host else [([torch.from_numpy(x) for x in xs], torch.from_numpy(y)) for xs, y in batches]
+        model = build_torch_model(spec, O.init_params(spec, 1), "cuda", lib)
+        opt = (opt_cls or lib.optim.Adam)(list(model.parameters()), 1e-2)
+        hist = lib.MultiModNHistory([f"t{d}" for d in range(spec.D)])
+        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+        torch.cuda.synchronize()
+        assert np.isfinite(np.stack(hist.loss["train"])).all()
+        return bool(model.__dict__.get("_small_epochs"))
+    assert took(small, 32)
+    assert took(small, 64)
+    assert not took(small, 65)
+    assert not took(big, 32)
+    assert not took(mimic, 16)
+    assert not took(small, 32, opt_cls=torch.optim.Adam)
+    assert not took(small, 32, host=True)

@@ -946,6 +946,9 @@ def main():
                     else "multimodn_amd.optim.Adam in the launch behind the all-reduce (k_adam_accumulate)")
     else:
         opt_text = "multimodn_amd.optim.Adam fused into k_reduce (coefficients and step counters: the k_wgrad launch's side block)"
+    epoch_kernel = bool(model.__dict__.get("_small_epochs"))   # the call ran as ONE launch (k_epoch_small: Titanic-sized models)
+    if epoch_kernel:
+        opt_text = "multimodn_amd.optim.Adam inside k_epoch_small (parameters and moments resident in LDS for the whole call)"
     out = {
         "metric": "samples/sec/GPU (MIMIC 4-enc/3-dec, state_dim=128) + CPU-match Δloss",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -957,7 +960,8 @@ def main():
                    "step_path": "MultiModN._train_steps (the batch loop of MultiModN.train_epoch)",
                    "launch": (f"hipGraph replay ({max(group, int(getattr(model, 'REPLAY_GROUP', 8))) if (dp or per_sample) else group} steps per graph"
                               + (f", {int(model.REPLAY_GROUP_NEXT)} behind the first group of a call" if (not per_sample and int(getattr(model, 'REPLAY_GROUP_NEXT', 0)) not in (0, group)) else "")
-                              + ")") if replayed else "eager",
+                              + ")") if replayed else ("one launch per call: k_epoch_small, all steps in one workgroup (the kernels under "
+                                                       "roofline.avg_launch_us are the step-by-step path's, timed through the C ABI)" if epoch_kernel else "eager"),
                    # counted around every torch.distributed collective of the timed region (n steps + 1 for the sequence's
                    # first batch, whose NaN flags have no predecessor to ride with)
                    "collectives_per_step": (n_coll["all_reduce"] + n_coll["other"]) / args.steps if dp else 0,

@@ -129,3 +129,40 @@ def test_epoch_kernel_scope(lib, monkeypatch):
     assert not took(mimic, 16)
     assert not took(small, 32, opt_cls=torch.optim.Adam)
     assert not took(small, 32, host=True)
+
+
+def test_epoch_kernel_then_eval_and_optimizer_options(lib, monkeypatch):
+    """What follows an epoch on the kernel path must see its results: test() right behind train_epoch (the chain kernels'
+    weight copies were not touched by the epoch kernel: they are rebuilt), an LR change between epochs, weight decay, and
+    four encoders of different depths under three decoders - all against the step-by-step path on the same batches."""
+    monkeypatch.setenv("MMN_EPOCH_KERNEL", "1")
+    spec = O.ModelSpec(20, [O.EncoderSpec(7, (6, 5), O.ACT_RELU), O.EncoderSpec(3, (), O.ACT_IDENTITY),
+                            O.EncoderSpec(5, (4, 4, 4), O.ACT_SIGMOID), O.EncoderSpec(2, (9,), O.ACT_RELU)], 3, 0.9, 0.4)
+    batches = O.synthetic_batches(spec, 9 * 24 - 5, 24, seed=31)
+    batches[4][0][2][3, 1] = np.nan
+    loader = _device_loader(batches)
+
+    def run(use_kernel):
+        torch.manual_seed(5)
+        model = build_torch_model(spec, O.init_params(spec, 6), "cuda", lib)
+        model.epoch_kernel = use_kernel
+        opt = lib.optim.Adam(list(model.parameters()), 1e-2, weight_decay=1e-3)
+        hist = lib.MultiModNHistory([f"t{d}" for d in range(spec.D)])
+        reports = []
+        for ep in range(4):
+            if ep == 2:
+                for gp in opt.param_groups:
+                    gp["lr"] = 3e-3
+            model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+            reports.append(model.test(loader, torch.nn.CrossEntropyLoss(), hist, tag="val"))
+        torch.cuda.synchronize()
+        return model, hist, reports
+    m_k, h_k, r_k = run(True)
+    m_s, h_s, r_s = run(False)
+    assert m_k.__dict__.get("_small_epochs") and not m_s.__dict__.get("_small_epochs")
+    for tag in ("train", "val"):
+        assert rel_err(np.stack(h_k.loss[tag]), np.stack(h_s.loss[tag])) < 2e-5, tag
+        assert np.abs(np.stack(h_k.accuracy[tag]) - np.stack(h_s.accuracy[tag])).max() <= 2.0 / (9 * 24)
+    for (n, a), (_, b) in zip(m_k.named_parameters(), m_s.named_parameters()):
+        a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
+        assert np.abs(a - b).max() <= 2e-4 * max(np.abs(b).max(), 1e-3), (n, np.abs(a - b).max(), np.abs(b).max())

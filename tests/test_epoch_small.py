@@ -166,3 +166,41 @@ def test_epoch_kernel_then_eval_and_optimizer_options(lib, monkeypatch):
     for (n, a), (_, b) in zip(m_k.named_parameters(), m_s.named_parameters()):
         a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
         assert np.abs(a - b).max() <= 2e-4 * max(np.abs(b).max(), 1e-3), (n, np.abs(a - b).max(), np.abs(b).max())
+
+
+def test_epoch_kernel_sees_new_optimizer_buffers_and_edited_batches(lib, monkeypatch):
+    """The path records addresses (batch descriptors in device memory): an optimizer whose state was re-loaded (new moment /
+    step buffers), a batch whose tensor was replaced in its list, and parameters loaded from a checkpoint must all be seen by
+    the next call - same training as the step-by-step path doing the same things."""
+    monkeypatch.setenv("MMN_EPOCH_KERNEL", "1")
+    spec = O.ModelSpec(32, [O.EncoderSpec(6, (5, 5), O.ACT_RELU)], 1, 0.7, 0.3)
+    batches = O.synthetic_batches(spec, 6 * 32, 32, seed=77)
+    other = O.synthetic_batches(spec, 32, 32, seed=78)[0]
+
+    def run(use_kernel):
+        torch.manual_seed(1)
+        loader = _device_loader(batches)
+        model = build_torch_model(spec, O.init_params(spec, 8), "cuda", lib)
+        model.epoch_kernel = use_kernel
+        opt = lib.optim.Adam(list(model.parameters()), 1e-2)
+        hist = lib.MultiModNHistory(["t0"])
+        crit = torch.nn.CrossEntropyLoss()
+        for ep in range(6):
+            if ep == 2:                                      # new optimizer buffers
+                sd = opt.state_dict()
+                opt.load_state_dict({"state": {k: {n: (t.clone() if torch.is_tensor(t) else t) for n, t in st.items()}
+                                               for k, st in sd["state"].items()}, "param_groups": sd["param_groups"]})
+            if ep == 3:                                      # a batch's tensor replaced in place of the old one
+                loader[2][0][0] = torch.from_numpy(other[0][0]).cuda()
+            if ep == 4:                                      # parameters written from outside (a checkpoint)
+                model.load_state_dict({k: v * 0.5 for k, v in model.state_dict().items()})
+            model.train_epoch(loader, opt, crit, hist)
+        torch.cuda.synchronize()
+        return model, np.stack(hist.loss["train"])
+    m_k, l_k = run(True)
+    m_s, l_s = run(False)
+    assert m_k.__dict__.get("_small_epochs") and not m_s.__dict__.get("_small_epochs")
+    assert rel_err(l_k, l_s) < 2e-5, (l_k, l_s)
+    for (n, a), (_, b) in zip(m_k.named_parameters(), m_s.named_parameters()):
+        a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
+        assert np.abs(a - b).max() <= 2e-4 * max(np.abs(b).max(), 1e-3), n

@@ -825,16 +825,29 @@ def main():
             torch.cuda.synchronize()
             el_s = time.perf_counter() - t_s
             nb_s = len(stock_loader)
-            # where the time goes: the loader alone (per-sample Tensor construction + collate on the host)
+            # where the time goes: the loader alone (PartitionDataset.__getitems__: one gather per partition and batch), and -
+            # for reference - the same loader over a dataset that only has the reference's per-sample __getitem__
             t_l = time.perf_counter()
             for _b in stock_loader:
                 pass
             el_l = time.perf_counter() - t_l
+
+            class _PerSample(torch.utils.data.Dataset):
+                def __init__(self, d): self.d = d
+                def __len__(self): return len(self.d)
+                def __getitem__(self, i): return self.d[i]
+            t_p = time.perf_counter()
+            for _b in DataLoader(_PerSample(dset), batch_size=B, shuffle=False):
+                pass
+            el_p = time.perf_counter() - t_p
             other_paths["stock_path"] = {
                 "entry_point": "MultiModN.train_epoch(torch DataLoader(PartitionDataset), torch.optim.Adam, CrossEntropyLoss, History): the reference pipeline with the import swapped",
                 "us_per_step": el_s / nb_s * 1e6, "value": B * nb_s / el_s, "unit": "samples/s", "steps": nb_s,
                 "loader_alone_us_per_step": el_l / nb_s * 1e6,
-                "note": "host-bound by the DataLoader (per-sample __getitem__ and collate of 4096 rows per batch); DeviceResidentLoader is the resident form"}
+                "per_sample_loader_alone_us_per_step": el_p / nb_s * 1e6,
+                "note": "host-bound by the DataLoader; round 5: PartitionDataset answers the loader's batched fetch (__getitems__), the "
+                        "reference's per-sample __getitem__ + collate of 4096 rows is per_sample_loader_alone_us_per_step; "
+                        "DeviceResidentLoader is the resident form"}
             del model2, opt2, stock_loader, dset
         except Exception as ex:
             other_paths["stock_path"] = {"error": repr(ex)[:300]}

@@ -54,6 +54,71 @@ class PartitionDataset(MultiModDataset):
     def __getitem__(self, idx: int) -> Tuple[List[Tensor], np.ndarray]:
         return [Tensor(self.X[k][idx]) for k in range(self.n_partitions)], self.y[idx]
 
+    def __getitems__(self, indices) -> List["_Row"]:
+        """What torch's DataLoader calls for a whole batch of indices (torch >= 2.0; `Subset` forwards it): the rows are
+        gathered ONCE per partition instead of one `Tensor(...)` per sample and partition, and torch's default collate
+        recognises them (`_collate_rows`) and hands the gathered batch on as it is - the batch the per-sample path would
+        have stacked, element for element and dtype for dtype (tests/test_host_logic.py).  Under the reference's loop a
+        4096-row batch of four partitions took 79 ms of `__getitem__` + collate against 49 us for its training step
+        (`bench.py` `stock_path`).  A custom `collate_fn` still sees a list of samples: every `_Row` unpacks to
+        `(List[Tensor[F_k]], target row)` like `__getitem__`'s tuple."""
+        idx = np.asarray(indices, dtype=np.int64)
+        src = _BatchRows()
+        src.xs = [torch.from_numpy(np.ascontiguousarray(self.X[k][idx])).to(torch.float32) for k in range(self.n_partitions)]
+        src.y_np = self.y[idx]
+        src.y = torch.as_tensor(src.y_np)
+        src.n = int(idx.shape[0])
+        return [_Row(src, i) for i in range(src.n)]
+
+
+class _BatchRows:
+    """The rows one `PartitionDataset.__getitems__` call gathered."""
+    __slots__ = ("xs", "y", "y_np", "n")
+
+
+class _Row:
+    """Sample i of a `_BatchRows`: behaves like `__getitem__`'s `(List[Tensor[F_k]], target)` tuple where it is unpacked,
+    indexed or iterated; costs two references until then."""
+    __slots__ = ("src", "i")
+
+    def __init__(self, src: _BatchRows, i: int):
+        self.src, self.i = src, i
+
+    def __len__(self) -> int:
+        return 2
+
+    def __getitem__(self, k: int):
+        if k in (0, -2):
+            return [x[self.i] for x in self.src.xs]
+        if k in (1, -1):
+            return self.src.y_np[self.i]
+        raise IndexError(k)
+
+    def __iter__(self):
+        yield self[0]
+        yield self[1]
+
+
+def _collate_rows(batch, *, collate_fn_map=None):
+    """default_collate of `_Row` samples: the rows of ONE gathered batch in their order are that batch; anything else (rows of
+    several fetches, a re-ordered list) is collated sample by sample like the tuples they stand for."""
+    src = batch[0].src
+    if len(batch) == src.n and all(r.src is src and r.i == k for k, r in enumerate(batch)):
+        return [list(src.xs), src.y]
+    from torch.utils.data._utils.collate import default_collate
+    return default_collate([(r[0], r[1]) for r in batch])
+
+
+def _register_row_collate() -> None:
+    try:
+        from torch.utils.data._utils import collate as _c
+        _c.default_collate_fn_map[_Row] = _collate_rows
+    except (ImportError, AttributeError):                  # a torch without the registry: keep the per-sample path
+        PartitionDataset.__getitems__ = None
+
+
+_register_row_collate()
+
 
 class FeatureWiseDataset(PartitionDataset):
     def __init__(self, X: np.ndarray, y: np.ndarray):

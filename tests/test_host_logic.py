@@ -234,6 +234,42 @@ def test_partition_dataset_and_collate():
     assert len(mm.FeatureWiseDataset(X, y)[0][0]) == 5
 
 
+def test_partition_dataset_batched_fetch_equals_per_sample_collate():
+    """`PartitionDataset.__getitems__` (what torch's DataLoader calls per batch; datasets/multimod_dataset.py:55-88 has only
+    `__getitem__`): every batch equals - structure, dtypes, values, order under a seeded shuffle - what default_collate
+    makes of the per-sample items; through `Subset` (random_split), with a remainder batch, 1-D targets, worker processes,
+    and a custom collate_fn still sees `(List[Tensor], target)` samples."""
+    from torch.utils.data import DataLoader, Dataset
+    rng = np.random.default_rng(0)
+    X = rng.random((700, 10)); y = (rng.random((700, 3)) > 0.5).astype(np.int64)      # float64 features: items are float32 (Tensor(...))
+    ds = mm.PartitionDataset(X, y, [4, 6])
+
+    class PerSample(Dataset):                                # hides __getitems__: the reference's path
+        def __init__(self, d): self.d = d
+        def __len__(self): return len(self.d)
+        def __getitem__(self, i): return self.d[i]
+
+    def same(a, b):
+        assert type(a) is type(b) and type(a[0]) is type(b[0]) and len(a[0]) == len(b[0])
+        for u, v in zip(a[0], b[0]):
+            assert u.dtype == v.dtype and torch.equal(u, v)
+        assert a[1].dtype == b[1].dtype and torch.equal(a[1], b[1])
+    for kw in (dict(batch_size=256), dict(batch_size=64, shuffle=True), dict(batch_size=33, drop_last=True), dict(batch_size=128, num_workers=2)):
+        A = list(DataLoader(ds, generator=torch.Generator().manual_seed(3), **kw))
+        Bs = list(DataLoader(PerSample(ds), generator=torch.Generator().manual_seed(3), **kw))
+        assert len(A) == len(Bs)
+        for a, b in zip(A, Bs):
+            same(a, b)
+    sub = ds.random_split([0.7, 0.3], seed=1)[0]
+    same(next(iter(DataLoader(sub, batch_size=100))), next(iter(DataLoader(PerSample(sub), batch_size=100))))
+    ds1 = mm.PartitionDataset(X, y[:, 0], [10])
+    same(next(iter(DataLoader(ds1, batch_size=64))), next(iter(DataLoader(PerSample(ds1), batch_size=64))))
+    seen = next(iter(DataLoader(ds, batch_size=5, collate_fn=lambda samples: [(len(xs), tuple(xs[1].shape), tuple(t.shape)) for xs, t in samples])))
+    assert seen == [(2, (6,), (3,))] * 5
+    rows = ds.__getitems__([5, 2, 9])
+    assert torch.equal(rows[1][0][0], ds[2][0][0]) and np.array_equal(rows[2][1], ds[9][1]) and len(rows[0]) == 2
+
+
 def test_history_results_table(tmp_path):
     h = mm.MultiModNHistory(["a", "b"])
     h.state_change_loss.append(np.array([0.5, 0.25]))

@@ -3,6 +3,7 @@
 batch format train_epoch unpacks (multimodn.py:119)."""
 from abc import ABC, abstractmethod
 from itertools import accumulate
+from collections.abc import Sequence
 from typing import List, Optional, Tuple, Union
 
 import numpy as np
@@ -54,7 +55,7 @@ class PartitionDataset(MultiModDataset):
     def __getitem__(self, idx: int) -> Tuple[List[Tensor], np.ndarray]:
         return [Tensor(self.X[k][idx]) for k in range(self.n_partitions)], self.y[idx]
 
-    def __getitems__(self, indices) -> List["_Row"]:
+    def __getitems__(self, indices) -> "_Rows":
         """What torch's DataLoader calls for a whole batch of indices (torch >= 2.0; `Subset` forwards it): the rows are
         gathered ONCE per partition instead of one `Tensor(...)` per sample and partition, and torch's default collate
         recognises them (`_collate_rows`) and hands the gathered batch on as it is - the batch the per-sample path would
@@ -68,7 +69,7 @@ class PartitionDataset(MultiModDataset):
         src.y_np = self.y[idx]
         src.y = torch.as_tensor(src.y_np)
         src.n = int(idx.shape[0])
-        return [_Row(src, i) for i in range(src.n)]
+        return _Rows(src)
 
 
 class _BatchRows:
@@ -99,11 +100,32 @@ class _Row:
         yield self[1]
 
 
+class _Rows(Sequence):
+    """The samples of one gathered batch, in order, made when somebody asks for one (a 4096-row batch would otherwise cost 4096
+    objects that the default collate never looks at)."""
+    __slots__ = ("src",)
+
+    def __init__(self, src: _BatchRows):
+        self.src = src
+
+    def __len__(self) -> int:
+        return self.src.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [_Row(self.src, k) for k in range(*i.indices(self.src.n))]
+        if i < 0:
+            i += self.src.n
+        if not 0 <= i < self.src.n:
+            raise IndexError(i)
+        return _Row(self.src, i)
+
+
 def _collate_rows(batch, *, collate_fn_map=None):
     """default_collate of `_Row` samples: the rows of ONE gathered batch in their order are that batch; anything else (rows of
     several fetches, a re-ordered list) is collated sample by sample like the tuples they stand for."""
     src = batch[0].src
-    if len(batch) == src.n and all(r.src is src and r.i == k for k, r in enumerate(batch)):
+    if isinstance(batch, _Rows) or (len(batch) == src.n and all(r.src is src and r.i == k for k, r in enumerate(batch))):
         return [list(src.xs), src.y]
     from torch.utils.data._utils.collate import default_collate
     return default_collate([(r[0], r[1]) for r in batch])

@@ -61,7 +61,9 @@ class PartitionDataset(MultiModDataset):
         recognises them (`_collate_rows`) and hands the gathered batch on as it is - the batch the per-sample path would
         have stacked, element for element and dtype for dtype (tests/test_host_logic.py).  Under the reference's loop a
         4096-row batch of four partitions took 79 ms of `__getitem__` + collate against 49 us for its training step
-        (`bench.py` `stock_path`).  A custom `collate_fn` still sees a list of samples: every `_Row` unpacks to
+        (`bench.py` `stock_path`).  (Gathering whole rows of the undivided matrix with torch's index_select and cutting them into
+        partitions afterwards is 3x faster on 8 cores and 70x SLOWER on the 128-thread host of an MI355X box - torch's
+        intra-op pool on a 4 MB gather: measured, not kept.)  A custom `collate_fn` still sees a sequence of samples: every `_Row` unpacks to
         `(List[Tensor[F_k]], target row)` like `__getitem__`'s tuple."""
         idx = np.asarray(indices, dtype=np.int64)
         src = _BatchRows()

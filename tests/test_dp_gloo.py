@@ -264,19 +264,38 @@ def test_eight_rank_dp_with_uneven_shards_on_one_gpu(tmp_path):
     _assert_equals_golden(r0, g, 1e-5)
 
 
+def _spawn_eight_peers(monkeypatch, tmp_path, make_args, attempts=6):
+    """Eight one-shot peers on ONE GPU: eight compute processes are all the VMIDs a GPU has, so any ninth process with a
+    queue (this test's parent, a process of the previous test still exiting, a monitoring agent of the box) makes the driver
+    time-slice them - and a rank whose exchange kernel spins for a peer that is not on the GPU holds its slot meanwhile.
+    Measured on this pool: 1 run in ~8 ends, as designed, in MMN_ERR_PEER (the bounded wait), whatever the bound (5 s: 3 of 24;
+    120 s: 1 of 4 full-suite runs; with this wrapper 2 of 3 runs of this file needed a second attempt somewhere).  One process
+    per GPU - the product's layout - never shares VMIDs.  So: a 15 s bound, and a run that ended in MMN_ERR_PEER - and only
+    that - is repeated, up to six times, each in a directory of its own."""
+    monkeypatch.setenv("MMN_DP_SPIN_MS", "15000")
+    last = None
+    for attempt in range(attempts):
+        d = tmp_path / f"attempt{attempt}"
+        d.mkdir()
+        try:
+            mp.spawn(_gpu_worker, args=make_args(d), nprocs=8, join=True)
+            return d
+        except Exception as ex:                              # (mp.spawn re-raises the first failing rank's traceback as text)
+            if "PEER" not in str(ex) and "peer" not in str(ex):
+                raise
+            last = ex
+    raise last
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["c3_small", "nan_skip"])
 def test_oneshot_exchange_with_eight_peers(name, tmp_path, monkeypatch):
     """k_adam_accumulate_oneshot<8> with eight peers: every rank adds the eight buffers in rank order, so the replicas stay
     bit-identical; against the reference's golden run to the usual tolerances (gloo's all-reduce adds in another order, so
     bit-equality with the collective path holds for two ranks only); one all-reduce per EPOCH.
-    (Eight compute processes are all the VMIDs one GPU has: with a ninth process around - this test's parent, a process of
-    the previous test still exiting - the driver time-slices them and a rank can be off the GPU for seconds while its
-    peers' kernels wait for it.  Measured: 3 of 24 runs hit the default 5 s bound of the wait and ended, as designed, in
-    MMN_ERR_PEER.  One process per GPU - the product's layout - never shares VMIDs; here the bound is raised.)"""
-    monkeypatch.setenv("MMN_DP_SPIN_MS", "120000")
+    (Eight processes on one GPU: _spawn_eight_peers.)"""
     g = Golden(name)
-    mp.spawn(_gpu_worker, args=(8, _free_port(), name, "device", str(tmp_path), False, True), nprocs=8, join=True)
+    tmp_path = _spawn_eight_peers(monkeypatch, tmp_path, lambda d: (8, _free_port(), name, "device", str(d), False, True))
     r0 = _replicas_identical(tmp_path, 8)
     _check_oneshot_collectives(r0)
     _assert_equals_golden(r0, g, 1e-5)
@@ -290,9 +309,12 @@ def test_captured_groups_with_the_exchange_inside(world, oneshot, tmp_path, monk
     of torch's RCCL all-reduce is opt-in, MMN_DP_GRAPH=1, and needs a device per rank).  Every rank agrees on replay-or-
     eager through one MIN all-reduce per group key (engine._dp_capture_agreed); the replayed epoch must leave the
     reference's History and weights, and a graph must really have been replayed."""
-    monkeypatch.setenv("MMN_DP_SPIN_MS", "120000")           # (eight processes on one GPU: see test_oneshot_exchange_with_eight_peers)
     g = Golden("mlp_sigmoid")                                # (16-row batches and one of 8: every rank of eight keeps a row)
-    mp.spawn(_gpu_worker, args=(world, _free_port(), "mlp_sigmoid", "device", str(tmp_path), False, oneshot, None, True), nprocs=world, join=True)
+    args = lambda d: (world, _free_port(), "mlp_sigmoid", "device", str(d), False, oneshot, None, True)
+    if world == 8:                                           # (eight processes on one GPU: see _spawn_eight_peers)
+        tmp_path = _spawn_eight_peers(monkeypatch, tmp_path, args)
+    else:
+        mp.spawn(_gpu_worker, args=args(tmp_path), nprocs=world, join=True)
     r0 = _replicas_identical(tmp_path, world)
     assert int(r0["graph_hits"][0]) >= 1
     _assert_equals_golden(r0, g, 1e-5)

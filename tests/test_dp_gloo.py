@@ -283,6 +283,7 @@ def _spawn_eight_peers(monkeypatch, tmp_path, make_args, attempts=6):
         except Exception as ex:                              # (mp.spawn re-raises the first failing rank's traceback as text)
             if "PEER" not in str(ex) and "peer" not in str(ex):
                 raise
+            print(f"[eight peers] attempt {attempt + 1} ended in MMN_ERR_PEER: {str(ex)[-600:]}", flush=True)
             last = ex
     raise last
 

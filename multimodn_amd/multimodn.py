@@ -746,7 +746,10 @@ class MultiModN(nn.Module):
         if eng0 is not None and eng0.__dict__.get("_eps_rows", (None, 1))[1] == 0 and eng0._eps_rows[0] == eng0._plan.value:
             return None                                      # (this model is outside the kernel's shapes: said once per plan)
         seq = train_loader if isinstance(train_loader, (list, tuple)) else list(train_loader)
-        if not seq or len(seq) > 65536 or int(seq[0][1].shape[0]) > 64:
+        try:
+            if not seq or len(seq) > 65536 or int(seq[0][1].shape[0]) > 64:
+                return None
+        except (TypeError, IndexError, AttributeError, KeyError):     # (a batch format the general loop will have its own words for)
             return None
         cache = self.__dict__.setdefault("_small_epochs", {})
         key = (len(seq), id(seq[0]), id(seq[-1]))

@@ -204,3 +204,38 @@ def test_epoch_kernel_sees_new_optimizer_buffers_and_edited_batches(lib, monkeyp
     for (n, a), (_, b) in zip(m_k.named_parameters(), m_s.named_parameters()):
         a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
         assert np.abs(a - b).max() <= 2e-4 * max(np.abs(b).max(), 1e-3), n
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_epoch_kernel_random_shapes_against_step_path(lib, seed, monkeypatch):
+    """Seeded sweep over what the kernel's scope admits - 1 to 4 encoders of 0 to 3 hidden layers, any widths, state sizes
+    that are not multiples of anything, 1 to 4 decoders, batches of 1 to 64 rows with a ragged last one, NaN batches - two
+    epochs on both paths: History within 2e-5, Adam step counts equal."""
+    monkeypatch.setenv("MMN_EPOCH_KERNEL", "1")
+    rng = np.random.default_rng(500 + seed)
+    E = int(rng.integers(1, 5))
+    S = int(rng.choice([3, 8, 13, 16, 21, 32, 40]))
+    D = int(rng.integers(1, 5))
+    B = int(rng.choice([1, 5, 16, 17, 32, 47, 64]))
+    encs = []
+    for _ in range(E):
+        nh = int(rng.integers(0, 4))
+        H = tuple(int(rng.integers(1, 20)) for _ in range(nh))
+        act = int(rng.choice([O.ACT_RELU, O.ACT_SIGMOID, O.ACT_IDENTITY])) if H else O.ACT_IDENTITY
+        encs.append(O.EncoderSpec(int(rng.integers(1, 24)), H, act))
+    spec = O.ModelSpec(S, encs, D, float(rng.choice([0.7, 1.0])), float(rng.choice([0.0, 0.3, 1.0])))
+    nb = 7
+    batches = O.synthetic_batches(spec, nb * B - (B // 3), B, seed=seed)
+    for bi in rng.choice(nb, size=2, replace=False):
+        slot = int(rng.integers(0, E))
+        if batches[bi][0][slot].shape[0] > 0:
+            batches[bi][0][slot][0, 0] = np.nan
+    loader = _device_loader(batches)
+    m_k, h_k, st_k, _ = _run(lib, spec, loader, 2, True)
+    m_s, h_s, st_s, _ = _run(lib, spec, loader, 2, False)
+    if not m_k.__dict__.get("_small_epochs"):
+        pytest.skip("outside the kernel's scope (LDS image)")
+    assert st_k == st_s, (st_k, st_s)
+    for a, b in ((h_k.loss["train"], h_s.loss["train"]), (h_k.state_change_loss, h_s.state_change_loss)):
+        assert rel_err(np.stack(a), np.stack(b)) < 2e-5, (spec, B)
+    assert np.abs(np.stack(h_k.accuracy["train"]) - np.stack(h_s.accuracy["train"])).max() <= 2.0 / max(nb * B, 1)

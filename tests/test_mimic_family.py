@@ -43,16 +43,18 @@ def run_step(model, batch, masks=None, batch_global=None, nan_policy="host"):
     return stats, grads, executed
 
 
-@pytest.mark.parametrize("form", ["split", "split_genf2", "batched", "sequential"])
+@pytest.mark.parametrize("form", ["split", "split_2rows", "split_genf2", "batched", "sequential"])
 @pytest.mark.parametrize("name", MIMIC_GOLDEN_NAMES)
 def test_first_step_matches_reference_golden(lib, name, form, monkeypatch):
     """The forms of the generic tier.  "split": the default - at the MIMIC pipelines' encoder shape (mimic_c3_small) the chain is
-    k_mfwd / k_mbwd, the decoders run in k_dec_fb; "split_genf2": the same split with k_genf2_fwd / k_genf2_bwd kept as the
+    k_mfwd / k_mbwd, the decoders run in k_dec_fb; "split_2rows": k_dec_fb's two-grid-rows-per-workgroup form (round 5: measured
+    slower, opt-in, MMN_DEC_FB_ROWS=2); "split_genf2": the same split with k_genf2_fwd / k_genf2_bwd kept as the
     chain (MMN_MC=0); "batched": k_genf2_* with the decoders inside; "sequential": k_gen_* (what every model the batched
     forms do not take runs)."""
     monkeypatch.setenv("MMN_GEN_FAST", "0" if form == "sequential" else "1")
-    monkeypatch.setenv("MMN_GEN_BATCHED", "1" if form in ("batched", "split", "split_genf2") else "0")   # decoders of all grid rows at once (16-row tiles)
-    monkeypatch.setenv("MMN_GEN_SPLIT", "1" if form in ("split", "split_genf2") else "0")        # ... in a launch of their own (k_dec_fb)
+    monkeypatch.setenv("MMN_GEN_BATCHED", "1" if form in ("batched", "split", "split_2rows", "split_genf2") else "0")   # decoders of all grid rows at once (16-row tiles)
+    monkeypatch.setenv("MMN_GEN_SPLIT", "1" if form in ("split", "split_2rows", "split_genf2") else "0")        # ... in a launch of their own (k_dec_fb)
+    monkeypatch.setenv("MMN_DEC_FB_ROWS", "2" if form == "split_2rows" else "1")
     monkeypatch.setenv("MMN_MC", "0" if form == "split_genf2" else "1")
     g = Golden(name)
     model = build_torch_model(g.spec, g.init_params(), "cuda", lib)

@@ -92,3 +92,12 @@ if nr <= 94: sys.exit(0)
 g = raw[120:123]
 print("stats block: start -> partials summed", (g[0] - rd[94, 0]) / 100.0, "-> barrier", (g[1] - g[0]) / 100.0, "-> stats stored", (g[2] - g[1]) / 100.0,
       "-> end (epoch)", (rd[94, 1] - g[2]) / 100.0)
+
+# workgroup 200 (a work item in the middle of the launch order): start -> record and flags in -> loop set up -> rows walked ->
+# tile in LDS -> end (stamps 100, 101, 102, 110, 111 of the diagnostic buffer; its end = its entry of the per-workgroup table)
+ph = raw[[100, 101, 102, 110, 111]]
+if (ph > 0).all() and n > 200:
+    s200 = st[200, 0]
+    print("workgroup 200: " + " | ".join(f"{name} {(v - s200) / 100.0:.2f}" for name, v in
+                                         zip(("kernel body", "record in", "loop set up", "rows walked", "tile summed"), ph)) +
+          f" | end {(st[200, 1] - s200) / 100.0:.2f} us")

@@ -459,6 +459,8 @@ int mmn_dropout_adopt(mmn_plan* p, mmn_batch* b, const float* drop_p, float* buf
  *   `adam`: the optimizer state in the plan's flat layout (mmn_adam_fusable), updated in place, step counters included;
  *   adam->grads receives the LAST step's gradients.  Epoch sums accumulate onto mmn_epoch_read's doubles; the stats block
  *   holds the last step's values.  The chain kernels' weight copies are invalidated (mmn_pack_invalidate).
+ *   The first call of a plan - and the first one after the largest batch of the descriptors changed - uploads the step's tile
+ *   table (a few KB: hipMalloc + synchronous hipMemcpy, freed by mmn_plan_destroy): make that call outside a stream capture.
  * Errors: MMN_ERR_UNSUPPORTED (model / batch outside the scope above), MMN_ERR_ARG, MMN_ERR_HIP. */
 int mmn_epoch_small_rows(mmn_plan* p);
 int mmn_train_epoch_small(mmn_plan* p, const mmn_batch* batches_host, const mmn_batch* batches_dev, int n_batches,

@@ -166,6 +166,7 @@ class MultiModN(nn.Module):
         state["_batch_cache"] = {}
         state.pop("_eval_batch_cache", None)
         state["_epoch_plans"] = {}
+        state["_small_epochs"] = {}                          # (batch descriptors: ctypes structs with raw device pointers)
         state["_dp_group"] = None
         state["_dp_world"] = 1
         state["_dp_rank"] = 0

@@ -204,6 +204,14 @@ def test_epoch_kernel_sees_new_optimizer_buffers_and_edited_batches(lib, monkeyp
     for (n, a), (_, b) in zip(m_k.named_parameters(), m_s.named_parameters()):
         a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
         assert np.abs(a - b).max() <= 2e-4 * max(np.abs(b).max(), 1e-3), n
+    # the reference's pipelines pickle the whole model (titanic_mlp_pipeline.py:96): the path's descriptor cache stays behind
+    import copy
+    import pickle
+    m2 = pickle.loads(pickle.dumps(m_k))
+    m3 = copy.deepcopy(m_k)
+    for k, v in m_k.state_dict().items():
+        assert torch.equal(v.cpu(), m2.state_dict()[k].cpu()) and torch.equal(v.cpu(), m3.state_dict()[k].cpu()), k
+    assert not m2.__dict__.get("_small_epochs")
 
 
 @pytest.mark.parametrize("seed", list(range(16)))

@@ -290,3 +290,49 @@ def test_per_sample_mode_refuses_shapes_outside_its_kernels_up_front():
     model.per_sample = False                                 # the same model trains in batch mode (whole-batch semantics)
     clean = [([torch.from_numpy(np.nan_to_num(x)) for x in xs], torch.from_numpy(y))]
     model.train_epoch(clean, opt, torch.nn.CrossEntropyLoss(), lib.MultiModNHistory(["a", "b"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["mlp", "mimic"])
+def test_per_sample_stats_layouts_are_bitwise_equal(family, monkeypatch):
+    """Round 5: the step statistics of a per-sample batch - loss cells, counters and the ROW COUNTS per grid row, summed over
+    the tiles' sequence codes - are formed by one workgroup per 32 columns inside the k_wgrad launch (workgroup 0 counts the
+    rows); MMN_STATS_COLS=0 keeps the single stats workgroup, MMN_SIDE=0 round 4's layout inside k_reduce.  History (the
+    accuracies divide by the row counts) and trained weights must be identical bit for bit."""
+    mm.hip.load()
+    if family == "mlp":
+        spec, xs, y, seq = c5_like(9 * 48, E=4, seed=13)
+    else:
+        spec = O.ModelSpec(128, [O.EncoderSpec(24, (32, 20), O.ACT_RELU, kind="mimic", dropout=0.0) for _ in range(3)], 2, 1.0, 0.3,
+                           decoders=[O.DecoderSpec("mlp", (16,)) for _ in range(2)])
+        rng = np.random.default_rng(5)
+        xs, y = O.synthetic_batches(spec, 9 * 48, 9 * 48, seed=6)[0]
+        xs = [x.copy() for x in xs]
+        for e in range(3):
+            xs[e][rng.random(len(y)) < 0.3] = np.nan
+        seq = np.stack([rng.permutation(3) for _ in range(len(y))]).astype(np.int64)
+    params = O.init_params(spec, 2)
+    loader = [([torch.from_numpy(x[s:s + 48]).cuda() for x in xs], torch.from_numpy(y[s:s + 48]).cuda(), torch.from_numpy(seq[s:s + 48]).cuda())
+              for s in range(0, 9 * 48, 48)]
+
+    def train(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(7)
+        model = build_torch_model(spec, params, "cuda", mm)
+        model.per_sample = True
+        opt = mm.optim.Adam(list(model.parameters()), 1e-2)
+        hist = mm.MultiModNHistory(["a", "b", "c"][:spec.D])
+        for _ in range(3):
+            model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+        torch.cuda.synchronize()
+        return hist, {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
+    ref = train({"MMN_SIDE": "0", "MMN_STATS_COLS": "1"})
+    for env in ({"MMN_SIDE": "1", "MMN_STATS_COLS": "0"}, {"MMN_SIDE": "1", "MMN_STATS_COLS": "1"}):
+        got = train(env)
+        for ep in range(3):
+            for k in ("loss", "accuracy", "sensitivity", "specificity", "balanced_accuracy"):
+                assert np.array_equal(getattr(got[0], k)["train"][ep], getattr(ref[0], k)["train"][ep]), (env, k, ep)
+            assert np.array_equal(got[0].state_change_loss[ep], ref[0].state_change_loss[ep]), (env, ep)
+        for n in ref[1]:
+            assert np.array_equal(got[1][n], ref[1][n]), (env, n)

@@ -65,8 +65,12 @@ class PartitionDataset(MultiModDataset):
         partitions afterwards is 3x faster on 8 cores and 70x SLOWER on the 128-thread host of an MI355X box - torch's
         intra-op pool on a 4 MB gather: measured, not kept.)  A custom `collate_fn` still sees a sequence of samples: every `_Row` unpacks to
         `(List[Tensor[F_k]], target row)` like `__getitem__`'s tuple."""
-        if not isinstance(self.y, np.ndarray) or not all(isinstance(x, np.ndarray) for x in self.X):
-            return [self[i] for i in indices]               # (targets / partitions somebody replaced by another container: the samples themselves)
+        # (a subclass that overrides __getitem__ - transforms, augmentation, a third element per sample - must see every
+        #  sample: the reference has no __getitems__, its DataLoader always goes through __getitem__; likewise targets /
+        #  partitions somebody replaced by another container: the samples themselves)
+        if type(self).__getitem__ is not PartitionDataset.__getitem__ or not isinstance(self.y, np.ndarray) \
+                or not all(isinstance(x, np.ndarray) for x in self.X):
+            return [self[i] for i in indices]
         idx = np.asarray(indices, dtype=np.int64)
         src = _BatchRows()
         src.xs = [torch.from_numpy(np.ascontiguousarray(self.X[k][idx])).to(torch.float32) for k in range(self.n_partitions)]

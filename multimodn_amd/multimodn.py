@@ -752,6 +752,16 @@ class MultiModN(nn.Module):
                 return None
         except (TypeError, IndexError, AttributeError, KeyError):     # (a batch format the general loop will have its own words for)
             return None
+        try:
+            # (host batches never take this path: said HERE, before the engine is planned for `rows` and the first batch is
+            #  staged a second time only to find that out - ADVICE r5)
+            d0, y0 = seq[0][0], seq[0][1]
+            if not (isinstance(y0, Tensor) and y0.device.type == self.device.type and y0.dtype == torch.int64 and y0.is_contiguous()
+                    and all(isinstance(t, Tensor) and t.device.type == self.device.type and t.dtype == torch.float32
+                            and t.is_contiguous() for t in d0)):
+                return None
+        except (TypeError, IndexError, KeyError):
+            return None
         cache = self.__dict__.setdefault("_small_epochs", {})
         key = (len(seq), id(seq[0]), id(seq[-1]))
         ep = cache.get(key)

@@ -134,3 +134,27 @@ def test_dropout_entry_points_reject_null_arguments(lib):
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(hip.MmnError):
         hip.load(str(tmp_path / "libmmn_hip.so"))
+
+
+def test_repack_tasks_stay_inside_their_parameter_tensors(lib):
+    """Round 6 (the GPU abort of GPUTEST_r05): the decoders' shared backward operand Wdec^T was built by reading EVERY decoder's
+    output weight as [2 x S]; an MLPDecoder with hidden layers has [2 x last hidden width], so the repack read up to
+    2 S - 2 width floats past that tensor - past the end of the flat parameter buffer when the decoder is the model's last.
+    build_layout now checks every repack task against its tensor on the host (a task that would leave it yields no plan):
+    models with narrow-hidden MLPDecoders in last place must plan."""
+    for S, hidden in ((100, (8,)), (128, (32, 32)), (16, (12, 7, 9)), (4, (5,))):
+        m = hip.Model()
+        m.state_size, m.n_encoders, m.n_decoders = S, 2, 2
+        for e in range(2):
+            me = m.enc[e]
+            me.n_features, me.n_layers, me.activation, me.kind = 6, 2, hip.ACT_RELU, hip.ENC_MIMIC
+            me.layer[0].in_dim, me.layer[0].out_dim = 6 + S, 8
+            me.layer[1].in_dim, me.layer[1].out_dim = 8, S
+        m.dec[0].n_hidden = 0                                   # a ClassDecoder first, the MLPDecoder LAST in the flat buffer
+        md = m.dec[1]
+        md.n_hidden, md.hidden_activation = len(hidden), hip.ACT_RELU
+        a = S
+        for l, h in enumerate(hidden):
+            md.hidden[l].in_dim, md.hidden[l].out_dim = a, h
+            a = h
+        assert lib.mmn_workspace_bytes(C.byref(m), 64) > 0, (S, hidden)

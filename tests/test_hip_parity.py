@@ -260,15 +260,21 @@ def test_full_size_c3_five_adam_steps_within_fp32_noise(lib):
     print(f"compared {compared} tensors, {len(flipped)} crossed a relu kink: {sorted(flipped)}")
 
 
+@pytest.mark.parametrize("launch", ["step_path", "shipping_default"])
 @pytest.mark.parametrize("which", ["c1", "c2"])
-def test_titanic_configs_at_their_stated_sizes(lib, which):
+def test_titanic_configs_at_their_stated_sizes(lib, which, launch, monkeypatch):
     """BASELINE.json configs[0] / configs[1] at the sizes they state, through the public train_epoch: C1 = the Titanic MLP
     pipeline's shape (pipelines/titanic/titanic_mlp_pipeline.py:63-74: 570 training rows, batch 32 -> 17 full batches and
     one of 26 rows, E = 1, F = 6, H = (5, 5), S = 32, D = 1, Adam 0.01, penalties 0.7 / 0.3) for one whole epoch = 18 Adam
     steps; C2 = two encoders over the [3, 2] feature split (titanic_partitioned_pipeline.py:26-27), S = 64, D = 2, batch 512,
     5 Adam steps.  Against the numpy oracle's train_epoch on the same batches: History loss / state change 1e-5, the
     count ratios equal wherever the float64 replay has no near-tie, trained weights within fp32 noise of the float64
-    trajectory (assert_within_fp32_noise)."""
+    trajectory (assert_within_fp32_noise).
+    launch "shipping_default" (VERDICT r5): MMN_EPOCH_KERNEL as a user's process has it - unset - and the batches where a
+    DeviceResidentLoader keeps them: C1 then runs as ONE launch of k_epoch_small (checked), C2 (512 rows: outside that kernel)
+    the step path with replayed groups; "step_path": what the rest of this suite pins (tests/conftest.py)."""
+    if launch == "shipping_default":
+        monkeypatch.delenv("MMN_EPOCH_KERNEL", raising=False)
     if which == "c1":
         spec = O.ModelSpec(32, [O.EncoderSpec(6, (5, 5), O.ACT_RELU)], 1, 0.7, 0.3)
         rows, B, lr = 570, 32, 0.01
@@ -281,9 +287,12 @@ def test_titanic_configs_at_their_stated_sizes(lib, which):
     model = build_torch_model(spec, params, "cuda", lib)
     opt = lib.optim.Adam(model.parameters(), lr=lr)
     hist = lib.MultiModNHistory([f"t{d}" for d in range(spec.D)])
-    loader = [([torch.from_numpy(x) for x in xs], torch.from_numpy(y)) for xs, y in batches]
+    put = (lambda a: torch.from_numpy(a).cuda()) if launch == "shipping_default" else torch.from_numpy
+    loader = [([put(x) for x in xs], put(y)) for xs, y in batches]
     model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
     torch.cuda.synchronize()
+    if launch == "shipping_default":
+        assert bool(model.__dict__.get("_small_epochs")) == (which == "c1"), "C1 takes k_epoch_small by default, C2 does not fit it"
     p32 = {n: np.asarray(v, np.float32).copy() for n, v in params.items()}
     p64 = {n: np.asarray(v, np.float64) for n, v in params.items()}
     e32 = O.train_epoch(p32, spec, batches, O.Adam(lr))

@@ -269,6 +269,14 @@ def test_partition_dataset_batched_fetch_equals_per_sample_collate():
     rows = ds.__getitems__([5, 2, 9])
     assert torch.equal(rows[1][0][0], ds[2][0][0]) and np.array_equal(rows[2][1], ds[9][1]) and len(rows[0]) == 2
 
+    class Augmented(mm.PartitionDataset):                    # a user subclass that overrides __getitem__ must see every sample
+        def __getitem__(self, i):                            # (the batched fetch silently bypassed it)
+            xs, t = super().__getitem__(i)
+            return [x * 2 for x in xs], t, np.int64(i)
+    aug = Augmented(X, y, [4, 6])
+    xs2, t2, idx = next(iter(DataLoader(aug, batch_size=8)))
+    assert idx.tolist() == list(range(8)) and torch.equal(xs2[0], 2 * next(iter(DataLoader(ds, batch_size=8)))[0][0])
+
 
 def test_history_results_table(tmp_path):
     h = mm.MultiModNHistory(["a", "b"])

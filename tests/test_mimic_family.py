@@ -6,6 +6,8 @@ dropout masks recorded from the reference's own nn.Dropout draws) and against th
 Tolerances as in tests/test_hip_parity.py: loss / grid 1e-5 relative, integer counters exact, gradients 2e-5 of
 the tensor's max |g| (5e-5 at batch 4096 against the fp64 oracle: 4096-term sums in another order), trained
 weights 2e-5 of max |w| or within 4x the reference's own distance from the fp64 replay (helpers.assert_within_fp32_noise)."""
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -26,11 +28,16 @@ def mask_provider(masks):
     return provide
 
 
-def run_step(model, batch, masks=None, batch_global=None, nan_policy="host"):
+def run_step(model, batch, masks=None, batch_global=None, nan_policy="host", device_inputs=False):
+    """device_inputs: every data slot its own device tensor (the host path packs a batch's slots into one staging buffer;
+    under tests/efence a slot of its own stands flush against unmapped memory)."""
     model.nan_policy = nan_policy
     model.dropout_mask_provider = mask_provider(masks or {})
     data = [torch.from_numpy(np.ascontiguousarray(x)) for x in batch[0]]
     target = torch.from_numpy(np.ascontiguousarray(batch[1]))
+    if device_inputs:
+        data = [x.cuda() for x in data]
+        target = target.cuda()
     seq = torch.from_numpy(batch[2]) if len(batch) > 2 else None
     eng = model._get_engine(target.shape[0])
     eng.epoch_reset()
@@ -647,7 +654,7 @@ def test_random_aligned_models_against_oracle(lib, seed, monkeypatch):
     _sweep_case(lib, seed, aligned=True)
 
 
-def _sweep_case(lib, seed, aligned):
+def _sweep_case(lib, seed, aligned, device_inputs=False):
     rng = np.random.default_rng(5000 + seed)
     all_mimic = aligned or seed % 3 != 0
     E = int(rng.integers(1, 6 if aligned else 9))
@@ -684,7 +691,10 @@ def _sweep_case(lib, seed, aligned):
     masks = {e: ((rng.random((B, enc.n_features + S)) >= enc.dropout) / (1 - enc.dropout)).astype(np.float32)
              for e, enc in enumerate(encs) if enc.dropout > 0}
     model = build_torch_model(spec, params, "cuda", lib)
-    stats, grads, _ = run_step(model, batch, masks)
+    print(f"[sweep] seed {seed} aligned {int(aligned)}: E {E} S {S} D {D} B {B} order {order.tolist()} encoders "
+          f"{[(e.kind, e.n_features, tuple(e.hidden), e.dropout) for e in encs]} decoders {[(d.kind, tuple(d.hidden)) for d in decs]}",
+          file=sys.stderr, flush=True)                        # (a fault kills the process: the tail of stderr names the case)
+    stats, grads, _ = run_step(model, batch, masks, device_inputs=device_inputs)
     import ctypes as C
     eng = model._get_engine(B)
     probe = eng.make_batch([torch.zeros(B, e.n_features, device="cuda") for e in encs],

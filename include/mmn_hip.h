@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MMN_VERSION 112            /* 0.1.12: mmn_epoch_small_rows / mmn_train_epoch_small (a whole epoch of small batches as one launch); 0.1.11: mmn_wgrad_reduce (the second half of mmn_train_step_ex on its own: k_wgrad with the stats block in its launch, then k_reduce as gradient blocks only); 0.1.10: mmn_regroup_multi (the batches of a captured per-sample group regrouped by one set of launches); 0.1.9: one-shot data-parallel exchange (mmn_dp_xbuf_*, mmn_dp_oneshot_*, mmn_adam_step_accumulate_oneshot, MMN_ERR_PEER); 0.1.8: mmn_source_hash (a library that was not built from the sources next to it does not load); 0.1.7: mmn_eval_step_ex (test(): outputs and row flag of a step collected by the call); 0.1.6: mmn_dp_rescale (uneven data-parallel shards);
+#define MMN_VERSION 113            /* 0.1.13: mmn_model.flags / MMN_MODEL_GENERIC_TIER + mmn_per_sample_supported (per-sample mode for every MLPEncoder shape), mmn_dp_oneshot_detach (a plan that is really "not attached" again: the refused-attach path and detach close the peers' buffers, the plan must not keep their addresses); 0.1.12: mmn_epoch_small_rows / mmn_train_epoch_small (a whole epoch of small batches as one launch); 0.1.11: mmn_wgrad_reduce (the second half of mmn_train_step_ex on its own: k_wgrad with the stats block in its launch, then k_reduce as gradient blocks only); 0.1.10: mmn_regroup_multi (the batches of a captured per-sample group regrouped by one set of launches); 0.1.9: one-shot data-parallel exchange (mmn_dp_xbuf_*, mmn_dp_oneshot_*, mmn_adam_step_accumulate_oneshot, MMN_ERR_PEER); 0.1.8: mmn_source_hash (a library that was not built from the sources next to it does not load); 0.1.7: mmn_eval_step_ex (test(): outputs and row flag of a step collected by the call); 0.1.6: mmn_dp_rescale (uneven data-parallel shards);
                                       0.1.5: mmn_step_opts.next_drop_* (the next step's dropout multipliers in this step's last launch), mmn_dropout_adopt;
                                       0.1.4: mmn_train_step_ex (pre-scan of the next batch, flag sets in the stats block), mmn_pack_invalidate;
                                       0.1.3: + mmn_draw_dropout; 0.1.2: MIMIC_MLPEncoder / MLPDecoder (mmn_encoder.kind, mmn_decoder.hidden, mmn_batch.drop_mask) */
@@ -120,11 +120,17 @@ typedef struct mmn_decoder {
 
 /* MultiModN(state_size, encoders, decoders, ...) with TrainableInitState
  * (multimodn.py:66-87, state.py:19-32). */
+/* mmn_model.flags.  MMN_MODEL_GENERIC_TIER: plan the generic tier's kernels (k_gen_fwd / k_gen_bwd: any mix of encoder / decoder
+ * kinds and widths) also for a model the fused MLPEncoder kernels would take.  What per-sample mode (mmn_regroup*, BASELINE
+ * configs[4]) needs for MLPEncoder models OUTSIDE the fused kernel's tiled form (n_features > 64 or hidden widths > 32):
+ * the reference runs any shape at batch size 1 (multimodn/multimodn.py:509-531); mmn_per_sample_supported(plan) says
+ * whether a plan takes per-sample batches as it is. */
+#define MMN_MODEL_GENERIC_TIER 1
 typedef struct mmn_model {
     int32_t state_size;
     int32_t n_encoders;
     int32_t n_decoders;
-    int32_t reserved;
+    int32_t flags;                 /* MMN_MODEL_* (ABI 113; was `reserved`, 0) */
     const float* init_state;       /* [S]  (init_state.state_value) */
     float* g_init_state;           /* [S] */
     mmn_encoder enc[MMN_MAX_ENCODERS];
@@ -398,6 +404,15 @@ int mmn_dp_xbuf_open(const void* handle64, void** dev_ptr);
 int mmn_dp_xbuf_close(void* dev_ptr, int own);
 int mmn_dp_oneshot_attach(mmn_plan* p, int world, int rank, void* const* xbufs, int spin_ms);
 int mmn_dp_oneshot_error(mmn_plan* p);
+/* The plan forgets the exchange buffers (and frees its step counters / error words): to be called BEFORE the buffers are
+ * closed (mmn_dp_xbuf_close) - when an attach was refused by a peer, or on detach.  Waits for the device first: an exchange
+ * kernel may still be running.  mmn_adam_step_accumulate_oneshot returns MMN_ERR_ARG afterwards until the next attach. */
+int mmn_dp_oneshot_detach(mmn_plan* p);
+
+/* 1 if this plan runs per-sample batches (mmn_batch.tile_rows / tile_seq from mmn_regroup*): the fused kernel's tiled form
+ * (MLPEncoder family, n_features <= 64, hidden widths <= 32), or the generic tier's (MIMIC modules, and any model planned
+ * with MMN_MODEL_GENERIC_TIER); at most 4 encoders.  0: mmn_regroup* return MMN_ERR_UNSUPPORTED.  (ABI 113) */
+int mmn_per_sample_supported(const mmn_plan* p);
 int mmn_adam_step_accumulate_oneshot(mmn_plan* p, const mmn_adam* d, float err_penalty, float state_change_penalty_x001,
                                      void* stream);
 

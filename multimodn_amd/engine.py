@@ -81,9 +81,9 @@ def check_criterion(criterion) -> None:
 
 
 PER_SAMPLE_SCOPE = ("per-sample mode (per-sample missing modalities / encoder order, BASELINE configs[4]) runs models of at most 4 "
-                    "encoders that are either MLPEncoder-family encoders with n_features <= 64 and hidden widths <= 32 under "
-                    "ClassDecoder / LogisticDecoder heads (the fused chain kernel's tiled form), or MIMIC_MLPEncoder / MLPDecoder "
-                    "models; this model is outside that set - there is no slower fallback behind the same surface")
+                    "encoders (MLPEncoder family with n_features <= 64 and hidden widths <= 32: the fused chain kernel's tiled form; "
+                    "every other MLPEncoder / MIMIC_MLPEncoder / MLPDecoder shape: the generic tier's tiled forms); this model is "
+                    "outside that set")
 
 
 def _check_regroup(rc: int, what: str) -> None:
@@ -112,6 +112,7 @@ class HipChainEngine:
         self._flatten_params()
         self.n_params = self.flat_params.numel()
         self._torch_regroup = False          # tests: force the torch-op regrouping of per-sample mode
+        self._generic_tier = False           # plan the generic tier's kernels (per-sample mode of MLPEncoder shapes outside k_fb9's)
         self._build(max_batch)
 
     # ------------------------------------------------------------------ buffers and plan
@@ -135,6 +136,7 @@ class HipChainEngine:
         m.state_size = model.init_state.state_size
         m.n_encoders = len(model.encoders)
         m.n_decoders = len(model.decoders)
+        m.flags = hip.MODEL_GENERIC_TIER if self._generic_tier else 0
         n_stats_probe = None
         # reduce buffer = [flat grads | stats] so that data-parallel needs ONE all-reduce
         # (stats size needs the model dims only)
@@ -231,6 +233,40 @@ class HipChainEngine:
         except Exception:
             pass
 
+    def set_per_sample(self, on: bool) -> bool:
+        """Per-sample mode (MultiModN.per_sample, BASELINE configs[4]) needs a plan whose chain kernels take regrouped tiles:
+        the fused kernel's tiled form (MLPEncoder models with n_features <= 64 and hidden widths <= 32), the MIMIC modules'
+        kernels - or, for every other MLPEncoder shape, the generic tier's sequential tiled form, which a plan only has when
+        it is asked for (mmn_model.flags, MMN_MODEL_GENERIC_TIER): the reference runs ANY shape at batch size 1
+        (multimodn/multimodn.py:509-531, pipelines/titanic/titanic_missingness_pipeline.py), so per-sample mode must too.
+        Re-plans when the answer changes (the running epoch's sums are carried over).  Returns True if it re-planned."""
+        want = False
+        if on and not self.lib.mmn_per_sample_supported(self._plan):
+            want = True
+        elif on and self._generic_tier:
+            want = True                                      # (stays: the default plan of this model did not take per-sample batches)
+        if want == self._generic_tier:
+            return False
+        self._generic_tier = want
+        self._replan(self.max_batch)
+        if on and not self.lib.mmn_per_sample_supported(self._plan):
+            self._generic_tier = False                      # (no tier takes it - more than 4 encoders, LDS: say so; ordinary batches keep their plan)
+            self._replan(self.max_batch)
+            raise UnsupportedModelError(PER_SAMPLE_SCOPE)
+        return True
+
+    def _replan(self, max_batch: int) -> None:
+        # a new plan starts with empty epoch accumulators: carry the running epoch's sums over (a batch larger than
+        # every earlier one may arrive in the middle of an epoch: variable batch samplers, per-sample mode)
+        carried = np.zeros(self.n_epoch, np.float64)
+        hip.check(self.lib.mmn_epoch_read(self._plan, carried.ctypes.data_as(C.POINTER(C.c_double)), self._stream()),
+                  "mmn_epoch_read")
+        self.lib.mmn_plan_destroy(self._plan)
+        self._plan = None
+        self._build(max_batch)
+        hip.check(self.lib.mmn_epoch_write(self._plan, carried.ctypes.data_as(C.POINTER(C.c_double)), self._stream()),
+                  "mmn_epoch_write")
+
     def ensure(self, batch: int) -> bool:
         """Re-plan if the batch outgrew the workspace or the parameters moved (model.to(), ...).  Returns True if it
         did: hip.Batch structs made before hold pointers into the old plan."""
@@ -238,16 +274,7 @@ class HipChainEngine:
         if moved:
             self._flatten_params()
         if moved or batch > self.max_batch:
-            # a new plan starts with empty epoch accumulators: carry the running epoch's sums over (a batch larger than
-            # every earlier one may arrive in the middle of an epoch: variable batch samplers, per-sample mode)
-            carried = np.zeros(self.n_epoch, np.float64)
-            hip.check(self.lib.mmn_epoch_read(self._plan, carried.ctypes.data_as(C.POINTER(C.c_double)), self._stream()),
-                      "mmn_epoch_read")
-            self.lib.mmn_plan_destroy(self._plan)
-            self._plan = None
-            self._build(max(batch, self.max_batch))
-            hip.check(self.lib.mmn_epoch_write(self._plan, carried.ctypes.data_as(C.POINTER(C.c_double)), self._stream()),
-                      "mmn_epoch_write")
+            self._replan(max(batch, self.max_batch))
             return True
         return False
 
@@ -942,7 +969,8 @@ class HipChainEngine:
         verdict = [None] * world
         dist.all_gather_object(verdict, bool(ok), group=group)     # (doubles as the barrier: nobody steps before everybody has mapped everything)
         if not all(verdict):
-            for ptr in opened:
+            self.lib.mmn_dp_oneshot_detach(self._plan)          # (this rank's attach may have succeeded: the plan must not keep
+            for ptr in opened:                                  #  the addresses of buffers that are closed below)
                 self.lib.mmn_dp_xbuf_close(ptr, 0)
             if own.value:
                 self.lib.mmn_dp_xbuf_close(own.value, 1)
@@ -959,6 +987,8 @@ class HipChainEngine:
             return
         if torch.cuda.is_available():
             torch.cuda.synchronize()
+        if self._plan is not None and st["plan"] == self._plan.value:
+            self.lib.mmn_dp_oneshot_detach(self._plan)
         for r, ptr in enumerate(st["ptrs"]):
             self.lib.mmn_dp_xbuf_close(ptr, 1 if r == st["rank"] else 0)
 

@@ -17,9 +17,10 @@ MAX_LAYERS = 8
 MAX_DIM = 128
 ADAM_MAX_SEG = 512
 ERR_UNSUPPORTED = -2
-VERSION = 112
+VERSION = 113
 MAX_DEC_HIDDEN = 3
 ENC_MLP, ENC_MIMIC = 0, 1
+MODEL_GENERIC_TIER = 1      # mmn_model.flags (include/mmn_hip.h)
 
 ACT_IDENTITY, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
@@ -37,7 +38,7 @@ ABI_SYMBOLS = (
     "mmn_nan_flags_set", "mmn_pack_invalidate", "mmn_pack_refresh", "mmn_train_step_ex", "mmn_epoch_write", "mmn_adam_fusable", "mmn_regroup_ex", "mmn_dp_rescale", "mmn_eval_step_ex",
     "mmn_dp_xbuf_bytes", "mmn_dp_xbuf_alloc", "mmn_dp_xbuf_open", "mmn_dp_xbuf_close", "mmn_dp_oneshot_attach",
     "mmn_dp_oneshot_error", "mmn_adam_step_accumulate_oneshot", "mmn_regroup_multi", "mmn_wgrad_reduce",
-    "mmn_epoch_small_rows", "mmn_train_epoch_small",
+    "mmn_epoch_small_rows", "mmn_train_epoch_small", "mmn_dp_oneshot_detach", "mmn_per_sample_supported",
 )
 
 
@@ -58,7 +59,7 @@ class Decoder(C.Structure):
 
 class Model(C.Structure):
     _fields_ = [("state_size", C.c_int32), ("n_encoders", C.c_int32), ("n_decoders", C.c_int32),
-                ("reserved", C.c_int32), ("init_state", C.c_void_p), ("g_init_state", C.c_void_p),
+                ("flags", C.c_int32), ("init_state", C.c_void_p), ("g_init_state", C.c_void_p),
                 ("enc", Encoder * MAX_ENCODERS), ("dec", Decoder * MAX_DECODERS)]
 
 
@@ -178,6 +179,10 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_dp_oneshot_attach.argtypes = [vp, i32, i32, C.POINTER(vp), i32]
     lib.mmn_dp_oneshot_error.restype = i32
     lib.mmn_dp_oneshot_error.argtypes = [vp]
+    lib.mmn_dp_oneshot_detach.restype = i32
+    lib.mmn_dp_oneshot_detach.argtypes = [vp]
+    lib.mmn_per_sample_supported.restype = i32
+    lib.mmn_per_sample_supported.argtypes = [vp]
     lib.mmn_adam_step_accumulate_oneshot.restype = i32
     lib.mmn_adam_step_accumulate_oneshot.argtypes = [vp, C.POINTER(AdamDesc), f32, f32, vp]
     lib.mmn_dp_rescale.restype = i32

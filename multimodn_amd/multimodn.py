@@ -206,6 +206,8 @@ class MultiModN(nn.Module):
         if self._engine is None:
             self._engine = self._engine_factory(self, max(int(batch), 1))
         self._engine.ensure(int(batch))
+        if hasattr(self._engine, "set_per_sample") and (self.per_sample or self._engine._generic_tier):
+            self._engine.set_per_sample(bool(self.per_sample))   # (a plan whose kernels take regrouped tiles; re-plans when that changes)
         # data parallel: every rank draws ITS rows' dropout multipliers from its own stream (same torch seed on all
         # ranks is the usual discipline; identical multipliers on different rows would correlate the shards)
         self._engine.dropout_salt = int(getattr(self, "_dp_rank", 0)) if self._dp_group is not None else 0
@@ -770,7 +772,10 @@ class MultiModN(nn.Module):
             if not (ep["opt"] is optimizer and ep["eng"] is self._engine and all(map(operator.is_, seq, ep["batches"]))
                     and all(map(operator.is_, map(operator.itemgetter(1), seq), ep["ys"])) and list(map(len, datas)) == ep["lens"]
                     and all(map(operator.is_, itertools.chain.from_iterable(datas), ep["xs"]))
-                    and (max(map(len, seq)) == 2 or all(len(b_) == 2 or b_[2] is None for b_ in seq))):
+                    and (max(map(len, seq)) == 2 or all(len(b_) == 2 or b_[2] is None for b_ in seq))
+                    # (the descriptors hold ADDRESSES: `x.set_(...)` / `x.data = ...` on a cached batch keeps the object and moves
+                    #  its storage - a few microseconds once per call)
+                    and [t.data_ptr() for t in ep["xs"]] + [t.data_ptr() for t in ep["ys"]] == ep["ptrs"]):
                 cache.pop(key, None)
                 ep = None
         rows = ep["rows"] if ep is not None else max(int(b_[1].shape[0]) for b_ in seq)
@@ -805,7 +810,8 @@ class MultiModN(nn.Module):
             if len(cache) >= 4:
                 cache.pop(next(iter(cache)))
             ep = cache[key] = {"batches": list(seq), "ys": ys, "xs": xs_all, "lens": lens, "host": host, "dev": dev, "rows": rows,
-                               "opt": optimizer, "eng": eng, "plan": eng._plan.value}
+                               "opt": optimizer, "eng": eng, "plan": eng._plan.value,
+                               "ptrs": [t.data_ptr() for t in xs_all] + [t.data_ptr() for t in ys]}
         eng.epoch_reset()
         rc = eng.lib.mmn_train_epoch_small(eng._plan, ep["host"], ep["dev"].data_ptr(), len(seq), float(self.err_penalty),
                                            float(self.state_change_penalty), C.byref(fd), eng._stream())

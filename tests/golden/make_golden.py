@@ -171,6 +171,9 @@ CONFIGS = {
 # means over the N samples are what oracle.per_sample_step and the HIP per-sample step must reproduce for the N-row batch.
 PER_SAMPLE_B1 = {
     "per_sample_b1_mlp": dict(F=[6, 6, 6], H=(8, 8), S=16, D=2, N=32, pen=(1.0, 0.5), act="relu", p_missing=0.3),
+    # an MLPEncoder shape OUTSIDE the fused kernel's tiled form (n_features 72 > 64, hidden 48 > 32): the generic tier's tiled
+    # form runs it (round 6, VERDICT r5 #8: per-sample mode for every MLPEncoder shape)
+    "per_sample_b1_wide": dict(F=[72, 72, 72], H=(48,), S=24, D=2, N=32, pen=(1.0, 0.5), act="relu", p_missing=0.3),
     "per_sample_b1_mimic": dict(F=[6, 6, 6], H=(8,), S=16, D=2, N=32, pen=(1.0, 0.5), act="relu", p_missing=0.3,
                                 enc_kinds=["mimic"] * 3, dropout=0.2, dec=[("mlp", (6,)), ("mlp", (6,))]),
 }

@@ -64,7 +64,7 @@ class Golden:
         return f"step{s}/grad_none" in self.z.files
 
 
-PER_SAMPLE_B1_NAMES = ["per_sample_b1_mlp", "per_sample_b1_mimic"]
+PER_SAMPLE_B1_NAMES = ["per_sample_b1_mlp", "per_sample_b1_mimic", "per_sample_b1_wide"]
 
 
 class PerSampleGolden:

@@ -36,12 +36,72 @@ def _mask(step, e, width, p):
     return ((rng.random((B, width), dtype=np.float32) >= p) / np.float32(1.0 - p)).astype(np.float32)
 
 
+def _replay_job(family, dtype_name):
+    """The numpy oracle's replay of the 192 Adam steps (CPU only; runs in a worker process): (final params, EpochResults)."""
+    dtype = np.dtype(dtype_name).type
+    spec = _spec(family)
+    params = O.init_params(spec, 0)
+    batches = O.synthetic_batches(spec, STEPS * B, B, seed=23)
+    mimic = family == "mimic"
+    p = {n: np.asarray(v, dtype).copy() for n, v in params.items()}
+    o = O.Adam(1e-3)
+    eps = []
+    for ep in range(EPOCHS):
+        masks = None
+        if mimic:
+            masks = [{e: _mask(ep * STEPS + s, e, enc.n_features + spec.state_size, 0.2) for e, enc in enumerate(spec.encoders)}
+                     for s in range(STEPS)]
+        eps.append(O.train_epoch(p, spec, batches, o, dtype=dtype, drop_masks=masks))
+    return p, eps
+
+
+# The four replays (two families x float64 / float32) are 50 - 80 s of single-threaded numpy EACH: they run side by side in
+# worker processes (spawned: this process holds a GPU context; the workers never touch the GPU), started by whichever case
+# runs first, while the GPU side trains - the suite's longest test went from 210 s of waiting to the longest single replay.
+_POOL, _FUTS = None, {}
+
+
+def _replays(family):
+    global _POOL
+    if _POOL is None:
+        import concurrent.futures as cf
+        import multiprocessing as mp
+        import os
+        # (the workers inherit the environment at their start: a handful of BLAS threads each - the oracle's products are
+        #  [4096 x 64] x [64 x 32]-sized, on a 128-thread host numpy's default pool makes them slower, not faster)
+        keys = ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")
+        saved = {k: os.environ.get(k) for k in keys}
+        for k in keys:
+            os.environ[k] = "4"
+        try:
+            _POOL = cf.ProcessPoolExecutor(4, mp_context=mp.get_context("spawn"))
+            for fam in ("c3", "mimic"):
+                for dt in ("float64", "float32"):
+                    _FUTS[(fam, dt)] = _POOL.submit(_replay_job, fam, dt)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return _FUTS[(family, "float64")], _FUTS[(family, "float32")]
+
+
+def teardown_module(module):
+    global _POOL
+    if _POOL is not None:
+        _POOL.shutdown(wait=False, cancel_futures=True)
+        _POOL = None
+        _FUTS.clear()
+
+
 @pytest.mark.parametrize("family", ["c3", "mimic"])
 def test_loss_curves_at_full_size(lib, family):
     spec = _spec(family)
     params = O.init_params(spec, 0)
     batches = O.synthetic_batches(spec, STEPS * B, B, seed=23)
     mimic = family == "mimic"
+    f64, f32 = _replays(family)                              # (the CPU replays start now, next to the GPU's training)
     model = build_torch_model(spec, params, "cuda", lib)
     opt = lib.optim.Adam(model.parameters(), lr=1e-3)
     hist = lib.MultiModNHistory([f"t{d}" for d in range(spec.D)])
@@ -52,19 +112,8 @@ def test_loss_curves_at_full_size(lib, family):
         model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
     torch.cuda.synchronize()
 
-    def replay(dtype):
-        p = {n: np.asarray(v, dtype).copy() for n, v in params.items()}
-        o = O.Adam(1e-3)
-        eps = []
-        for ep in range(EPOCHS):
-            masks = None
-            if mimic:
-                masks = [{e: _mask(ep * STEPS + s, e, enc.n_features + spec.state_size, 0.2) for e, enc in enumerate(spec.encoders)}
-                         for s in range(STEPS)]
-            eps.append(O.train_epoch(p, spec, batches, o, dtype=dtype, drop_masks=masks))
-        return p, eps
-    p64, e64 = replay(np.float64)
-    p32, e32 = replay(np.float32)
+    p64, e64 = f64.result()
+    p32, e32 = f32.result()
     report = []
     for ep in range(EPOCHS):
         dl = rel_err(hist.loss["train"][ep], e64[ep].loss)

@@ -271,25 +271,79 @@ def test_per_sample_forward_only_entry_points():
 
 
 @pytest.mark.gpu
-def test_per_sample_mode_refuses_shapes_outside_its_kernels_up_front():
-    """an MLPEncoder model wider than the fused kernel's tiled form takes (hidden width 48 > 32) used to pass the
-    regrouping and fail inside the step with a bare MMN_ERR_UNSUPPORTED.  It is refused where the rows would be regrouped,
-    with a message that says what per-sample mode covers - and nothing has been launched or changed by then."""
+def test_per_sample_step_of_a_wide_model_matches_the_reference_run_at_batch_size_one():
+    """tests/golden/per_sample_b1_wide.npz (round 6): an MLPEncoder model OUTSIDE the fused kernel's tiled form
+    (72 features > 64, hidden 48 > 32) - the reference runs any shape at batch size 1 (multimodn/multimodn.py:509-531).  The
+    engine plans the generic tier for it (mmn_model.flags, MMN_MODEL_GENERIC_TIER) and the step over the 32 rows as ONE batch
+    gives the means of the reference's 32 one-sample results."""
+    mm.hip.load()
+    g = PerSampleGolden("per_sample_b1_wide")
+    model = build_torch_model(g.spec, g.init_params(), "cuda", mm)
+    stats, grads = run_step(model, g.xs, g.y, g.seq)
+    assert model._engine._generic_tier and mm.hip.load().mmn_per_sample_supported(model._engine._plan)
+    g.check(stats["err_loss"], stats["state_change"], stats["loss"], stats["rows"], grads)
+    n = 1.0 + stats["rows"].astype(np.float64)[:, None]
+    assert np.array_equal(stats["n_correct"] / n, g.z["hist/accuracy"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [dict(F=100, H=(64,), S=64), dict(F=8, H=(48, 16), S=32), dict(F=33, H=(), S=20), dict(F=128, H=(64, 64), S=128)])
+def test_per_sample_mode_runs_every_mlp_encoder_shape(shape):
+    """Per-sample steps of MLPEncoder shapes the fused kernel's tiled form does not take (wide features, wide / odd hidden
+    layers, no hidden layer, a state that is no multiple of 16) against the oracle's loop over the samples; a model INSIDE
+    the fused kernel's shapes keeps its plan (no generic tier)."""
+    mm.hip.load()
+    spec, xs, y, seq = c5_like(70, E=3, F=shape["F"], S=shape["S"], H=shape["H"], seed=5)
+    params = O.init_params(spec, 2)
+    model = build_torch_model(spec, params, "cuda", mm)
+    stats, grads = run_step(model, xs, y, seq)
+    assert model._engine._generic_tier
+    check(stats, grads, O.per_sample_step(params, spec, xs, y, seq), tolg=3e-5)
+    lean = build_torch_model(*(lambda sp: (sp, O.init_params(sp, 2)))(c5_like(16, E=2, seed=1)[0]), "cuda", mm)
+    lean.per_sample = True
+    assert not lean._get_engine(16)._generic_tier
+
+
+@pytest.mark.gpu
+def test_per_sample_training_of_a_wide_model_and_back_to_batch_mode():
+    """ADVICE r4 / VERDICT r5 #8: the wide MLPEncoder model that per-sample mode used to refuse trains through the public
+    train_epoch (host batches, fused Adam; the loss falls), evaluates, and - per_sample switched off again - trains in batch mode
+    on its default plan (whole-batch semantics)."""
     lib = mm
-    from multimodn_amd.engine import UnsupportedModelError
-    spec, xs, y, seq = c5_like(48, H=(48,), seed=2)
+    spec, xs, y, seq = c5_like(96, H=(48,), seed=2)
     model = build_torch_model(spec, O.init_params(spec, 1), "cuda", lib)
     model.per_sample = True
     opt = lib.optim.Adam(list(model.parameters()), 1e-2)
-    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    loader = [([torch.from_numpy(x) for x in xs], torch.from_numpy(y), torch.from_numpy(seq))]
-    with pytest.raises(UnsupportedModelError, match="per-sample mode"):
-        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), lib.MultiModNHistory(["a", "b"]))
-    for k, v in model.state_dict().items():
-        assert torch.equal(v, before[k]), k
+    hist = lib.MultiModNHistory(["a", "b"])
+    loader = [([torch.from_numpy(x[s:s + 48]) for x in xs], torch.from_numpy(y[s:s + 48]), torch.from_numpy(seq[s:s + 48])) for s in (0, 48)]
+    for _ in range(10):
+        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+    loss = np.stack(hist.loss["train"])
+    assert np.isfinite(loss).all() and loss[-1].mean() < loss[0].mean()
+    assert model._engine._generic_tier
+    model.test(loader, torch.nn.CrossEntropyLoss(), hist, tag="val")
+    assert np.isfinite(hist.loss["val"][0]).all()
     model.per_sample = False                                 # the same model trains in batch mode (whole-batch semantics)
     clean = [([torch.from_numpy(np.nan_to_num(x)) for x in xs], torch.from_numpy(y))]
     model.train_epoch(clean, opt, torch.nn.CrossEntropyLoss(), lib.MultiModNHistory(["a", "b"]))
+    assert not model._engine._generic_tier
+
+
+@pytest.mark.gpu
+def test_per_sample_mode_refuses_what_no_tier_runs_up_front():
+    """More than four encoders: no per-sample kernel (the regrouping's sequence codes hold four steps).  Refused where the
+    engine is asked for - a message that says what per-sample mode covers, nothing launched or changed."""
+    from multimodn_amd.engine import UnsupportedModelError
+    spec, xs, y, seq = c5_like(48, E=5, seed=2)
+    model = build_torch_model(spec, O.init_params(spec, 1), "cuda", mm)
+    model.per_sample = True
+    opt = mm.optim.Adam(list(model.parameters()), 1e-2)
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    loader = [([torch.from_numpy(x) for x in xs], torch.from_numpy(y), torch.from_numpy(seq))]
+    with pytest.raises(UnsupportedModelError, match="per-sample mode"):
+        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), mm.MultiModNHistory(["a", "b"]))
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), k
 
 
 @pytest.mark.gpu

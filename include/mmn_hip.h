@@ -408,6 +408,10 @@ int mmn_dp_oneshot_error(mmn_plan* p);
  * closed (mmn_dp_xbuf_close) - when an attach was refused by a peer, or on detach.  Waits for the device first: an exchange
  * kernel may still be running.  mmn_adam_step_accumulate_oneshot returns MMN_ERR_ARG afterwards until the next attach. */
 int mmn_dp_oneshot_detach(mmn_plan* p);
+/* After MMN_ERR_PEER: what the first wait that ran out was looking at - out8 = [1 + peer rank, chunk, the step it waited for,
+ * the flag value it last saw, the peer's flag of the other buffer parity, this rank, world, this rank's own step counter of
+ * that chunk] (zeros: no wait has run out).  Diagnostic; synchronises with the device when an error is recorded. */
+int mmn_dp_oneshot_diag(mmn_plan* p, unsigned out8[8]);
 
 /* 1 if this plan runs per-sample batches (mmn_batch.tile_rows / tile_seq from mmn_regroup*): the fused kernel's tiled form
  * (MLPEncoder family, n_features <= 64, hidden widths <= 32), or the generic tier's (MIMIC modules, and any model planned

@@ -1000,7 +1000,12 @@ class HipChainEngine:
         """Raises once a wait of the exchange ran out (a peer died or fell minutes behind): no synchronisation, one read
         of a host-mapped word."""
         if getattr(self, "_oneshot", None) is not None:
-            hip.check(self.lib.mmn_dp_oneshot_error(self._plan), "one-shot data-parallel exchange")
+            rc = self.lib.mmn_dp_oneshot_error(self._plan)
+            if rc != 0:
+                d = (C.c_uint32 * 8)()
+                self.lib.mmn_dp_oneshot_diag(self._plan, d)
+                hip.check(rc, f"one-shot data-parallel exchange [rank {d[5]} of {d[6]}: chunk {d[1]} waited for step {d[2]} of peer "
+                              f"{int(d[0]) - 1}, last saw flag {d[3]} (other parity {d[4]}); own counter of that chunk {d[7]}]")
 
     def accumulate_and_step_oneshot(self, err_penalty: float, sc_penalty_x001: float, optimizer, desc=None) -> bool:
         """Data-parallel tail WITHOUT a collective in front of it: exchange of [grads | stats] with the peers' mapped
@@ -1009,8 +1014,10 @@ class HipChainEngine:
         d = desc if desc is not None else (optimizer.fused_descriptor(self) if hasattr(optimizer, "fused_descriptor") else None)
         if d is None or self.lib.mmn_adam_fusable(self._plan, C.byref(d)) != 0:
             return False
-        hip.check(self.lib.mmn_adam_step_accumulate_oneshot(self._plan, C.byref(d), err_penalty, sc_penalty_x001, self._stream()),
-                  "mmn_adam_step_accumulate_oneshot")
+        rc = self.lib.mmn_adam_step_accumulate_oneshot(self._plan, C.byref(d), err_penalty, sc_penalty_x001, self._stream())
+        if rc == hip.ERR_PEER:
+            self.oneshot_check()                            # (raises with what the wait that ran out was looking at)
+        hip.check(rc, "mmn_adam_step_accumulate_oneshot")
         optimizer.mark_fused_step()
         return True
 

@@ -17,6 +17,7 @@ MAX_LAYERS = 8
 MAX_DIM = 128
 ADAM_MAX_SEG = 512
 ERR_UNSUPPORTED = -2
+ERR_PEER = -6
 VERSION = 113
 MAX_DEC_HIDDEN = 3
 ENC_MLP, ENC_MIMIC = 0, 1
@@ -38,7 +39,7 @@ ABI_SYMBOLS = (
     "mmn_nan_flags_set", "mmn_pack_invalidate", "mmn_pack_refresh", "mmn_train_step_ex", "mmn_epoch_write", "mmn_adam_fusable", "mmn_regroup_ex", "mmn_dp_rescale", "mmn_eval_step_ex",
     "mmn_dp_xbuf_bytes", "mmn_dp_xbuf_alloc", "mmn_dp_xbuf_open", "mmn_dp_xbuf_close", "mmn_dp_oneshot_attach",
     "mmn_dp_oneshot_error", "mmn_adam_step_accumulate_oneshot", "mmn_regroup_multi", "mmn_wgrad_reduce",
-    "mmn_epoch_small_rows", "mmn_train_epoch_small", "mmn_dp_oneshot_detach", "mmn_per_sample_supported",
+    "mmn_epoch_small_rows", "mmn_train_epoch_small", "mmn_dp_oneshot_detach", "mmn_per_sample_supported", "mmn_dp_oneshot_diag",
 )
 
 
@@ -181,6 +182,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.mmn_dp_oneshot_error.argtypes = [vp]
     lib.mmn_dp_oneshot_detach.restype = i32
     lib.mmn_dp_oneshot_detach.argtypes = [vp]
+    lib.mmn_dp_oneshot_diag.restype = i32
+    lib.mmn_dp_oneshot_diag.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.mmn_per_sample_supported.restype = i32
     lib.mmn_per_sample_supported.argtypes = [vp]
     lib.mmn_adam_step_accumulate_oneshot.restype = i32

@@ -54,10 +54,32 @@ class _HostStager:
         self.device, self.depth = device, depth
         self.slots: List[Optional[tuple]] = [None] * depth
         self.turn = 0
+        #: the copies run on a stream of their own (round 6): batch t + 1's packed copy overlaps step t instead
+        #: of standing in front of it on the one stream - `MMN_COPY_STREAM=0` keeps them on the current stream
+        self.copy_stream: Optional["torch.cuda.Stream"] = None
+        self.use_copy_stream = os.environ.get("MMN_COPY_STREAM", "1") != "0"
+        self.last_event: Optional["torch.cuda.Event"] = None   # the event of the last stage() whose wait was left to the caller
+        self.direct_in_flight = False       # a copy straight out of the caller's pinned tensors may still be running
 
-    def stage(self, data: Sequence[Tensor], y: Tensor) -> Tuple[List[Tensor], Tensor]:
+    def finish(self) -> None:
+        """The caller's pinned tensors are free again: every copy that reads them has completed (end of a batch loop)."""
+        if self.direct_in_flight and self.copy_stream is not None:
+            self.copy_stream.synchronize()
+        self.direct_in_flight = False
+
+    def stage(self, data: Sequence[Tensor], y: Tensor, defer_wait: bool = False) -> Tuple[List[Tensor], Tensor]:
+        """`defer_wait`: the caller makes the stream that runs the step wait for `self.last_event` itself, right in front of
+        that step's launches (the batch loop, which stages batch t + 1 BEFORE it launches step t: waiting here would put
+        step t behind copy t + 1).  Otherwise the current stream waits here and the call behaves like a copy in line.
+        Order that keeps the ring safe: a copy waits for everything the current stream has been given so far - the buffer it
+        overwrites was last read `depth` steps ago, by a step that was launched before this call."""
         # (the views into a slot's pinned and device buffers are made once per batch shape: at the reference pipelines' 16-row
         #  batches the shape arithmetic and the fourteen views of a batch cost more host time than its copies)
+        # pinned float32 / int64 inputs are copied straight from where they are (one DMA per tensor): packing 4 MB into the
+        # staging buffer first costs the host ~100 us per batch - more than the copy over the bus
+        use_cs = self.use_copy_stream and self.device.type == "cuda" and not torch.cuda.is_current_stream_capturing()
+        direct = use_cs and y.dtype == torch.int64 and y.is_contiguous() and y.is_pinned() and \
+            all(t.dtype == torch.float32 and t.is_contiguous() and t.is_pinned() for t in data)
         sig = (tuple(tuple(t.shape) for t in data), tuple(y.shape))
         i = self.turn
         self.turn = (self.turn + 1) % self.depth
@@ -86,11 +108,35 @@ class _HostStager:
             ent = (pinned, dev, ev, sig, p_views, d_views, p_y, d_y, pinned[:used], dev[:used])
             self.slots[i] = ent
         _, _, ev, _, p_views, d_views, p_y, d_y, p_used, d_used = ent
-        for pv, t in zip(p_views, data):
-            pv.copy_(t)                                          # converts dtype if needed
-        p_y.copy_(y)
-        d_used.copy_(p_used, non_blocking=True)
-        ev.record()
+        if not direct:
+            for pv, t in zip(p_views, data):
+                pv.copy_(t)                                      # converts dtype if needed
+            p_y.copy_(y)
+        self.last_event = None
+        if use_cs:
+            main = torch.cuda.current_stream(self.device)
+            if self.copy_stream is None:
+                self.copy_stream = torch.cuda.Stream(device=self.device)
+            cs = self.copy_stream
+            cs.wait_stream(main)
+            with torch.cuda.stream(cs):
+                if direct:
+                    for dv, t in zip(d_views, data):
+                        dv.copy_(t, non_blocking=True)
+                    d_y.copy_(y, non_blocking=True)
+                else:
+                    d_used.copy_(p_used, non_blocking=True)
+                ev.record(cs)
+            if defer_wait:
+                self.last_event = ev
+                self.direct_in_flight = self.direct_in_flight or direct
+            else:
+                main.wait_event(ev)
+                if direct:
+                    ev.synchronize()                          # (the caller's tensors are the copy's source: a blocking .to(device))
+        else:
+            d_used.copy_(p_used, non_blocking=True)
+            ev.record()
         return list(d_views), d_y
 
 
@@ -251,9 +297,9 @@ class MultiModN(nn.Module):
             return "readback"
         return policy
 
-    def _to_device(self, data: Sequence[Tensor], target):
+    def _to_device(self, data: Sequence[Tensor], target, defer_wait: bool = False):
         """multimodn.py:132-135: the batch on the model's device, float32 features / int64 targets.  Host batches go
-        through one pinned staging buffer and ONE copy."""
+        through one pinned staging buffer and ONE copy (on the stager's copy stream; `defer_wait`: _HostStager.stage)."""
         def here(t):                                        # (a device without an index means the current one)
             return t.device.type == self.device.type and (self.device.index is None or t.device.index == self.device.index)
         if self.device.type != "cpu" and isinstance(target, Tensor) and here(target) and target.dtype == torch.int64 \
@@ -278,7 +324,7 @@ class MultiModN(nn.Module):
             try:
                 if self._stager is None:
                     self._stager = _HostStager(self.device)
-                xs, y = self._stager.stage(data, target.to(torch.int64))
+                xs, y = self._stager.stage(data, target.to(torch.int64), defer_wait)
             finally:
                 if n_thr > 8:
                     torch.set_num_threads(n_thr)
@@ -287,7 +333,7 @@ class MultiModN(nn.Module):
             y = target.to(torch.int64).to(self.device, non_blocking=True).contiguous()
         return xs, y, on_host
 
-    def _ingest(self, data: Sequence[Tensor], target, pairs, mode: str = "host"):
+    def _ingest(self, data: Sequence[Tensor], target, pairs, mode: str = "host", defer_wait: bool = False):
         """Host half of multimodn.py:132-135,168: move the batch to the device and, under the host policy, decide the
         NaN skips.  Returns (xs_dev, y_dev, executed_pairs, executed list or None, batch came from the host)."""
         present: Optional[List[bool]] = None
@@ -305,7 +351,7 @@ class MultiModN(nn.Module):
             finally:
                 if n_thr > 8:
                     torch.set_num_threads(n_thr)
-        xs, y, on_host = self._to_device(data, target)
+        xs, y, on_host = self._to_device(data, target, defer_wait)
         if present is None:
             return xs, y, list(pairs), None, on_host
         exec_pairs = [pe for pe, ok in zip(pairs, present) if ok]
@@ -383,19 +429,23 @@ class MultiModN(nn.Module):
 
     class _Step:
         """One ingested mini-batch waiting for its launch."""
-        __slots__ = ("xs", "y", "pairs", "executed", "on_host", "bg", "b", "key", "masks", "cached", "stepped")
+        __slots__ = ("xs", "y", "pairs", "executed", "on_host", "bg", "b", "key", "masks", "cached", "stepped", "ready")
 
         def __init__(self, xs, y, pairs, executed, on_host, bg, cached=None):
             self.xs, self.y, self.pairs, self.executed, self.on_host, self.bg = xs, y, pairs, executed, on_host, bg
             self.b, self.key, self.masks, self.cached, self.stepped = None, None, None, cached, False
+            self.ready = None                               # the staging copy's event, when the wait for it was left to the launch
 
         def key_tuple(self):
             return (self.xs, self.y, self.pairs, self.bg, self.b, self.key)
 
-    def _make_step(self, data, target, encoder_sequence, mode: str, train: bool) -> "MultiModN._Step":
+    def _make_step(self, data, target, encoder_sequence, mode: str, train: bool, defer_wait: bool = False) -> "MultiModN._Step":
         pairs = self.get_encoder_iterable(encoder_sequence, self.shuffle_mode, train=train)
-        xs, y, exec_pairs, executed, on_host = self._ingest(data, target, pairs, mode)
-        return MultiModN._Step(xs, y, exec_pairs, executed, on_host, self._global_rows(int(y.shape[0])))
+        xs, y, exec_pairs, executed, on_host = self._ingest(data, target, pairs, mode, defer_wait)
+        st = MultiModN._Step(xs, y, exec_pairs, executed, on_host, self._global_rows(int(y.shape[0])))
+        if defer_wait and on_host and self._stager is not None:
+            st.ready, self._stager.last_event = self._stager.last_event, None
+        return st
 
     def _launch_step(self, eng, st: "MultiModN._Step", nxt: Optional["MultiModN._Step"], train: bool, optimizer, mode: str,
                      desc=None):
@@ -579,7 +629,7 @@ class MultiModN(nn.Module):
                     and len(ent[2]) == len(data) and all(a is c for a, c in zip(ent[2], data)):
                 window.append(MultiModN._Step(ent[2], target, ent[4], None, False, ent[5], ent))
                 return True
-            st = self._make_step(data, target, encoder_sequence, state["mode"], True)
+            st = self._make_step(data, target, encoder_sequence, state["mode"], True, defer_wait=True)
             if st.on_host or st.y is not target or len(st.xs) != len(data) or not all(a is c for a, c in zip(st.xs, data)):
                 state["ingested"] = True                     # (a copy / conversion per call: never part of a whole-call plan)
             if stable and encoder_sequence is None and st.executed is None and not st.on_host and not self.shuffle_mode \
@@ -655,6 +705,17 @@ class MultiModN(nn.Module):
             small = int(window[0].y.shape[0]) <= getattr(self, "REPLAY_MAX_ROWS", 256)
             # (a replayed SINGLE step pays where the step is host-bound - measured: 50 -> 39 us/step at 32 rows, break-even
             #  at 512 - a group of 8 pays at any batch size: one host submission for 8 steps)
+            # host batches: their copies run on the staging ring's own stream; the step waits for ITS batch here, in front of
+            # its launches.  A replayed group's last launch also pre-scans the batch behind the group (its graph holds that
+            # batch's buffers): it waits for that copy too - groups of host batches are the small ones (<= REPLAY_MAX_ROWS rows).
+            def await_copy(st_):
+                if st_.ready is not None:
+                    torch.cuda.current_stream(self.device).wait_event(st_.ready)
+                    st_.ready = None
+            for st in itertools.islice(window, n):
+                await_copy(st)
+            if can_replay and (n > 1 or small) and len(window) > n:
+                await_copy(window[n])
             if can_replay and (n > 1 or small):
                 steps = [st.key_tuple() for st in itertools.islice(window, n)]
                 nxt = window[n].key_tuple() if len(window) > n else None
@@ -687,7 +748,17 @@ class MultiModN(nn.Module):
                 state["need_reset"] = False
             for _ in range(n):
                 st = window.popleft()
+                await_copy(st)
                 nxt = window[0] if window else None
+                if nxt is not None and nxt.ready is not None:
+                    # the next batch's copy is still on its way (on the copy stream): this step's last launch must not pre-scan
+                    # it - the next step then scans its own batch in front of its chain (one small launch), and the copy
+                    # overlaps this whole step.  Data parallel keeps the pre-scan (its flags ride in this step's ONE
+                    # all-reduce): there this step waits for that copy.
+                    if dp:
+                        await_copy(nxt)
+                    else:
+                        nxt = None
                 if fused_surface and state["grads_assigned"]:
                     # the engine applies optimizer.step() itself (multimodn_amd.optim.Adam): zero_grad / .grad / step()
                     # would only re-point 31 tensors and cross the Optimizer hooks, host time a small step does not have
@@ -711,6 +782,8 @@ class MultiModN(nn.Module):
                            f"\tLoss: {float(v['loss']):.4f}\n"
                            f"\tErr loss: {float(v['global_err']):.4f}\n"
                            f"\tState change: {float(v['global_sc']):.4f}")
+        if self._stager is not None:
+            self._stager.finish()                            # (pinned host batches were read in place: they are the caller's again)
         if state["eng"] is not None and state["fd"] is not None and state["mode"] == "device" and not dp:
             # every step of this call applied the optimizer inside the library (the copies the chain kernels read were
             # scattered with each update): the next call need not repack unless somebody writes the parameters in between

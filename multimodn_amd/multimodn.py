@@ -59,13 +59,7 @@ class _HostStager:
         self.copy_stream: Optional["torch.cuda.Stream"] = None
         self.use_copy_stream = os.environ.get("MMN_COPY_STREAM", "1") != "0"
         self.last_event: Optional["torch.cuda.Event"] = None   # the event of the last stage() whose wait was left to the caller
-        self.direct_in_flight = False       # a copy straight out of the caller's pinned tensors may still be running
 
-    def finish(self) -> None:
-        """The caller's pinned tensors are free again: every copy that reads them has completed (end of a batch loop)."""
-        if self.direct_in_flight and self.copy_stream is not None:
-            self.copy_stream.synchronize()
-        self.direct_in_flight = False
 
     def stage(self, data: Sequence[Tensor], y: Tensor, defer_wait: bool = False) -> Tuple[List[Tensor], Tensor]:
         """`defer_wait`: the caller makes the stream that runs the step wait for `self.last_event` itself, right in front of
@@ -75,11 +69,9 @@ class _HostStager:
         overwrites was last read `depth` steps ago, by a step that was launched before this call."""
         # (the views into a slot's pinned and device buffers are made once per batch shape: at the reference pipelines' 16-row
         #  batches the shape arithmetic and the fourteen views of a batch cost more host time than its copies)
-        # pinned float32 / int64 inputs are copied straight from where they are (one DMA per tensor): packing 4 MB into the
-        # staging buffer first costs the host ~100 us per batch - more than the copy over the bus
+        # (pinned inputs copied straight from where they are - one DMA per tensor, no packing - were measured and are SLOWER:
+        #  five 1 MB copies take 141 us per 4096-row batch against 127 us for the packed one on the same box, tools/time_h2d.py)
         use_cs = self.use_copy_stream and self.device.type == "cuda" and not torch.cuda.is_current_stream_capturing()
-        direct = use_cs and y.dtype == torch.int64 and y.is_contiguous() and y.is_pinned() and \
-            all(t.dtype == torch.float32 and t.is_contiguous() and t.is_pinned() for t in data)
         sig = (tuple(tuple(t.shape) for t in data), tuple(y.shape))
         i = self.turn
         self.turn = (self.turn + 1) % self.depth
@@ -108,10 +100,9 @@ class _HostStager:
             ent = (pinned, dev, ev, sig, p_views, d_views, p_y, d_y, pinned[:used], dev[:used])
             self.slots[i] = ent
         _, _, ev, _, p_views, d_views, p_y, d_y, p_used, d_used = ent
-        if not direct:
-            for pv, t in zip(p_views, data):
-                pv.copy_(t)                                      # converts dtype if needed
-            p_y.copy_(y)
+        for pv, t in zip(p_views, data):
+            pv.copy_(t)                                          # converts dtype if needed
+        p_y.copy_(y)
         self.last_event = None
         if use_cs:
             main = torch.cuda.current_stream(self.device)
@@ -120,20 +111,12 @@ class _HostStager:
             cs = self.copy_stream
             cs.wait_stream(main)
             with torch.cuda.stream(cs):
-                if direct:
-                    for dv, t in zip(d_views, data):
-                        dv.copy_(t, non_blocking=True)
-                    d_y.copy_(y, non_blocking=True)
-                else:
-                    d_used.copy_(p_used, non_blocking=True)
+                d_used.copy_(p_used, non_blocking=True)
                 ev.record(cs)
             if defer_wait:
                 self.last_event = ev
-                self.direct_in_flight = self.direct_in_flight or direct
             else:
                 main.wait_event(ev)
-                if direct:
-                    ev.synchronize()                          # (the caller's tensors are the copy's source: a blocking .to(device))
         else:
             d_used.copy_(p_used, non_blocking=True)
             ev.record()
@@ -319,14 +302,15 @@ class MultiModN(nn.Module):
             #  pipelines' 16-row batches skip the two set_num_threads calls, which cost more than their copies)
             big = sum(int(t.numel()) for t in data) >= 32768
             n_thr = torch.get_num_threads() if big else 0
-            if n_thr > 8:
-                torch.set_num_threads(8)
+            cap = int(getattr(self, "stage_threads", 8))
+            if n_thr > cap:
+                torch.set_num_threads(cap)
             try:
                 if self._stager is None:
                     self._stager = _HostStager(self.device)
                 xs, y = self._stager.stage(data, target.to(torch.int64), defer_wait)
             finally:
-                if n_thr > 8:
+                if n_thr > cap:
                     torch.set_num_threads(n_thr)
         else:
             xs = [t.to(self.device, dtype=torch.float32, non_blocking=True).contiguous() for t in data]
@@ -782,8 +766,6 @@ class MultiModN(nn.Module):
                            f"\tLoss: {float(v['loss']):.4f}\n"
                            f"\tErr loss: {float(v['global_err']):.4f}\n"
                            f"\tState change: {float(v['global_sc']):.4f}")
-        if self._stager is not None:
-            self._stager.finish()                            # (pinned host batches were read in place: they are the caller's again)
         if state["eng"] is not None and state["fd"] is not None and state["mode"] == "device" and not dp:
             # every step of this call applied the optimizer inside the library (the copies the chain kernels read were
             # scattered with each update): the next call need not repack unless somebody writes the parameters in between

@@ -264,14 +264,30 @@ def test_eight_rank_dp_with_uneven_shards_on_one_gpu(tmp_path):
     _assert_equals_golden(r0, g, 1e-5)
 
 
-def _spawn_eight_peers(monkeypatch, tmp_path, make_args, attempts=6):
-    """Eight one-shot peers on ONE GPU: eight compute processes are all the VMIDs a GPU has, so any ninth process with a
-    queue (this test's parent, a process of the previous test still exiting, a monitoring agent of the box) makes the driver
-    time-slice them - and a rank whose exchange kernel spins for a peer that is not on the GPU holds its slot meanwhile.
-    Measured on this pool: 1 run in ~8 ends, as designed, in MMN_ERR_PEER (the bounded wait), whatever the bound (5 s: 3 of 24;
-    120 s: 1 of 4 full-suite runs; with this wrapper 2 of 3 runs of this file needed a second attempt somewhere).  One process
-    per GPU - the product's layout - never shares VMIDs.  So: a 15 s bound, and a run that ended in MMN_ERR_PEER - and only
-    that - is repeated, up to six times, each in a directory of its own."""
+EIGHT_PEER_ATTEMPTS = []                                     # (test id, attempts it took): printed by the last eight-peer test
+
+
+def _spawn_eight_peers(monkeypatch, tmp_path, make_args, attempts=4):
+    """Eight one-shot peers on ONE GPU - a layout only this test has (the product runs one process per GPU).  About one run
+    in five ends, as designed, in MMN_ERR_PEER: a rank's exchange kernel waits the whole bound for a peer's chunk.  What round 6
+    established about it (tools/eight_peers_probe.py):
+      * it is NOT a ninth process on the GPU (the VMID hypothesis of round 5): a parent without a GPU context, and a parent that
+        is itself rank 0 with seven children, stall as often (1 / 8, 3 / 16 and 1 / 8 runs) as the parent with a context (2 / 8);
+      * it is not the number of hardware queues per process (GPU_MAX_HW_QUEUES=1: 3 / 12) and not the buffers' memory type
+        (fine-grained exchange buffers: 3 / 12; coarse-grained: 3 / 12);
+      * SEVEN ranks (the same <8> instantiation, seven processes on the GPU) stall as well: 3 / 30; six ranks under a parent
+        with a context: 0 / 20 - so it needs about seven or more processes whose kernels spin on each other;
+      * it is not visibility: the record of the wait that ran out (mmn_dp_oneshot_diag) shows the awaited peer's flag of the
+        OTHER buffer parity at the previous step's number - that store was seen - and the awaited flag still at its initial
+        value: the peer's workgroup of that chunk had not published, i.e. had not run, within the bound, although the peer had
+        completed the step before; with a 120 s bound the wait still runs out (round 5), so the awaited workgroup does not
+        run UNTIL a waiting one gives up - eight processes' spinning kernels on one GPU starve one of them.  Which resource
+        they hold is not known (wave slots, LDS and registers all have room for 8 x 95 small workgroups many times over).
+    The wait is bounded, the error is reported, the model is unusable after it - that is the contract this test checks; what
+    it cannot promise is that eight spinning processes on ONE GPU always finish.  So: a 15 s bound; a run that ended in
+    MMN_ERR_PEER - and only that - is repeated in a directory of its own; the number of attempts is RECORDED and a test that
+    needed more than one is reported as xfail (strict=False: visible in the summary, not green by silence) once its own
+    checks have passed on the attempt that completed."""
     monkeypatch.setenv("MMN_DP_SPIN_MS", "15000")
     last = None
     for attempt in range(attempts):
@@ -279,13 +295,21 @@ def _spawn_eight_peers(monkeypatch, tmp_path, make_args, attempts=6):
         d.mkdir()
         try:
             mp.spawn(_gpu_worker, args=make_args(d), nprocs=8, join=True)
-            return d
+            EIGHT_PEER_ATTEMPTS.append(attempt + 1)
+            return d, attempt + 1
         except Exception as ex:                              # (mp.spawn re-raises the first failing rank's traceback as text)
             if "PEER" not in str(ex) and "peer" not in str(ex):
                 raise
-            print(f"[eight peers] attempt {attempt + 1} ended in MMN_ERR_PEER: {str(ex)[-600:]}", flush=True)
+            lines = [ln.strip() for ln in str(ex).splitlines() if "one-shot data-parallel exchange [" in ln and "failed" in ln]
+            print(f"[eight peers] attempt {attempt + 1} ended in MMN_ERR_PEER: {lines[-1] if lines else str(ex)[-600:]}", flush=True)
             last = ex
     raise last
+
+
+def _report_attempts(n_attempts):
+    if n_attempts > 1:
+        pytest.xfail(f"eight one-shot peers on one GPU: the run completed and passed its checks on attempt {n_attempts}; "
+                     f"{n_attempts - 1} earlier attempt(s) ended in MMN_ERR_PEER (a bounded wait that ran out: see _spawn_eight_peers)")
 
 
 @pytest.mark.gpu
@@ -296,10 +320,11 @@ def test_oneshot_exchange_with_eight_peers(name, tmp_path, monkeypatch):
     bit-equality with the collective path holds for two ranks only); one all-reduce per EPOCH.
     (Eight processes on one GPU: _spawn_eight_peers.)"""
     g = Golden(name)
-    tmp_path = _spawn_eight_peers(monkeypatch, tmp_path, lambda d: (8, _free_port(), name, "device", str(d), False, True))
+    tmp_path, n_attempts = _spawn_eight_peers(monkeypatch, tmp_path, lambda d: (8, _free_port(), name, "device", str(d), False, True))
     r0 = _replicas_identical(tmp_path, 8)
     _check_oneshot_collectives(r0)
     _assert_equals_golden(r0, g, 1e-5)
+    _report_attempts(n_attempts)
 
 
 @pytest.mark.gpu
@@ -312,13 +337,15 @@ def test_captured_groups_with_the_exchange_inside(world, oneshot, tmp_path, monk
     reference's History and weights, and a graph must really have been replayed."""
     g = Golden("mlp_sigmoid")                                # (16-row batches and one of 8: every rank of eight keeps a row)
     args = lambda d: (world, _free_port(), "mlp_sigmoid", "device", str(d), False, oneshot, None, True)
+    n_attempts = 1
     if world == 8:                                           # (eight processes on one GPU: see _spawn_eight_peers)
-        tmp_path = _spawn_eight_peers(monkeypatch, tmp_path, args)
+        tmp_path, n_attempts = _spawn_eight_peers(monkeypatch, tmp_path, args)
     else:
         mp.spawn(_gpu_worker, args=args(tmp_path), nprocs=world, join=True)
     r0 = _replicas_identical(tmp_path, world)
     assert int(r0["graph_hits"][0]) >= 1
     _assert_equals_golden(r0, g, 1e-5)
+    _report_attempts(n_attempts)
 
 
 @pytest.mark.gpu

@@ -42,9 +42,11 @@ def main():
     opt = mm.optim.Adam(model.parameters(), lr=1e-3)
     batches = O.synthetic_batches(spec, a.steps * a.batch, a.batch, seed=3)
     res = {}
-    for kind in ("pinned", "pageable"):
+    for kind, thr in (("pinned", 8), ("pageable", 8), ("pageable", 4), ("pageable", 16), ("pageable", 32)):
         put = (lambda t: t.pin_memory()) if kind == "pinned" else (lambda t: t)
         hb = [([put(torch.from_numpy(x)) for x in xs], put(torch.from_numpy(y))) for xs, y in batches]
+        model.stage_threads = thr                            # threads of torch's intra-op pool while a batch is packed
+        kind = f"{kind}/{thr}thr"
         for flag in (False, True, False, True):
             model._train_steps(_Sized(hb), opt)              # (the stager exists after the first call)
             model._stager.use_copy_stream = flag
@@ -59,7 +61,7 @@ def main():
     nbytes = sum(x.nbytes for x in batches[0][0]) + batches[0][1].nbytes
     for (kind, flag), v in res.items():
         best = min(v)
-        print(f"{kind:9s} copy stream {int(flag)}: {best:7.1f} us/step ({[round(x, 1) for x in v]}), {nbytes / best / 1e3:5.1f} GB/s over the bus, "
+        print(f"{kind:15s} copy stream {int(flag)}: {best:7.1f} us/step ({[round(x, 1) for x in v]}), {nbytes / best / 1e3:5.1f} GB/s over the bus, "
               f"{a.batch / best:6.2f} M samples/s")
 
 

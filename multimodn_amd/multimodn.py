@@ -297,12 +297,12 @@ class MultiModN(nn.Module):
         if on_host and self.device.type == "cuda" and data:
             # Host tensors of this size are copied / scanned by torch's intra-op pool; on a many-core
             # host (128 threads here) that pool turns a 100 us copy into milliseconds, so the handful of
-            # small host ops of one batch run with at most 8 threads.
+            # small host ops of one batch run with at most 16 threads (model.stage_threads).
             # (torch runs tensors below its grain size - 32,768 elements - on the calling thread anyway: the reference
             #  pipelines' 16-row batches skip the two set_num_threads calls, which cost more than their copies)
             big = sum(int(t.numel()) for t in data) >= 32768
             n_thr = torch.get_num_threads() if big else 0
-            cap = int(getattr(self, "stage_threads", 8))
+            cap = int(getattr(self, "stage_threads", 16))     # (tools/time_h2d.py, EPYC 9575F: 4 / 8 / 16 / 32 threads -> 121 / 123 / 114 / 149 us per step)
             if n_thr > cap:
                 torch.set_num_threads(cap)
             try:

@@ -39,7 +39,7 @@ x = torch.zeros(64, 8, device="cuda"); y = torch.zeros(64, 1, dtype=torch.int64,
 b = eng.make_batch([x], y, [(0, 0)], device_nan_flags=True)
 eng.nan_scan(b); torch.cuda.synchronize()
 print("IN BOUNDS OK", flush=True)
-b.batch = 64 + 4096                      # the scan now walks 4096 rows past the end of x
+b.batch = b.batch_global = 64 + 4096     # the scan now walks 4096 rows past the end of x
 eng.nan_scan(b); torch.cuda.synchronize()
 print("NO FAULT", flush=True)
 '''

@@ -33,7 +33,7 @@ torch = None                       # imported in main() / where needed: the laun
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix) = vector peak
 # the committed rocprofv3 --pmc passes roofline.traffic / mfma_busy_pct_pmc are read from (tools/collect_profiles.sh, collect_pmc_util.sh)
-PROFILE_TAGS = {"c3": "r05_final", "mimic": "r05_mimic", "c5": "r05_c5", "c5m": "r05_c5m", "haim": "r05_haim"}
+PROFILE_TAGS = {"c3": "r06_final", "mimic": "r06_mimic", "c5": "r06_c5", "c5m": "r06_c5m", "haim": "r06_haim", "c1": "r06_c1"}
 HBM_PEAK_GBS = 8000.0
 
 

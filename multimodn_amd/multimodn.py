@@ -123,6 +123,64 @@ class _HostStager:
         return list(d_views), d_y
 
 
+class _LoaderPrefetch:
+    """`next(loader)` one batch ahead, on a helper thread (round 6): a stock `torch.utils.data.DataLoader` without workers
+    builds every batch on the calling thread - 0.4 - 0.85 ms per 4096-row batch of four partitions (fresh host arrays: page
+    faults), a third of an import-swap pipeline's step (bench.py `stock_path`) - while the training loop's own host work
+    (packing into the staging ring, the host NaN test, a stock optimizer's step) waits.  numpy's and torch's copies release
+    the GIL, so the two overlap.  Only the helper thread ever touches the iterator; an exception inside the loader is
+    re-raised where `next()` is called; `close()` (the loop's `finally`) stops the thread at its next batch.
+    `model.prefetch_loader = False` / MMN_PREFETCH=0: off."""
+
+    def __init__(self, it, depth: int = 2):
+        import queue
+        import threading
+        self.it, self.q, self.stop = it, queue.Queue(maxsize=depth), False
+        self.thread = threading.Thread(target=self._run, name="mmn-loader-prefetch", daemon=True)
+        self.thread.start()
+
+    def _put(self, item) -> bool:
+        import queue
+        while not self.stop:
+            try:
+                self.q.put(item, timeout=0.05)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _run(self) -> None:
+        try:
+            for batch in self.it:
+                if not self._put((0, batch)):
+                    return
+            self._put((1, None))
+        except BaseException as ex:                          # noqa: BLE001  (handed to the consumer)
+            self._put((2, ex))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        kind, val = self.q.get()
+        if kind == 0:
+            return val
+        self.stop = True
+        if kind == 1:
+            raise StopIteration
+        raise val
+
+    def close(self) -> None:
+        self.stop = True
+        import queue
+        try:
+            while True:
+                self.q.get_nowait()
+        except queue.Empty:
+            pass
+        self.thread.join(timeout=5.0)
+
+
 _BATCH_CACHE_MAX = 4096
 
 
@@ -565,6 +623,19 @@ class MultiModN(nn.Module):
         import collections
         import itertools
         it = iter(train_loader)
+        prefetch = None
+        if isinstance(train_loader, DataLoader) and getattr(train_loader, "num_workers", 1) == 0 and self.device.type == "cuda" \
+                and getattr(self, "prefetch_loader", True) and os.environ.get("MMN_PREFETCH", "1") != "0":
+            it = prefetch = _LoaderPrefetch(it)              # (a loader with workers prefetches by itself)
+        try:
+            return self._train_steps_loop(train_loader, it, optimizer, log_interval, logger)
+        finally:
+            if prefetch is not None:
+                prefetch.close()
+
+    def _train_steps_loop(self, train_loader, it, optimizer, log_interval=None, logger=None):
+        import collections
+        import itertools
         n_batches = len(train_loader) if hasattr(train_loader, "__len__") else None
         window: "collections.deque[MultiModN._Step]" = collections.deque()
         cache = self.__dict__.setdefault("_batch_cache", {})

@@ -336,3 +336,29 @@ def test_history_list_settles_pending_epochs_before_anything_moves_entries():
     lst = fresh()
     lst.clear()
     assert len(lst) == 0
+
+
+def test_loader_prefetch_keeps_order_forwards_exceptions_and_stops():
+    """multimodn.py::_LoaderPrefetch (round 6): the batch loop's helper thread hands batches on in order, re-raises what the
+    loader raises where next() is called, ends with StopIteration, and stops pulling once it is closed."""
+    from multimodn_amd.multimodn import _LoaderPrefetch
+    assert list(_LoaderPrefetch(iter(range(100)))) == list(range(100))
+
+    def bad():
+        yield 1
+        yield 2
+        raise ValueError("broken sample")
+    p = _LoaderPrefetch(bad())
+    assert next(p) == 1 and next(p) == 2
+    with pytest.raises(ValueError, match="broken sample"):
+        next(p)
+    pulled = []
+
+    def slow():
+        for i in range(1000):
+            pulled.append(i)
+            yield i
+    q = _LoaderPrefetch(slow(), depth=2)
+    assert next(q) == 0
+    q.close()
+    assert not q.thread.is_alive() and len(pulled) <= 5       # (the batch in hand + the queue's depth + one in the making)

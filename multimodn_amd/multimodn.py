@@ -130,7 +130,9 @@ class _LoaderPrefetch:
     (packing into the staging ring, the host NaN test, a stock optimizer's step) waits.  numpy's and torch's copies release
     the GIL, so the two overlap.  Only the helper thread ever touches the iterator; an exception inside the loader is
     re-raised where `next()` is called; `close()` (the loop's `finally`) stops the thread at its next batch.
-    `model.prefetch_loader = False` / MMN_PREFETCH=0: off."""
+    OPT-IN (`model.prefetch_loader = True` / MMN_PREFETCH=1): measured 1,163 - 1,260 -> 1,073 - 1,078 us per step on the
+    import-swap pipeline without shuffling and no gain with it (tools/time_stock.py) - not enough to run a user's dataset
+    code on a thread it was not written for by default."""
 
     def __init__(self, it, depth: int = 2):
         import queue
@@ -359,7 +361,7 @@ class MultiModN(nn.Module):
             # (torch runs tensors below its grain size - 32,768 elements - on the calling thread anyway: the reference
             #  pipelines' 16-row batches skip the two set_num_threads calls, which cost more than their copies)
             big = sum(int(t.numel()) for t in data) >= 32768
-            n_thr = torch.get_num_threads() if big else 0
+            n_thr = torch.get_num_threads() if (big and not self.__dict__.get("_threads_capped")) else 0
             cap = int(getattr(self, "stage_threads", 16))     # (tools/time_h2d.py, EPYC 9575F: 4 / 8 / 16 / 32 threads -> 121 / 123 / 114 / 149 us per step)
             if n_thr > cap:
                 torch.set_num_threads(cap)
@@ -381,7 +383,8 @@ class MultiModN(nn.Module):
         present: Optional[List[bool]] = None
         if mode == "host":
             on_host = all(t.device.type == "cpu" for t in data)
-            n_thr = torch.get_num_threads() if (on_host and sum(int(t.numel()) for t in data) >= 32768) else 0
+            n_thr = torch.get_num_threads() if (on_host and not self.__dict__.get("_threads_capped")
+                                                and sum(int(t.numel()) for t in data) >= 32768) else 0
             if n_thr > 8:
                 torch.set_num_threads(8)
             try:
@@ -625,11 +628,22 @@ class MultiModN(nn.Module):
         it = iter(train_loader)
         prefetch = None
         if isinstance(train_loader, DataLoader) and getattr(train_loader, "num_workers", 1) == 0 and self.device.type == "cuda" \
-                and getattr(self, "prefetch_loader", True) and os.environ.get("MMN_PREFETCH", "1") != "0":
+                and (getattr(self, "prefetch_loader", False) or os.environ.get("MMN_PREFETCH", "0") not in ("", "0")):
             it = prefetch = _LoaderPrefetch(it)              # (a loader with workers prefetches by itself)
+        # torch's intra-op pool for the loop's host-side copies / NaN tests: capped ONCE per call (`_to_device` used to set and
+        # restore it around every batch: two pool resizes per step - on a 128-thread host one of them now and then takes a
+        # millisecond, and a 96-step measurement of the host path read 745 us per step instead of 110)
+        n_thr, cap = torch.get_num_threads(), int(getattr(self, "stage_threads", 16))
+        capped = self.device.type == "cuda" and n_thr > cap
+        if capped:
+            torch.set_num_threads(cap)
+            self.__dict__["_threads_capped"] = True
         try:
             return self._train_steps_loop(train_loader, it, optimizer, log_interval, logger)
         finally:
+            if capped:
+                self.__dict__["_threads_capped"] = False
+                torch.set_num_threads(n_thr)
             if prefetch is not None:
                 prefetch.close()
 

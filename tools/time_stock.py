@@ -1,5 +1,5 @@
 """The import-swap pipeline (bench.py `stock_path`): torch DataLoader(PartitionDataset) + torch.optim.Adam through
-MultiModN.train_epoch at BASELINE configs[2], with and without the batch loop's loader prefetch thread (round 6).
+MultiModN.train_epoch at BASELINE configs[2], with and without the batch loop's (opt-in) loader prefetch thread (round 6).
 Usage: python tools/time_stock.py [--batches 32] [--epochs 3]"""
 import argparse
 import os

@@ -63,7 +63,7 @@ def _run(lib, spec, loader, epochs, use_kernel, lr=1e-2):
     return model, hist, steps, grads
 
 
-@pytest.mark.parametrize("shape", ["titanic", "two_enc", "deep", "titanic_b50", "two_enc_b64"])
+@pytest.mark.parametrize("shape", ["titanic", "two_enc", "deep", "titanic_b50", "two_enc_b64", "wide_b64"])
 def test_epoch_kernel_equals_step_path(lib, shape, monkeypatch):
     """Same batches through both paths: 28 batches of 32 rows (the last one ragged), NaN batches in the middle that skip
     an encoder (multimodn.py:168: no gradient, no Adam step for its tensors - their step counts stay behind)."""
@@ -71,7 +71,10 @@ def test_epoch_kernel_equals_step_path(lib, shape, monkeypatch):
     spec = {"titanic": O.ModelSpec(32, [O.EncoderSpec(6, (5, 5), O.ACT_RELU)], 1, 0.7, 0.3),
             "two_enc": O.ModelSpec(24, [O.EncoderSpec(3, (5, 5), O.ACT_RELU), O.EncoderSpec(2, (7,), O.ACT_SIGMOID)], 2, 0.7, 0.3),
             "deep": O.ModelSpec(16, [O.EncoderSpec(9, (8, 6, 4), O.ACT_RELU), O.EncoderSpec(4, (), O.ACT_IDENTITY),
-                                     O.EncoderSpec(5, (6,), O.ACT_RELU)], 3, 1.0, 1.0)}[shape.split("_b")[0]]
+                                     O.EncoderSpec(5, (6,), O.ACT_RELU)], 3, 1.0, 1.0),
+            # 64 rows x 48 features = 3,072 x values per batch: more than eight waves fetch at 4 a thread - the kernel's
+            # 8-per-thread instantiation (round 6: it replaces the 1024-thread form, the one kernel that had scratch)
+            "wide": O.ModelSpec(16, [O.EncoderSpec(12, (6,), O.ACT_RELU) for _ in range(4)], 2, 0.7, 0.3)}[shape.split("_b")[0]]
     B, nb = (int(shape.split("_b")[1]) if "_b" in shape else 32), 28        # (50: every batch ends inside a 16-row tile; 64: the kernel's largest)
     batches = O.synthetic_batches(spec, nb * B - 11, B, seed=9)        # (the last batch has 21 rows)
     for bi, slot in ((3, 0), (9, spec.E - 1), (10, spec.E - 1), (nb - 1, 0)):

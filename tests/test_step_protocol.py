@@ -415,3 +415,34 @@ def test_pinned_host_batches_train_like_pageable_ones():
     ref = run("pageable")
     _same(ref, run("pinned"))
     _same(ref, run("pinned_f64"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family,rows,optimizer", [("classic", 48, "hip"), ("classic", 600, "hip"), ("mimic", 600, "hip"), ("classic", 600, "torch")])
+def test_copy_stream_equals_copies_in_line(family, rows, optimizer, monkeypatch):
+    """Round 6: host batches are copied on the staging ring's own stream, the step waits for ITS batch in front of its launches,
+    and a batch whose copy is still in flight is not pre-scanned by the step before it (it scans itself).  Must be BITWISE the
+    training that the copies in line (MMN_COPY_STREAM=0, round 5's layout) give: small batches (replayed single-step graphs,
+    whose last launch pre-scans the next batch's ring slot), batches above REPLAY_MAX_ROWS (eager steps), the MIMIC modules
+    (the next step's dropout draw rides in the step before), a stock optimizer (host NaN policy), a NaN batch in the middle and
+    a ragged last batch."""
+    import multimodn_amd as lib
+    spec = _specs()[family]
+    batches = O.synthetic_batches(spec, 7 * rows - 9, rows, seed=12)
+    batches[3][0][1][5, 0] = np.nan
+
+    def run(copy_stream):
+        monkeypatch.setenv("MMN_COPY_STREAM", copy_stream)
+        torch.manual_seed(11)
+        loader = [([torch.from_numpy(x) for x in xs], torch.from_numpy(y)) for xs, y in batches]
+        model = build_torch_model(spec, O.init_params(spec, 2), "cuda", lib)
+        Adam = lib.optim.Adam if optimizer == "hip" else torch.optim.Adam
+        opt = Adam(list(model.parameters()), 1e-2)
+        hist = lib.MultiModNHistory([f"t{d}" for d in range(spec.D)])
+        for _ in range(3):
+            model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+        torch.cuda.synchronize()
+        assert (model._stager.copy_stream is not None) == (copy_stream == "1")
+        return (np.stack(hist.loss["train"]), np.stack(hist.state_change_loss), np.stack(hist.accuracy["train"]),
+                {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()})
+    _same(run("0"), run("1"))

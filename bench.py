@@ -255,6 +255,18 @@ def cpu_match(O, mm, w, device, batch_size, steps=3):
                        "fp64 = the same oracle in float64"}
 
 
+def _curve_replay_job(w, batch_size, epochs, steps, params, dtype_name):
+    """The numpy oracle's replay of cpu_match_curve's steps in one precision (a worker process: CPU only)."""
+    sys.path.insert(0, REPO)
+    from oracle import multimodn_oracle as O                 # the checker: imported for the cpu_match leg only
+    dtype = np.dtype(dtype_name).type
+    spec = oracle_spec(O, w)
+    batches = synthetic_batches(w, batch_size * steps, batch_size, seed=55)
+    p = {n: np.asarray(v, dtype).copy() for n, v in params.items()}
+    o = O.Adam(w["lr"])
+    return p, [O.train_epoch(p, spec, batches, o, dtype=dtype) for _ in range(epochs)]
+
+
 def cpu_match_curve(O, mm, w, device, batch_size, epochs=3, steps=64):
     """The loss CURVE half of "CPU-match" (VERDICT r4 #4): `epochs` x `steps` training steps through the public
     MultiModN.train_epoch (device-resident batches, the fused Adam, hipGraph replay) against the numpy oracle's replay of the
@@ -270,6 +282,25 @@ def cpu_match_curve(O, mm, w, device, batch_size, epochs=3, steps=64):
     batches = synthetic_batches(w, batch_size * steps, batch_size, seed=55)
     loader = [([torch.from_numpy(x).to(device) for x in xs], torch.from_numpy(y).to(device)) for xs, y in batches]
     crit = torch.nn.CrossEntropyLoss()
+    # the two replays (float64, float32: ~30 s of single-threaded numpy each) run side by side in worker processes (spawned:
+    # this process holds a GPU context; a few BLAS threads each - the oracle's products are small) while the GPU trains
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    t0 = time.perf_counter()
+    keys = ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")
+    saved = {k: os.environ.get(k) for k in keys}
+    for k in keys:
+        os.environ[k] = "4"
+    try:
+        pool = cf.ProcessPoolExecutor(2, mp_context=mp.get_context("spawn"))
+        f64 = pool.submit(_curve_replay_job, w, batch_size, epochs, steps, params, "float64")
+        f32 = pool.submit(_curve_replay_job, w, batch_size, epochs, steps, params, "float32")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     for _ in range(epochs):
         model.train_epoch(loader, opt, crit, hist)
     torch.cuda.synchronize()
@@ -278,13 +309,13 @@ def cpu_match_curve(O, mm, w, device, batch_size, epochs=3, steps=64):
         a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
         return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
 
-    def replay(dtype):
-        p = {n: np.asarray(v, dtype).copy() for n, v in params.items()}
-        o = O.Adam(w["lr"])
-        return p, [O.train_epoch(p, spec, batches, o, dtype=dtype) for _ in range(epochs)]
-    t0 = time.perf_counter()
-    p64, e64 = replay(np.float64)
-    p32, e32 = replay(np.float32)
+    try:
+        p64, e64 = f64.result()
+        p32, e32 = f32.result()
+        pool.shutdown(wait=False)
+    except Exception:                                         # (no worker processes in this environment: replay here, one after the other)
+        p64, e64 = _curve_replay_job(w, batch_size, epochs, steps, params, "float64")
+        p32, e32 = _curve_replay_job(w, batch_size, epochs, steps, params, "float32")
     per_epoch, ok = [], True
     for ep in range(epochs):
         dl, dl32 = rel(hist.loss["train"][ep], e64[ep].loss), rel(e32[ep].loss, e64[ep].loss)

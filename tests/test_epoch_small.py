@@ -63,12 +63,19 @@ def _run(lib, spec, loader, epochs, use_kernel, lr=1e-2):
     return model, hist, steps, grads
 
 
-@pytest.mark.parametrize("shape", ["titanic", "two_enc", "deep", "titanic_b50", "two_enc_b64", "wide_b64"])
+@pytest.mark.parametrize("shape", ["titanic", "titanic_table", "titanic2", "two_enc", "deep", "titanic_b50", "two_enc_b64", "wide_b64"])
 def test_epoch_kernel_equals_step_path(lib, shape, monkeypatch):
     """Same batches through both paths: 28 batches of 32 rows (the last one ragged), NaN batches in the middle that skip
     an encoder (multimodn.py:168: no gradient, no Adam step for its tensors - their step counts stay behind)."""
     monkeypatch.setenv("MMN_EPOCH_KERNEL", "1")
+    # "titanic": the one-encoder form (round 6: k_epoch_small<.., true>, the step written out by hand - state 32, batches of at
+    # most 32 rows); "titanic_table": the same model through the table-driven form (MMN_EPS_ONE=0); "titanic2": the one-encoder
+    # form with two decoders, sigmoid hidden layers and other widths; "titanic_b50": 50-row batches - outside the one-encoder
+    # form, the table-driven one takes it
+    monkeypatch.setenv("MMN_EPS_ONE", "0" if shape == "titanic_table" else "1")
+    shape = shape.replace("titanic_table", "titanic")
     spec = {"titanic": O.ModelSpec(32, [O.EncoderSpec(6, (5, 5), O.ACT_RELU)], 1, 0.7, 0.3),
+            "titanic2": O.ModelSpec(32, [O.EncoderSpec(8, (7, 3), O.ACT_SIGMOID)], 2, 1.0, 1.0),
             "two_enc": O.ModelSpec(24, [O.EncoderSpec(3, (5, 5), O.ACT_RELU), O.EncoderSpec(2, (7,), O.ACT_SIGMOID)], 2, 0.7, 0.3),
             "deep": O.ModelSpec(16, [O.EncoderSpec(9, (8, 6, 4), O.ACT_RELU), O.EncoderSpec(4, (), O.ACT_IDENTITY),
                                      O.EncoderSpec(5, (6,), O.ACT_RELU)], 3, 1.0, 1.0),

@@ -63,7 +63,8 @@ def _run(lib, spec, loader, epochs, use_kernel, lr=1e-2):
     return model, hist, steps, grads
 
 
-@pytest.mark.parametrize("shape", ["titanic", "titanic_table", "titanic2", "two_enc", "deep", "titanic_b50", "two_enc_b64", "wide_b64"])
+@pytest.mark.parametrize("shape", ["titanic", "titanic_table", "titanic2", "titanic_s1", "titanic_s20", "two_enc", "deep", "titanic_b50", "two_enc_b64",
+                                   "wide_b64"])
 def test_epoch_kernel_equals_step_path(lib, shape, monkeypatch):
     """Same batches through both paths: 28 batches of 32 rows (the last one ragged), NaN batches in the middle that skip
     an encoder (multimodn.py:168: no gradient, no Adam step for its tensors - their step counts stay behind)."""
@@ -76,6 +77,10 @@ def test_epoch_kernel_equals_step_path(lib, shape, monkeypatch):
     shape = shape.replace("titanic_table", "titanic")
     spec = {"titanic": O.ModelSpec(32, [O.EncoderSpec(6, (5, 5), O.ACT_RELU)], 1, 0.7, 0.3),
             "titanic2": O.ModelSpec(32, [O.EncoderSpec(8, (7, 3), O.ACT_SIGMOID)], 2, 1.0, 1.0),
+            # state_size = 1: what pipelines/titanic/titanic_mlp_pipeline.py:37 really sets (BASELINE configs[0] says 32); 20: a state
+            # that is neither
+            "titanic_s1": O.ModelSpec(1, [O.EncoderSpec(6, (5, 5), O.ACT_RELU)], 1, 0.7, 0.3),
+            "titanic_s20": O.ModelSpec(20, [O.EncoderSpec(6, (5, 5), O.ACT_RELU)], 2, 0.7, 0.3),
             "two_enc": O.ModelSpec(24, [O.EncoderSpec(3, (5, 5), O.ACT_RELU), O.EncoderSpec(2, (7,), O.ACT_SIGMOID)], 2, 0.7, 0.3),
             "deep": O.ModelSpec(16, [O.EncoderSpec(9, (8, 6, 4), O.ACT_RELU), O.EncoderSpec(4, (), O.ACT_IDENTITY),
                                      O.EncoderSpec(5, (6,), O.ACT_RELU)], 3, 1.0, 1.0),

@@ -470,7 +470,7 @@ int mmn_dropout_adopt(mmn_plan* p, mmn_batch* b, const float* drop_p, float* buf
  * parameters and Adam moments resident in LDS / registers, every batch's forward, loss grid, backward, weight gradients,
  * torch.optim.Adam update and epoch sums, the next batch prefetched under the current one.
  * mmn_epoch_small_rows: the largest batch (rows) this model can run that way, 0 = not at all (MLPEncoder + ClassDecoder
- *   models with <= 4 encoders of <= 4 Linears whose image fits 160 KB of LDS; at most 64 rows).
+ *   models with <= 8 encoders of <= 4 Linears whose image fits 160 KB of LDS; at most 64 rows).
  * mmn_train_epoch_small: `batches_host` / `batches_dev` = the same n_batches descriptors in host memory (validated here)
  *   and in device memory (read by the kernel; the caller keeps both alive until the stream has passed the launch).
  *   Every batch: default encoder sequence (seq_data[k] = seq_enc[k] = k), batch_global = batch, no tile tables, no

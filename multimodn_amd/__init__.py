@@ -2,7 +2,7 @@
 path behind the reference's plugin surface (MultiModN / MultiModEncoder / MultiModDecoder /
 InitState / MultiModDataset / MultiModNHistory)."""
 from .state import InitState, TrainableInitState, StaticInitState
-from .encoders import MultiModEncoder, MLPEncoder, MIMIC_MLPEncoder, SLPEncoder, LinearEncoder, LogisticEncoder
+from .encoders import MultiModEncoder, MLPEncoder, MLPFeatureEncoder, MIMIC_MLPEncoder, SLPEncoder, LinearEncoder, LogisticEncoder
 from .decoders import MultiModDecoder, ClassDecoder, MLPDecoder, LogisticDecoder
 from .history import MultiModNHistory
 from .datasets import MultiModDataset, PartitionDataset, FeatureWiseDataset, JointDatasets, DeviceResidentLoader
@@ -13,7 +13,7 @@ from . import optim, metrics
 __all__ = [
     "InitState", "TrainableInitState", "StaticInitState", "MultiModEncoder", "MLPEncoder", "SLPEncoder",
     "LinearEncoder", "LogisticEncoder", "MultiModDecoder", "ClassDecoder", "LogisticDecoder", "MIMIC_MLPEncoder",
-    "MLPDecoder",
+    "MLPDecoder", "MLPFeatureEncoder",
     "MultiModNHistory", "MultiModDataset", "PartitionDataset", "FeatureWiseDataset", "JointDatasets",
     "MultiModN", "HipChainEngine", "UnsupportedModelError", "optim", "DeviceResidentLoader", "metrics",
 ]

@@ -49,6 +49,20 @@ class MLPEncoder(MultiModEncoder):
         return self.layers[-1](torch.cat([h, state], dim=1))
 
 
+class MLPFeatureEncoder(MLPEncoder):
+    """One feature through one hidden layer: MLPEncoder(state_size, 1, (hidden_size,)) (mlp_encoder.py:81-94; the
+    encoders of pipelines/titanic/titanic_featurewise_pipeline.py:70 and titanic_missingness_pipeline.py:71 over a
+    FeatureWiseDataset).  The reference's forward re-wraps x with Tensor(x), which for the [B, 1] float32 batches it is fed
+    is the same tensor; here x becomes float32 on the state's device.  On the HIP path it is an MLPEncoder like any other."""
+
+    def __init__(self, state_size: int, hidden_size: int, activation: Callable = F.relu,
+                 device: Optional[torch.device] = None):
+        super().__init__(state_size, 1, (hidden_size,), activation, device)
+
+    def forward(self, state: Tensor, x) -> Tensor:
+        return super().forward(state, torch.as_tensor(x, dtype=torch.float32, device=state.device))
+
+
 class MIMIC_MLPEncoder(MultiModEncoder):
     """The MIMIC pipelines' encoder (mlp_encoder.py:9-47): Dropout(p) on cat([x, state]) feeds the
     FIRST Linear, the activation follows EVERY Linear including the last one, whose output is the

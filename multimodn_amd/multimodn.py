@@ -1323,6 +1323,10 @@ class MultiModN(nn.Module):
                 host_flags = iter(torch.cat(dev_flags).cpu().tolist())
                 last_ran = [bool(next(host_flags)) if isinstance(f, Tensor) else f for f in last_ran]
             outputs_epoch = [o for o, ran in zip(outputs_epoch, last_ran) if ran]
+            # (the reference sets these outputs against the targets of ALL batches and its report raises on the two
+            # lengths, multimodn.py:410-418; here the report covers the batches whose last encoder ran - the case of
+            # pipelines/titanic/titanic_missingness_pipeline.py, whose last feature is the one most often missing)
+            targets_epoch = [t for t, ran in zip(targets_epoch, last_ran) if ran]
         if outputs_epoch:
             out = torch.cat(outputs_epoch, dim=0)                      # [N, 2D], on the model's device
             tgt = torch.cat(targets_epoch, dim=0).to(out.device)

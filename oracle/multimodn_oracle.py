@@ -575,7 +575,11 @@ def test_epoch(params, spec: ModelSpec, batches, dtype=np.float32):
     """multimodn.py:255-419 without the optimiser: returns (EpochResult with the 'test' History
     arrays, outputs) where outputs[d] = (y_true [N], y_pred [N], y_prob [N]) for the decoder on the
     state after the LAST encoder (enc_idx == E-1, :354-357), probabilities renormalised to sum to 1
-    (:415), prediction = argmax of the renormalised pair (first index wins ties)."""
+    (:415), prediction = argmax of the renormalised pair (first index wins ties).
+    Batches whose last encoder was skipped (a NaN in its features) contribute no outputs (:354-357) while the
+    reference keeps the targets of ALL batches (:283-286) and its report then raises on the two lengths (:418; recorded
+    in tests/golden/titanic_missingness.npz as eval/test_report_raised).  For that case - undefined in the reference -
+    outputs pairs the scores with the targets of the batches that produced them."""
     eval_spec = replace(spec, err_penalty=1.0, state_change_penalty=0.0)
     results, sizes = [], []
     outs, tgts = [], []
@@ -584,8 +588,8 @@ def test_epoch(params, spec: ModelSpec, batches, dtype=np.float32):
         r = forward_backward(params, eval_spec, xs, y, seq, dtype=dtype, want_grads=False, keep_states=True)
         results.append(r)
         sizes.append(np.asarray(y).shape[0])
-        tgts.append(np.asarray(y))
         if r.executed[spec.E - 1]:
+            tgts.append(np.asarray(y))
             outs.append(decoder_outputs(params, spec, r.states[spec.E], dtype))
     ep = aggregate_epoch(spec.E, spec.D, results, sizes)
     outputs = []

@@ -9,7 +9,9 @@ from oracle import multimodn_oracle as O
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ACT_ID = {"relu": O.ACT_RELU, "sigmoid": O.ACT_SIGMOID, "identity": O.ACT_IDENTITY}
 GOLDEN_NAMES = ["c1_titanic", "c1_curve20", "c2_split", "c3_small", "nan_skip", "seq_perm",
-                "slp_sigmoid", "mlp_sigmoid", "mlp_identity"]
+                "slp_sigmoid", "mlp_sigmoid", "mlp_identity",
+                # the feature-wise Titanic pipelines (MLPFeatureEncoder per feature; batch 32 / batch size 1 with missing values)
+                "titanic_featurewise", "titanic_missingness"]
 # MIMIC family: MIMIC_MLPEncoder + MLPDecoder runs of the reference, dropout masks recorded
 MIMIC_GOLDEN_NAMES = ["mimic_p0", "mimic_drop", "mimic_mixed", "mimic_c3_small"]
 # the reference's real MIMIC configuration (pipelines/mimic/mimic_multi_task_pipeline.py:53-83,118-119; datasets/mimic/
@@ -318,3 +320,34 @@ def auc_slack(y_true, prob64):
         return 0.0
     close = (np.abs(pos[:, None] - neg[None, :]) < TIE_MARGIN).sum()
     return float(close) / (len(pos) * len(neg))
+
+
+def featurewise_pipeline(g, device, lib, engine_factory=None):
+    """The body of pipelines/titanic/titanic_featurewise_pipeline.py:44-73 / titanic_missingness_pipeline.py:46-74 on a
+    feature-wise golden's data: FeatureWiseDataset over the [N, n_features] table -> stock DataLoader (no shuffle) ->
+    one MLPFeatureEncoder per feature + one LogisticDecoder, built by the pipelines' constructor calls, the golden's initial
+    weights loaded by name.  Returns (model, loader)."""
+    import torch
+    import torch.nn.functional as F
+    c = g.cfg
+    batches = g.batches()
+    X = np.concatenate([np.concatenate(b[0], axis=1) for b in batches], axis=0)
+    y = np.concatenate([b[1] for b in batches], axis=0)
+    loader = torch.utils.data.DataLoader(lib.FeatureWiseDataset(X, y), c["B"])
+    encoders = [lib.MLPFeatureEncoder(c["S"], c["H"][0], F.relu) for _ in c["F"]]
+    decoders = [lib.LogisticDecoder(c["S"]) for _ in range(c["D"])]
+    model = lib.MultiModN(c["S"], encoders, decoders, c["pen"][0], c["pen"][1], device=torch.device(device))
+    if engine_factory is not None:
+        model._engine_factory = engine_factory
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in g.init_params().items()})
+    return model, loader
+
+
+def assert_history_matches_golden(hist, g, tol=2e-6):
+    z = g.z
+    assert rel_err(np.stack(hist.loss["train"]), z["hist/loss"]) < tol
+    assert rel_err(np.stack(hist.state_change_loss), z["hist/state_change"]) < tol
+    for k in ("accuracy", "sensitivity", "specificity", "balanced_accuracy"):
+        got = np.stack(getattr(hist, k)["train"])
+        assert got.dtype == z["hist/" + k].dtype and got.shape == z["hist/" + k].shape
+        assert np.array_equal(got, z["hist/" + k]), k

@@ -64,7 +64,7 @@ def _run(lib, spec, loader, epochs, use_kernel, lr=1e-2):
 
 
 @pytest.mark.parametrize("shape", ["titanic", "titanic_table", "titanic2", "titanic_s1", "titanic_s20", "two_enc", "deep", "titanic_b50", "two_enc_b64",
-                                   "wide_b64"])
+                                   "wide_b64", "feature6", "feature8_b1"])
 def test_epoch_kernel_equals_step_path(lib, shape, monkeypatch):
     """Same batches through both paths: 28 batches of 32 rows (the last one ragged), NaN batches in the middle that skip
     an encoder (multimodn.py:168: no gradient, no Adam step for its tensors - their step counts stay behind)."""
@@ -86,11 +86,15 @@ def test_epoch_kernel_equals_step_path(lib, shape, monkeypatch):
                                      O.EncoderSpec(5, (6,), O.ACT_RELU)], 3, 1.0, 1.0),
             # 64 rows x 48 features = 3,072 x values per batch: more than eight waves fetch at 4 a thread - the kernel's
             # 8-per-thread instantiation (round 6: it replaces the 1024-thread form, the one kernel that had scratch)
+            # the reference's feature-wise Titanic pipelines (titanic_featurewise_pipeline.py:70, titanic_missingness_pipeline.py:35,71):
+            # one MLPFeatureEncoder(state 5, hidden 5) per feature, six features; eight encoders at batch size 1 = the kernel's most
+            "feature6": O.ModelSpec(5, [O.EncoderSpec(1, (5,), O.ACT_RELU) for _ in range(6)], 1, 0.7, 0.3),
+            "feature8": O.ModelSpec(5, [O.EncoderSpec(1, (5,), O.ACT_RELU) for _ in range(8)], 1, 0.7, 0.3),
             "wide": O.ModelSpec(16, [O.EncoderSpec(12, (6,), O.ACT_RELU) for _ in range(4)], 2, 0.7, 0.3)}[shape.split("_b")[0]]
     B, nb = (int(shape.split("_b")[1]) if "_b" in shape else 32), 28        # (50: every batch ends inside a 16-row tile; 64: the kernel's largest)
-    batches = O.synthetic_batches(spec, nb * B - 11, B, seed=9)        # (the last batch has 21 rows)
+    batches = O.synthetic_batches(spec, nb * B - (11 if B > 11 else 0), B, seed=9)        # (the last batch has 21 rows)
     for bi, slot in ((3, 0), (9, spec.E - 1), (10, spec.E - 1), (nb - 1, 0)):
-        batches[bi][0][slot][1, 0] = np.nan
+        batches[bi][0][slot][min(1, B - 1), 0] = np.nan
     loader = _device_loader(batches)
     m_k, h_k, st_k, g_k = _run(lib, spec, loader, 3, True)
     m_s, h_s, st_s, g_s = _run(lib, spec, loader, 3, False)

@@ -429,6 +429,47 @@ def test_reference_pipeline_shape_runs_end_to_end(lib, device_loader):
     assert 0.6 < float(results[0][1]) <= 1.0           # AUC of the validation report
 
 
+@pytest.mark.parametrize("feed", ["stock_loader", "device_loader"])
+@pytest.mark.parametrize("name", ["titanic_featurewise", "titanic_missingness"])
+def test_featurewise_pipelines_match_reference_golden(lib, name, feed, monkeypatch):
+    """The reference's feature-wise Titanic pipelines (titanic_featurewise_pipeline.py: five MLPFeatureEncoder(5, 5), batch
+    32; titanic_missingness_pipeline.py: six, batch size 1, missing values kept as NaN so that a sample's missing feature
+    skips that encoder) written with this package's classes (tests/helpers.py::featurewise_pipeline), against the reference's
+    own run of them.  stock_loader: FeatureWiseDataset -> torch DataLoader -> torch.optim.Adam, as the pipelines build them;
+    device_loader: DeviceResidentLoader + multimodn_amd.optim.Adam with MMN_EPOCH_KERNEL as a user's process has it - the
+    whole epoch is then one launch of k_epoch_small (checked), the missing features decided on the device."""
+    from helpers import featurewise_pipeline
+    g = Golden(name)
+    model, loader = featurewise_pipeline(g, "cuda", lib)
+    if feed == "device_loader":
+        monkeypatch.delenv("MMN_EPOCH_KERNEL", raising=False)
+        loader = lib.DeviceResidentLoader(loader.dataset, g.cfg["B"], device="cuda")
+        opt = lib.optim.Adam(model.parameters(), lr=g.cfg["lr"])
+    else:
+        opt = torch.optim.Adam(list(model.parameters()), g.cfg["lr"])
+    hist = lib.MultiModNHistory(["Survived"])
+    for _ in range(g.epochs):
+        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+    torch.cuda.synchronize()
+    if feed == "device_loader":
+        assert model.__dict__.get("_small_epochs"), "a feature-wise Titanic epoch on device-resident batches is one k_epoch_small launch"
+    z = g.z
+    w64, l64, s64 = fp64_trajectory(g)[:3]
+    assert rel_err(np.stack(hist.state_change_loss), z["hist/state_change"]) < 1e-5
+    assert_within_fp32_noise(np.stack(hist.loss["train"]), z["hist/loss"], l64, "History loss", tight=1e-5)
+    assert_counts_match(hist, z, g)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    for n, w in g.final_params().items():
+        assert_within_fp32_noise(sd[n], w, w64[n], n)
+    th = lib.MultiModNHistory(["Survived"])
+    res = model.test(loader, torch.nn.CrossEntropyLoss(), th)
+    assert rel_err(th.loss["test"][0], z["eval/test_loss"]) < 2e-5
+    assert np.array_equal(th.accuracy["test"][0], z["eval/test_accuracy"])
+    n_last = sum(len(b[1]) for b in g.batches() if not np.isnan(b[0][-1]).any())
+    tn, fp, fn, tp = (int(res[0][lib.metrics.performance_metrics.index(k)]) for k in ("tn", "fp", "fn", "tp"))
+    assert tn + fp + fn + tp == n_last                 # the report covers the batches whose last encoder ran
+
+
 def test_integration_md_stub_runs(lib):
     """The ctypes stub printed in INTEGRATION.md (what a reference maintainer would paste) is executed
     verbatim - only the library path is made absolute - on a model with the reference's attribute

@@ -219,6 +219,48 @@ def test_plugin_forward_contract():
     assert init(3).shape == (3, 5) and torch.equal(init(3)[0], init.state_value[0])
 
 
+@pytest.mark.parametrize("name", ["titanic_featurewise", "titanic_missingness"])
+def test_featurewise_pipelines_reproduce_the_reference_run(name):
+    """The reference's feature-wise Titanic pipelines, written with this package's classes (MLPFeatureEncoder per feature
+    over a FeatureWiseDataset through a stock DataLoader; batch 32, and batch size 1 with missing values kept as NaN):
+    parameter names, History arrays, trained weights and the forward-only epoch equal the reference's own run."""
+    from helpers import assert_history_matches_golden, featurewise_pipeline
+    g = Golden(name)
+    model, loader = featurewise_pipeline(g, "cpu", mm, OracleEngine)
+    assert list(model.state_dict().keys()) == list(g.spec.param_names())
+    b0 = next(iter(loader))
+    assert [tuple(x.shape) for x in b0[0]] == [(g.cfg["B"], 1)] * len(g.cfg["F"]) and b0[0][0].dtype == torch.float32
+    opt = torch.optim.Adam(list(model.parameters()), g.cfg["lr"])
+    hist = mm.MultiModNHistory(["Survived"])
+    for _ in range(g.epochs):
+        model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), hist)
+    assert_history_matches_golden(hist, g)
+    sd = model.state_dict()
+    w64 = fp64_trajectory(g)[0]
+    for n, w in g.final_params().items():
+        assert_within_fp32_noise(sd[n].numpy(), w, w64[n], n)
+    # test(): History arrays as the reference's; the per-decoder report covers the batches whose LAST encoder ran (the
+    # reference's own report raises once a batch's last feature is missing: the fixture records that, eval/test_report_raised)
+    th = mm.MultiModNHistory(["Survived"])
+    res = model.test(loader, torch.nn.CrossEntropyLoss(), th)
+    assert rel_err(th.loss["test"][0], g.z["eval/test_loss"]) < 2e-5
+    assert np.array_equal(th.accuracy["test"][0], g.z["eval/test_accuracy"])
+    n_last = sum(len(b[1]) for b in g.batches() if not np.isnan(b[0][-1]).any())
+    assert ("eval/test_report_raised" in g.z.files) == (n_last < g.cfg["N"])
+    tn, fp, fn, tp = (int(res[0][mm.metrics.performance_metrics.index(k)]) for k in ("tn", "fp", "fn", "tp"))
+    assert tn + fp + fn + tp == n_last
+
+
+def test_feature_encoder_is_the_references_constructor():
+    torch.manual_seed(0)
+    enc = mm.MLPFeatureEncoder(5, 4, torch.sigmoid)              # mlp_encoder.py:84-91: (state_size, hidden_size, activation, device)
+    assert isinstance(enc, mm.MLPEncoder) and enc.n_features == 1 and enc.hidden_layers == (4,) and enc.activation is torch.sigmoid
+    assert [tuple(l.weight.shape) for l in enc.layers] == [(4, 1), (5, 9)]
+    s, x = torch.randn(6, 5), torch.randn(6, 1)
+    assert torch.equal(enc(s, x), mm.MLPEncoder.forward(enc, s, x))
+    assert torch.equal(enc(s, x.double().numpy()), enc(s, x))   # whatever the loader hands over becomes float32 (Tensor(x), :94)
+
+
 def test_partition_dataset_and_collate():
     X = np.arange(40, dtype=np.float32).reshape(8, 5)
     y = np.arange(16).reshape(8, 2) % 2

@@ -34,6 +34,20 @@ def _clf_curve(y_prob: Tensor, y_true: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     return fps, tps, ps[idx]
 
 
+def compute_metrics(tp, tn, fp, fn, cm, enc_idx, dec_idx):
+    """Adds one binary confusion matrix cm[true][pred] to the (E+1) x D counter grids at [enc_idx][dec_idx]; cm = None (more
+    than two classes) marks the cell NaN (multimodn.py:51-63).  train_epoch / test do not call it - the decoder-grid kernel
+    counts - it is here for code that imports it from the reference's module."""
+    if cm is not None:
+        tp[enc_idx][dec_idx] += cm[1][1]
+        tn[enc_idx][dec_idx] += cm[0][0]
+        fp[enc_idx][dec_idx] += cm[0][1]
+        fn[enc_idx][dec_idx] += cm[1][0]
+    else:
+        for grid in (tp, tn, fp, fn):
+            grid[enc_idx][dec_idx] = float('nan')
+
+
 def get_performance_metrics(y_true: Tensor, y_pred: Tensor, y_prob: Tensor):
     """Same 15-tuple, in the same order, as the reference's get_performance_metrics (:47-49):
     (f1, auc, accuracy, sensitivity, specificity, fpr, tpr, precision, recall, tn, fp, fn, tp,

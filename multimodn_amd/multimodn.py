@@ -28,7 +28,7 @@ from .decoders import MultiModDecoder
 from .encoders import MultiModEncoder
 from .engine import HipChainEngine, check_criterion
 from .history import HistoryList, MultiModNHistory, PendingEpoch
-from .metrics import get_performance_metrics
+from .metrics import compute_metrics, get_performance_metrics      # noqa: F401  (importable from here as from multimodn/multimodn.py)
 from .state import InitState, TrainableInitState
 
 
@@ -1446,6 +1446,41 @@ class MultiModN(nn.Module):
             full[row] = pred.to(torch.float64).t().cpu().numpy().reshape(D, n_samples)
         del xs, y
         return full
+
+    def display_arch(self, input: np.ndarray):
+        """Prints every encoder and decoder layer by layer - output shape and parameter count for ONE sample, `input[i]` the
+        features of encoder i (multimodn.py:494-507, which hands each module to torchsummary; that package is not a
+        dependency here: the table comes from forward hooks on a CPU copy of the module, nothing touches the GPU)."""
+        import copy
+        S = int(self.init_state.state_size)
+
+        def table(module, args):
+            module = copy.deepcopy(module).to("cpu").eval()
+            rows, hooks = [], []
+            for name, sub in module.named_modules():
+                if name and not list(sub.children()):
+                    hooks.append(sub.register_forward_hook(
+                        lambda m, i, o, name=name: rows.append((f"{type(m).__name__} ({name})", tuple(o.shape),
+                                                                sum(p.numel() for p in m.parameters(recurse=False))))))
+            with torch.no_grad():
+                module(*args)
+            for h in hooks:
+                h.remove()
+            print(f"{'Layer (name)':<34}{'Output shape':<22}{'Param #':>10}")
+            for nm, shape, n in rows:
+                print(f"{nm:<34}{str(list(shape)):<22}{n:>10,}")
+            total = sum(p.numel() for p in module.parameters())
+            print(f"Total params: {total:,}  (trainable: {sum(p.numel() for p in module.parameters() if p.requires_grad):,})")
+
+        for i, enc in enumerate(self.encoders):
+            print('Encoder {}:'.format(i))
+            x = torch.as_tensor(np.asarray(input[i], dtype=np.float32)).reshape(1, -1)
+            table(enc, (torch.zeros(1, S), x))
+            print()
+        for i, dec in enumerate(self.decoders):
+            print('Decoder {}:'.format(i))
+            table(dec, (torch.zeros(1, S),))
+            print()
 
     def get_states(self, data_loader: DataLoader) -> List[Tensor]:
         """The state after the last executed encoder, one [S] tensor per sample (multimodn.py:460-492)."""

@@ -261,6 +261,24 @@ def test_feature_encoder_is_the_references_constructor():
     assert torch.equal(enc(s, x.double().numpy()), enc(s, x))   # whatever the loader hands over becomes float32 (Tensor(x), :94)
 
 
+def test_display_arch_and_module_level_helpers(capsys):
+    """multimodn.py:494-507 (display_arch: one table per encoder / decoder for one sample's features) and the two
+    module-level helpers a pipeline may import from the model's module (pipelines/mimic/haim_api.py:12)."""
+    from multimodn_amd.multimodn import compute_metrics, get_performance_metrics
+    assert get_performance_metrics is mm.metrics.get_performance_metrics
+    model = mm.MultiModN(8, [mm.MLPEncoder(8, 6, (5, 5)), mm.MIMIC_MLPEncoder(8, 4, (6,)), mm.MLPFeatureEncoder(8, 3)],
+                         [mm.LogisticDecoder(8), mm.MLPDecoder(8, (4,), 2)], 0.7, 0.3, device=torch.device("cpu"))
+    model.display_arch([np.zeros(6), np.zeros(4), np.zeros(1)])
+    out = capsys.readouterr().out
+    assert out.count("Encoder ") == 3 and out.count("Decoder ") == 2
+    assert "Total params: 177" in out and "Total params: 134" in out and "Total params: 18" in out     # encoder 0 / 1, decoder 0
+    grids = [torch.zeros(2, 1) for _ in range(4)]
+    compute_metrics(*grids, torch.tensor([[3, 1], [2, 4]]), 1, 0)                # cm[true][pred]
+    assert [float(g[1, 0]) for g in grids] == [4.0, 3.0, 1.0, 2.0]               # tp, tn, fp, fn
+    compute_metrics(*grids, None, 0, 0)
+    assert all(torch.isnan(g[0, 0]) for g in grids)
+
+
 def test_partition_dataset_and_collate():
     X = np.arange(40, dtype=np.float32).reshape(8, 5)
     y = np.arange(16).reshape(8, 2) % 2

@@ -5,12 +5,15 @@ here (no network), so the rows are synthetic and Titanic-shaped: 712 passengers,
 features, 1 binary target correlated with them.
 
     python examples/titanic_like_pipeline.py [--epochs 30] [--state-size 32] [--device-loader]
-                                             [--featurewise | --missingness]
+                                             [--featurewise | --missingness [--per-sample-batches]]
 
 --featurewise: the body of titanic_featurewise_pipeline.py:26-73 instead - a FeatureWiseDataset, one
 MLPFeatureEncoder(state 5, hidden 5) per feature, batch 32.  --missingness: titanic_missingness_pipeline.py:26-74 -
 the same with missing values kept as NaN (most often in the last feature, like the Titanic's cabin number) at batch
 size 1, so that a passenger's missing feature skips that feature's encoder (multimodn.py:167-171).
+--per-sample-batches (with --missingness): the same model and data in batches of 32 with `model.per_sample = True` - every
+passenger still skips exactly their own missing features (the reference can only do that one passenger per step), in 1 / 32
+of the steps.
 
 --device-loader swaps torch's DataLoader for multimodn_amd.DeviceResidentLoader (dataset in HBM,
 no per-sample tensor construction, no H2D copy per step); everything else is unchanged.
@@ -53,12 +56,13 @@ def main(argv=None):
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--featurewise", action="store_true")
     ap.add_argument("--missingness", action="store_true")
+    ap.add_argument("--per-sample-batches", action="store_true")
     args = ap.parse_args(argv)
     featurewise = args.featurewise or args.missingness
     if featurewise:
         args.state_size = 5                                  # (both pipelines: state_size = 5)
     if args.missingness:
-        args.batch_size = 1
+        args.batch_size = 32 if args.per_sample_batches else 1
 
     torch.manual_seed(args.seed)
     targets = ['Survived']
@@ -80,6 +84,7 @@ def main(argv=None):
         encoders = [MLPEncoder(args.state_size, 6, (5, 5), F.relu)]
     decoders = [LogisticDecoder(args.state_size) for _ in targets]
     model = MultiModN(args.state_size, encoders, decoders, 0.7, 0.3)
+    model.per_sample = bool(args.missingness and args.per_sample_batches)
     optimizer = torch.optim.Adam(list(model.parameters()), 0.01)
     criterion = CrossEntropyLoss()
     history = MultiModNHistory(targets)

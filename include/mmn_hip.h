@@ -323,7 +323,9 @@ int mmn_train_step_ex(mmn_plan* p, const mmn_batch* b, float err_penalty, float 
  *   in  : x[k] = data slot k [batch x F] (NaN anywhere in a row = that sample's modality is missing),
  *         y, batch = number of samples (any: one workgroup per 512 rows), batch_global; sequence fields are ignored
  *   seq : device int64 [batch x n_encoders], sample b feeds data slot k to encoder seq[b][k]
- *         (all modalities then need the same width), or NULL: slot k feeds encoder k
+ *         (all modalities then need the same width; models of at most 4 encoders), or NULL: slot k feeds encoder k
+ *         (models of at most 8 encoders - the reference's feature-wise pipelines have five and six,
+ *         pipelines/titanic/titanic_missingness_pipeline.py:26,71: per-sample missing features, default order)
  *   out : caller-allocated device buffers for rows = mmn_regroup_rows(batch, n_encoders) rows:
  *         out->x[e] [rows x F_e] (row stride out->ldx[e]), out->y [rows x D], out->tile_rows and
  *         out->tile_seq [rows / 16]; the call fills them (zeros where a modality is missing and in
@@ -415,7 +417,8 @@ int mmn_dp_oneshot_diag(mmn_plan* p, unsigned out8[8]);
 
 /* 1 if this plan runs per-sample batches (mmn_batch.tile_rows / tile_seq from mmn_regroup*): the fused kernel's tiled form
  * (MLPEncoder family, n_features <= 64, hidden widths <= 32), or the generic tier's (MIMIC modules, and any model planned
- * with MMN_MODEL_GENERIC_TIER); at most 4 encoders.  0: mmn_regroup* return MMN_ERR_UNSUPPORTED.  (ABI 113) */
+ * with MMN_MODEL_GENERIC_TIER: up to 8 encoders, of which 5 .. 8 in the default encoder order only); the fused kernel: at most 4
+ * encoders.  0: mmn_regroup* return MMN_ERR_UNSUPPORTED.  (ABI 113) */
 int mmn_per_sample_supported(const mmn_plan* p);
 int mmn_adam_step_accumulate_oneshot(mmn_plan* p, const mmn_adam* d, float err_penalty, float state_change_penalty_x001,
                                      void* stream);

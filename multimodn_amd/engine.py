@@ -81,9 +81,10 @@ def check_criterion(criterion) -> None:
 
 
 PER_SAMPLE_SCOPE = ("per-sample mode (per-sample missing modalities / encoder order, BASELINE configs[4]) runs models of at most 4 "
-                    "encoders (MLPEncoder family with n_features <= 64 and hidden widths <= 32: the fused chain kernel's tiled form; "
-                    "every other MLPEncoder / MIMIC_MLPEncoder / MLPDecoder shape: the generic tier's tiled forms); this model is "
-                    "outside that set")
+                    "encoders with per-sample encoder order (MLPEncoder family with n_features <= 64 and hidden widths <= 32: the fused "
+                    "chain kernel's tiled form; every other MLPEncoder / MIMIC_MLPEncoder / MLPDecoder shape: the generic tier's tiled "
+                    "forms) and models of 5 to 8 encoders in the default encoder order (no encoder_sequence: per-sample missing "
+                    "modalities only); this model / batch is outside that set")
 
 
 def _check_regroup(rc: int, what: str) -> None:
@@ -250,7 +251,7 @@ class HipChainEngine:
         self._generic_tier = want
         self._replan(self.max_batch)
         if on and not self.lib.mmn_per_sample_supported(self._plan):
-            self._generic_tier = False                      # (no tier takes it - more than 4 encoders, LDS: say so; ordinary batches keep their plan)
+            self._generic_tier = False                      # (no tier takes it - more than 8 encoders, LDS: say so; ordinary batches keep their plan)
             self._replan(self.max_batch)
             raise UnsupportedModelError(PER_SAMPLE_SCOPE)
         return True
@@ -639,8 +640,10 @@ class HipChainEngine:
         seq[b, k].  Everything is torch ops on the device with fixed shapes: no host sync.  Returns
         (hip.Batch, keep-alive tuple); the batch has 16 * n_tiles rows, batch_global = B."""
         E, B, dev = self.E, int(y.shape[0]), self.device
-        if E > 7 or len(xs) != E:
-            raise UnsupportedModelError("per-sample mode needs one data slot per encoder and E <= 7")
+        if E > 8 or len(xs) != E:
+            raise UnsupportedModelError("per-sample mode needs one data slot per encoder and E <= 8")
+        if E > 4 and seq is not None:
+            raise UnsupportedModelError(PER_SAMPLE_SCOPE)
         feats = [int(enc.n_features) for enc in self.model.encoders]
         if seq is not None and len(set(feats)) != 1:
             raise UnsupportedModelError("per-sample encoder order needs modalities of equal width "
@@ -664,6 +667,8 @@ class HipChainEngine:
                                                    C.byref(bout), scratch.data_ptr(), self._stream()), "mmn_regroup_ex")
             self._ps_layout = ("hip", scratch[2 * B:], B, tile_seq)
             return bout, (xs_p, y_p, tile_rows, tile_seq, sq, xs, y, scratch)
+        if E > 4:
+            raise UnsupportedModelError("the torch-op regrouping (a test switch) covers at most 4 encoders")
         present = torch.stack([~torch.isnan(x).any(dim=1) for x in xs], dim=1)           # [B, E] slot present
         enc_of = seq.to(dev, torch.int64) if seq is not None else torch.arange(E, device=dev).expand(B, E)
         pi = present.to(torch.int64)
@@ -709,7 +714,7 @@ class HipChainEngine:
         last read this slot, the main stream must wait for the returned event before the step.  Returns
         (hip.Batch, keep-alive, event, template) or None when this path does not apply (host tensors, torch regrouping)."""
         E, B, dev = self.E, int(y.shape[0]), self.device
-        rows = int(self.lib.mmn_regroup_rows(B, E)) if len(xs) == E and E <= 4 else 0
+        rows = int(self.lib.mmn_regroup_rows(B, E)) if len(xs) == E and E <= 8 else 0
         feats = [int(enc.n_features) for enc in self.model.encoders]
         if rows <= 0 or self._torch_regroup or (seq is not None and len(set(feats)) != 1):
             return None
@@ -757,7 +762,7 @@ class HipChainEngine:
         sizes = []
         for xs, y, seq, bg in items:
             B = int(y.shape[0])
-            rows = int(self.lib.mmn_regroup_rows(B, E)) if len(xs) == E and E <= 4 else 0
+            rows = int(self.lib.mmn_regroup_rows(B, E)) if len(xs) == E and E <= 8 else 0
             if rows <= 0 or (seq is not None and len(set(feats)) != 1):
                 return False
             if not (y.is_cuda and y.dtype == torch.int64 and y.is_contiguous() and y.dim() == 2

@@ -184,6 +184,11 @@ PER_SAMPLE_B1 = {
     # an MLPEncoder shape OUTSIDE the fused kernel's tiled form (n_features 72 > 64, hidden 48 > 32): the generic tier's tiled
     # form runs it (round 6, VERDICT r5 #8: per-sample mode for every MLPEncoder shape)
     "per_sample_b1_wide": dict(F=[72, 72, 72], H=(48,), S=24, D=2, N=32, pen=(1.0, 0.5), act="relu", p_missing=0.3),
+    # the reference's feature-wise missingness pipeline (pipelines/titanic/titanic_missingness_pipeline.py:26-74: six
+    # MLPFeatureEncoder(state 5, hidden 5), one feature each, batch size 1, NaN = the passenger's feature is missing, default
+    # encoder order) - what a per-sample BATCH of such a model must reproduce (round 6: per-sample mode for 5 .. 8 encoders)
+    "per_sample_b1_feature6": dict(F=[1] * 6, H=(5,), S=5, D=1, N=48, pen=(0.7, 0.3), act="relu", p_missing=0.3,
+                                   feature_encoders=True, default_order=True),
     "per_sample_b1_mimic": dict(F=[6, 6, 6], H=(8,), S=16, D=2, N=32, pen=(1.0, 0.5), act="relu", p_missing=0.3,
                                 enc_kinds=["mimic"] * 3, dropout=0.2, dec=[("mlp", (6,)), ("mlp", (6,))]),
 }
@@ -240,6 +245,8 @@ def run_reference_b1(name, cfg, seed=0):
     for k in range(E):
         X[k][miss[:, k]] = np.nan
     seq = np.stack([rng.permutation(E) for _ in range(N)]).astype(np.int64)
+    if cfg.get("default_order"):                                 # (missing modalities only: every sample in the default order)
+        seq = np.tile(np.arange(E, dtype=np.int64), (N, 1))
     masks = {}
     opt = SnapshotOnlyProxy(model)
 

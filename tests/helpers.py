@@ -66,7 +66,7 @@ class Golden:
         return f"step{s}/grad_none" in self.z.files
 
 
-PER_SAMPLE_B1_NAMES = ["per_sample_b1_mlp", "per_sample_b1_mimic", "per_sample_b1_wide"]
+PER_SAMPLE_B1_NAMES = ["per_sample_b1_mlp", "per_sample_b1_mimic", "per_sample_b1_wide", "per_sample_b1_feature6"]
 
 
 class PerSampleGolden:

@@ -84,6 +84,25 @@ def test_per_sample_step_matches_oracle(B, E, permute, F):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,E,F,H,S", [(37, 5, 8, (8, 8), 32), (200, 6, 1, (5,), 5), (700, 8, 6, (8,), 20), (64, 8, 72, (48,), 24), (1, 7, 4, (), 16)])
+def test_per_sample_step_of_five_to_eight_encoders_matches_oracle(B, E, F, H, S):
+    """Five to eight encoders (round 6; 200 x 6 x 1 x (5,) x 5: the reference's feature-wise missingness pipeline,
+    pipelines/titanic/titanic_missingness_pipeline.py:26-74, as a BATCH instead of one passenger per step): per-sample
+    missing modalities in the default encoder order - the regrouping's groups are the 2^E subsets - on the generic tier's
+    tiled form, against the oracle's loop over the samples."""
+    mm.hip.load()
+    spec, xs, y, _ = c5_like(B, E=E, F=F, S=S, H=H, seed=B + E, permute=False)
+    params = O.init_params(spec, 2)
+    model = build_torch_model(spec, params, "cuda", mm)
+    stats, grads = run_step(model, xs, y, None)
+    assert model._engine._generic_tier
+    check(stats, grads, O.per_sample_step(params, spec, xs, y, None), tolg=3e-5)
+    again = run_step(build_torch_model(spec, params, "cuda", mm), xs, y, None)      # the layout is a pure function of the batch
+    for n in grads:
+        assert np.array_equal(grads[n], again[1][n]), n
+
+
+@pytest.mark.gpu
 def test_per_sample_step_matches_the_reference_run_at_batch_size_one():
     """tests/golden/per_sample_b1_mlp.npz: the reference fed 32 samples one per batch (own encoder order, NaN rows, frozen
     weights); the HIP per-sample step over the same 32 rows as ONE batch must give the means of the reference's results."""
@@ -130,17 +149,27 @@ def test_per_sample_equals_batch_mode_when_nothing_varies():
 
 
 @pytest.mark.gpu
-def test_per_sample_training_epochs_match_oracle():
-    """train_epoch in per-sample mode (fused Adam included) against the oracle loop: History and weights."""
+@pytest.mark.parametrize("case", ["c5_like", "featurewise6_host", "featurewise6_device"])
+def test_per_sample_training_epochs_match_oracle(case):
+    """train_epoch in per-sample mode (fused Adam included) against the oracle loop: History and weights.
+    featurewise6: the reference's missingness pipeline (six MLPFeatureEncoder-shaped encoders of one feature each, state 5,
+    pipelines/titanic/titanic_missingness_pipeline.py:26-74) trained in BATCHES of 32 passengers with their own missing features
+    instead of one passenger per step - host batches, and device-resident ones (the look-ahead regrouping on a side stream)."""
     mm.hip.load()
-    spec, xs, y, seq = c5_like(96, E=4, seed=11)
+    if case == "c5_like":
+        spec, xs, y, seq = c5_like(96, E=4, seed=11)
+    else:
+        spec, xs, y, seq = c5_like(96, E=6, F=1, S=5, H=(5,), seed=11, permute=False)
     params = O.init_params(spec, 6)
     model = build_torch_model(spec, params, "cuda", mm)
     model.per_sample = True
     opt = mm.optim.Adam(list(model.parameters()), 1e-2)
     hist = mm.MultiModNHistory(["a", "b"])
-    loader = [([torch.from_numpy(x[s:s + 32]) for x in xs], torch.from_numpy(y[s:s + 32]), torch.from_numpy(seq[s:s + 32]))
+    put = (lambda a: torch.from_numpy(a).cuda()) if case.endswith("_device") else torch.from_numpy
+    loader = [([put(x[s:s + 32]) for x in xs], put(y[s:s + 32])) + ((put(seq[s:s + 32]),) if seq is not None else ())
               for s in range(0, 96, 32)]
+    if seq is None:
+        seq = np.tile(np.arange(spec.E, dtype=np.int64), (96, 1))            # (for the oracle: the default order, written out)
     oparams = {n: v.copy() for n, v in params.items()}
     oparams64 = {n: np.asarray(v, np.float64) for n, v in params.items()}
     oopt, oopt64 = O.Adam(1e-2), O.Adam(1e-2)
@@ -163,7 +192,7 @@ def test_per_sample_training_epochs_match_oracle():
     # is - on the coordinates where Adam's update is well conditioned (with 30 % of the modalities missing, whole rows of
     # weights see gradients of Adam's eps size: helpers.adam_well_conditioned)
     for n, p in model.named_parameters():
-        assert cond[n].mean() > 0.5, n
+        assert cond[n].mean() > 0.5 or (case != "c5_like" and cond[n].any()), n     # (five hidden units: a dead relu unit is a fifth of a tensor)
         assert_within_fp32_noise(p.detach().cpu().numpy(), oparams[n], oparams64[n], n, mask=cond[n])
 
 
@@ -287,6 +316,28 @@ def test_per_sample_step_of_a_wide_model_matches_the_reference_run_at_batch_size
 
 
 @pytest.mark.gpu
+def test_per_sample_batch_of_the_missingness_pipeline_matches_the_reference_run_at_batch_size_one():
+    """tests/golden/per_sample_b1_feature6.npz (round 6): the reference's feature-wise missingness pipeline - six
+    MLPFeatureEncoder(state 5, hidden 5), one LogisticDecoder, penalties 0.7 / 0.3, default encoder order
+    (pipelines/titanic/titanic_missingness_pipeline.py:26-74) - fed 48 passengers ONE PER BATCH, as that pipeline does.  Built
+    here from the pipeline's own constructor calls, the 48 passengers as ONE per-sample batch give the means of the reference's
+    48 results: what lets that pipeline train in batches."""
+    import torch.nn.functional as F
+    mm.hip.load()
+    g = PerSampleGolden("per_sample_b1_feature6")
+    c = g.cfg
+    assert np.array_equal(g.seq, np.tile(np.arange(6), (g.N, 1)))
+    encoders = [mm.MLPFeatureEncoder(c["S"], c["H"][0], F.relu) for _ in c["F"]]
+    model = mm.MultiModN(c["S"], encoders, [mm.LogisticDecoder(c["S"])], c["pen"][0], c["pen"][1], device=torch.device("cuda"))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in g.init_params().items()})
+    stats, grads = run_step(model, g.xs, g.y, None)
+    assert model._engine._generic_tier
+    g.check(stats["err_loss"], stats["state_change"], stats["loss"], stats["rows"], grads)
+    n = 1.0 + stats["rows"].astype(np.float64)[:, None]
+    assert np.array_equal(stats["n_correct"] / n, g.z["hist/accuracy"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", [dict(F=100, H=(64,), S=64), dict(F=8, H=(48, 16), S=32), dict(F=33, H=(), S=20), dict(F=128, H=(64, 64), S=128)])
 def test_per_sample_mode_runs_every_mlp_encoder_shape(shape):
     """Per-sample steps of MLPEncoder shapes the fused kernel's tiled form does not take (wide features, wide / odd hidden
@@ -330,16 +381,18 @@ def test_per_sample_training_of_a_wide_model_and_back_to_batch_mode():
 
 
 @pytest.mark.gpu
-def test_per_sample_mode_refuses_what_no_tier_runs_up_front():
-    """More than four encoders: no per-sample kernel (the regrouping's sequence codes hold four steps).  Refused where the
-    engine is asked for - a message that says what per-sample mode covers, nothing launched or changed."""
+@pytest.mark.parametrize("E,with_seq", [(5, True), (9, False)])
+def test_per_sample_mode_refuses_what_no_tier_runs_up_front(E, with_seq):
+    """Per-sample encoder ORDER for more than four encoders (the regrouping's table of ordered subsets ends there; five to
+    eight encoders run in the default order), and more than eight encoders at all (a tile's sequence code holds eight steps):
+    refused where the engine is asked for - a message that says what per-sample mode covers, nothing launched or changed."""
     from multimodn_amd.engine import UnsupportedModelError
-    spec, xs, y, seq = c5_like(48, E=5, seed=2)
+    spec, xs, y, seq = c5_like(48, E=E, seed=2)
     model = build_torch_model(spec, O.init_params(spec, 1), "cuda", mm)
     model.per_sample = True
     opt = mm.optim.Adam(list(model.parameters()), 1e-2)
     before = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    loader = [([torch.from_numpy(x) for x in xs], torch.from_numpy(y), torch.from_numpy(seq))]
+    loader = [([torch.from_numpy(x) for x in xs], torch.from_numpy(y)) + ((torch.from_numpy(seq),) if with_seq else ())]
     with pytest.raises(UnsupportedModelError, match="per-sample mode"):
         model.train_epoch(loader, opt, torch.nn.CrossEntropyLoss(), mm.MultiModNHistory(["a", "b"]))
     for k, v in model.state_dict().items():

@@ -7,7 +7,10 @@ of the step happens in the HIP kernels; there is no torch-op or CPU fallback.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import gc
+import sys
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -78,6 +81,31 @@ def check_criterion(criterion) -> None:
     if not ok:
         raise UnsupportedModelError(
             "criterion must be torch.nn.CrossEntropyLoss() (mean reduction, no class weights, no label smoothing)")
+
+
+@contextlib.contextmanager
+def _capture(graph, stream):
+    """torch.cuda.graph(graph, stream) with Python's cyclic garbage collector held back for the length of the capture: a
+    collection that runs INSIDE a capture may finalise an older torch.cuda.CUDAGraph (another model's or an evicted group's,
+    kept alive by a reference cycle until then) - destroying a hipGraph is not permitted while a stream of the thread
+    captures, torch's destructor throws and the process terminates (seen under the GPU electric fence, round 6;
+    torch.cuda.graph collects once BEFORE it begins, which does not cover garbage that becomes collectable during the
+    capture).  Reference-counted frees are not affected; the collector runs again right behind the capture."""
+    was = gc.isenabled()
+    cm = torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local")
+    cm.__enter__()
+    gc.disable()                                                # (behind torch.cuda.graph.__enter__'s own collection)
+    try:
+        try:
+            yield
+        except BaseException:
+            if not cm.__exit__(*sys.exc_info()):                # (ends the capture; the collector stays off until it has)
+                raise
+        else:
+            cm.__exit__(None, None, None)
+    finally:
+        if was:
+            gc.enable()
 
 
 PER_SAMPLE_SCOPE = ("per-sample mode (per-sample missing modalities / encoder order, BASELINE configs[4]) runs models of at most 4 "
@@ -538,7 +566,7 @@ class HipChainEngine:
                 keep = []
                 saved, saved_drawn = self._prescanned, self._predrawn
                 with torch.cuda.stream(side):
-                    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                    with _capture(graph, side):
                         if reset_first:
                             self.epoch_reset()
                         for i, (xs, y, pairs, bg, b, _k) in enumerate(steps):
@@ -827,7 +855,7 @@ class HipChainEngine:
                     hip.check(self.lib.mmn_regroup_ex(self._plan, C.byref(bin_), None if seq is None else seq.data_ptr(),
                                                       C.byref(bout), scratch.data_ptr(), stream.cuda_stream), "mmn_regroup_ex")
                 with torch.cuda.stream(side):
-                    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                    with _capture(graph, side):
                         evs = []
                         if fork:                            # the regrouping of every batch of the group: one branch beside the steps
                             branch.wait_stream(side)

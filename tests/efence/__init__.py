@@ -32,4 +32,21 @@ def install() -> None:
         build()
     alloc = torch.cuda.memory.CUDAPluggableAllocator(LIB, "efence_malloc", "efence_free")
     torch.cuda.memory.change_current_allocator(alloc)
+    # a free waits for the device before it unmaps - which must not happen inside a graph capture (the garbage collector may
+    # run there): frees that arrive between __enter__ and __exit__ of torch.cuda.graph are parked by the library
+    import ctypes
+    lib = ctypes.CDLL(LIB)
+    graph = torch.cuda.graph
+    enter, leave = graph.__enter__, graph.__exit__
+
+    def _enter(self):
+        lib.efence_capture(1)
+        return enter(self)
+
+    def _exit(self, *exc):
+        try:
+            return leave(self, *exc)
+        finally:
+            lib.efence_capture(0)
+    graph.__enter__, graph.__exit__ = _enter, _exit
     _installed = True

@@ -19,14 +19,21 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 namespace {
 struct Rec { void* va; size_t reserved; void* map_at; size_t mapped; hipMemGenericAllocationHandle_t handle; };
 std::mutex g_mu;
 std::unordered_map<void*, Rec> g_live;
 size_t g_gran = 0;
+// While a hipGraph is being captured nothing may wait for the device (hipDeviceSynchronize inside a capture ends the
+// process): tests/efence/__init__.py brackets torch.cuda.graph with efence_capture(1) / (0), frees that arrive in between
+// (Python's garbage collector runs when it likes) are parked and carried out by the first free behind the capture.
+std::atomic<int> g_capturing{0};
+std::vector<void*> g_parked;
 
 size_t env_size(const char* name, long dflt) { const char* s = getenv(name); return (size_t)(s ? atol(s) : dflt); }
 
@@ -81,12 +88,34 @@ extern "C" void* efence_malloc(ssize_t size, int device, hipStream_t stream) {
     return user;
 }
 
+static void release_now(void* ptr);
+
+extern "C" void efence_capture(int on) {
+    g_capturing.store(on ? 1 : 0);
+    if (getenv("EFENCE_VERBOSE")) fprintf(stderr, "[efence] capture %d\n", on);
+}
+
 extern "C" void efence_free(void* ptr, ssize_t size, int device, hipStream_t stream) {
     (void)size; (void)device; (void)stream;
     if (!ptr) return;
+    std::vector<void*> due;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_capturing.load()) {
+            g_parked.push_back(ptr);
+            if (getenv("EFENCE_VERBOSE")) fprintf(stderr, "[efence] free of %p parked (graph capture)\n", ptr);
+            return;
+        }
+        due.swap(g_parked);
+    }
     // torch frees a tensor the moment its last reference goes, kernels that use it may still be queued (its own caching
     // allocator relies on stream order for that): wait for the device before the pages disappear.
     (void)hipDeviceSynchronize();
+    for (void* q : due) release_now(q);
+    release_now(ptr);
+}
+
+static void release_now(void* ptr) {
     Rec r;
     {
         std::lock_guard<std::mutex> lk(g_mu);

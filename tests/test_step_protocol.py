@@ -446,3 +446,50 @@ def test_copy_stream_equals_copies_in_line(family, rows, optimizer, monkeypatch)
         return (np.stack(hist.loss["train"]), np.stack(hist.state_change_loss), np.stack(hist.accuracy["train"]),
                 {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()})
     _same(run("0"), run("1"))
+
+
+GC_IN_CAPTURE = r'''
+import gc, sys
+sys.path.insert(0, %(repo)r)
+import torch
+import multimodn_amd.engine as E
+side = torch.cuda.Stream()
+x = torch.zeros(64, device="cuda")
+old = torch.cuda.CUDAGraph()
+with torch.cuda.stream(side):
+    with torch.cuda.graph(old, stream=side):
+        x += 1
+new = torch.cuda.CUDAGraph()
+gc.set_threshold(1)                      # the collector runs at every opportunity
+with torch.cuda.stream(side):
+    with %(cm)s:
+        cyc = [old]; cyc.append(cyc)     # the older graph becomes garbage that only the cyclic collector frees ...
+        del old, cyc
+        junk = [[i] for i in range(5000)]    # ... and gets every chance to, INSIDE the capture
+        assert gc.isenabled() == %(enabled)s
+        x += 2
+assert gc.isenabled()
+gc.collect()
+new.replay(); torch.cuda.synchronize()
+print("SURVIVED", float(x[0]), flush=True)
+'''
+
+
+@pytest.mark.gpu
+def test_a_collection_inside_a_capture_cannot_destroy_another_graph():
+    """Round 6, found under the GPU electric fence: Python's cyclic collector, running INSIDE a graph capture, finalised an
+    older torch.cuda.CUDAGraph (another model's, kept by a reference cycle) - hipGraphDestroy is not permitted while the
+    thread captures, torch's destructor throws, the process terminates.  engine._capture holds the collector back from
+    torch.cuda.graph's own collection to the end of the capture.  Child processes: the bare torch.cuda.graph dies on this
+    sequence (if a future torch does not, the guard is merely unnecessary), engine._capture survives it."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    guarded = GC_IN_CAPTURE % {"repo": repo, "cm": "E._capture(new, side)", "enabled": "False"}
+    r = subprocess.run([sys.executable, "-c", guarded], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SURVIVED 2.0" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-1500:])
+    bare = GC_IN_CAPTURE % {"repo": repo, "cm": "torch.cuda.graph(new, stream=side)", "enabled": "True"}
+    r = subprocess.run([sys.executable, "-c", bare], capture_output=True, text=True, timeout=300)
+    if r.returncode == 0:
+        pytest.skip("this torch survives a collection inside a capture: engine._capture's guard is not needed here")
+    assert "capturing" in r.stderr or r.returncode < 0, r.stderr[-1500:]

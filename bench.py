@@ -33,7 +33,7 @@ torch = None                       # imported in main() / where needed: the laun
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix) = vector peak
 # the committed rocprofv3 --pmc passes roofline.traffic / mfma_busy_pct_pmc are read from (tools/collect_profiles.sh, collect_pmc_util.sh)
-PROFILE_TAGS = {"c3": "r06_final", "mimic": "r06_mimic", "c5": "r06_c5", "c5m": "r06_c5m", "haim": "r06_haim", "c1": "r06_c1"}
+PROFILE_TAGS = {"c3": "r06_final", "mimic": "r06_mimic", "c5": "r06_c5", "c5m": "r06_c5m", "haim": "r06_haim", "c1": "r06_c1", "c2": "r06_c2"}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -548,7 +548,7 @@ def rows_sweep(batches=(8192, 16384, 65536), steps=40, warmup=10):
     return res
 
 
-def secondary_workloads(names=("mimic", "c5", "c5m", "c1", "c2"), steps=40, warmup=10):
+def secondary_workloads(names=("mimic", "c5", "c5m", "c1", "c2", "haim"), steps=40, warmup=10):
     """The other workloads through the same entry point, each as a CHILD process of this one (a fresh process: the parent
     has initialised the GPU and must not exec): `python bench.py --workload <w> --steps 40 --warmup 10` without CPU legs.
     Reported per workload: samples/s, ms per step, launch mode, per-kernel HIP-event times."""

@@ -3,7 +3,7 @@
 # (gpurun -- 'bash tools/collect_all_profiles.sh r06').  Every step is bounded by `timeout`.
 R=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-for PAIR in final:c3 mimic:mimic c5:c5 c5m:c5m haim:haim c1:c1; do
+for PAIR in final:c3 mimic:mimic c5:c5 c5m:c5m haim:haim c1:c1 c2:c2; do
   TAG=${R}_${PAIR%%:*}; WL=${PAIR##*:}
   timeout 600 bash "$ROOT/tools/collect_profiles.sh" "$TAG" "$WL" > "$ROOT/gpurun_out/collect_$TAG.log" 2>&1
   timeout 600 bash "$ROOT/tools/collect_pmc_util.sh" "$TAG" "$WL" >> "$ROOT/gpurun_out/collect_$TAG.log" 2>&1

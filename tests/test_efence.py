@@ -12,7 +12,7 @@ device allocation):
   * the sweep seeds that faulted before the fix (and a sample of the others, both sweeps) run clean under it, flush to 16 and
     to 4 bytes, with host-staged and with device-resident inputs.
 The whole `-m gpu` suite runs under it too (MMN_EFENCE=1 python -m pytest tests -m gpu; tools/fault_hunt.py per seed):
-round 6, 481 passed."""
+round 6: 481 passed after the fix, 540 at the end of the round."""
 import os
 import subprocess
 import sys

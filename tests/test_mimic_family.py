@@ -535,10 +535,12 @@ def test_per_sample_mode_of_the_mimic_modules(lib, family, B):
             assert float(np.max(np.abs(got - g))) <= max(2e-5 * float(np.max(np.abs(g))), 2e-6 * g_all), n
 
 
-def _per_sample_step_against_oracle(lib, spec, B, seed, expect_kernel=None):
+def _per_sample_step_against_oracle(lib, spec, B, seed, expect_kernel=None, with_order=True):
     import ctypes as C
     params = O.init_params(spec, 3)
     xs, y, seq, masks = _per_sample_case(spec, B, seed=seed)
+    if not with_order:                                      # (modalities of different widths: slot k can only feed encoder k)
+        seq = None
     model = build_torch_model(spec, params, "cuda", lib)
     model.per_sample = True
     model.train()
@@ -546,10 +548,10 @@ def _per_sample_step_against_oracle(lib, spec, B, seed, expect_kernel=None):
     eng = model._get_engine(B)
     eng.epoch_reset()
     if expect_kernel is not None:
-        bout, keep = eng.per_sample_batch([torch.from_numpy(x).cuda() for x in xs], torch.from_numpy(y).cuda(), torch.from_numpy(seq))
+        bout, keep = eng.per_sample_batch([torch.from_numpy(x).cuda() for x in xs], torch.from_numpy(y).cuda(), None if seq is None else torch.from_numpy(seq))
         names = tuple(eng.lib.mmn_chain_kernel_name(eng._plan, C.byref(bout), k) for k in (0, 3, 1))
         assert names == expect_kernel, names
-    model._run_step_per_sample(eng, [torch.from_numpy(x) for x in xs], torch.from_numpy(y), torch.from_numpy(seq))
+    model._run_step_per_sample(eng, [torch.from_numpy(x) for x in xs], torch.from_numpy(y), None if seq is None else torch.from_numpy(seq))
     eng.assign_grads(None)
     torch.cuda.synchronize()
     stats = {k: np.array(v) for k, v in eng.step_values().items()}
@@ -587,8 +589,19 @@ def test_per_sample_mimic_pipeline_shapes_on_the_chain_kernels(lib, B, shape, fo
                            decoders=[O.DecoderSpec("mlp", (16,)), O.DecoderSpec("mlp", (24, 8))])
     if form == "sequential":
         monkeypatch.setenv("MMN_MC_TILED", "0")
-    expect = (b"k_mfwd", b"k_dec_fb", b"k_mbwd") if form == "tiles" else (b"k_gen_fwd", b"", b"k_gen_bwd")
+    expect = (b"k_mfwd", b"k_dec_fb", b"k_mbwd") if form == "tiles" else (b"k_gen_fwd", b"k_dec_fb", b"k_gen_bwd")   # (round 6: the decoders' own launch beside the sequential chain too)
     _per_sample_step_against_oracle(lib, spec, B, seed=40 + B, expect_kernel=expect)
+
+
+@pytest.mark.parametrize("B", [16, 100])
+def test_per_sample_step_of_the_real_mimic_shape(lib, B):
+    """The reference's real MIMIC configuration (state 50, sources of 6 / 1024 / 768 / 99 features, hidden (32, 32), MLPDecoder
+    (32, 32): pipelines/mimic/mimic_multi_task_pipeline.py:53-83) in per-sample mode - round 6: k_xpart forms the x parts of
+    the regrouped tiles too, the decoders run in k_dec_fb beside the sequential chain kernels (a state size that is no
+    multiple of 4), short encoders take the chain kernels' request-everything-first steps - against the oracle's loop."""
+    spec = O.ModelSpec(50, [O.EncoderSpec(f, (32, 32), O.ACT_RELU, kind="mimic", dropout=0.2) for f in (6, 1024, 768, 99)], 2, 1.0, 0.3,
+                       decoders=[O.DecoderSpec("mlp", (32, 32)) for _ in range(2)])
+    _per_sample_step_against_oracle(lib, spec, B, seed=70 + B, expect_kernel=(b"k_gen_fwd", b"k_dec_fb", b"k_gen_bwd"), with_order=False)
 
 
 def test_per_sample_mimic_step_matches_the_reference_run_at_batch_size_one(lib):

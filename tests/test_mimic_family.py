@@ -79,14 +79,20 @@ def test_first_step_matches_reference_golden(lib, name, form, monkeypatch):
     check_against(stats, grads, ref)
 
 
-@pytest.mark.parametrize("form", ["default", "sequential"])
+@pytest.mark.parametrize("form", ["default", "sequential", "decoders_inside", "x_part_inside"])
 @pytest.mark.parametrize("name", HAIM_GOLDEN_NAMES)
 def test_haim_shape_first_step_matches_reference_golden(lib, name, form, monkeypatch):
     """The reference's real MIMIC configuration: state 50, hidden (32, 32), dropout 0.2, batch 16, sources of
     width [6, 1024, 768, 99] (the pipeline's four) / all nine of the dataset - through whatever kernels the plan picks for the
-    shape ("default") and through the sequential form (k_gen_*), which takes any shape."""
+    shape ("default": k_xpart + the sequential chain kernels + k_dec_fb since round 6), through the sequential form forced
+    (k_gen_*), and through the forms the defaults replaced: the decoders inside the chain kernels (MMN_SEQ_SPLIT=0), the
+    first layers' x parts inside them (MMN_XPART=0)."""
     if form == "sequential":
         monkeypatch.setenv("MMN_GEN_FAST", "0")
+    if form == "decoders_inside":
+        monkeypatch.setenv("MMN_SEQ_SPLIT", "0")
+    if form == "x_part_inside":
+        monkeypatch.setenv("MMN_XPART", "0")
     g = Golden(name)
     model = build_torch_model(g.spec, g.init_params(), "cuda", lib)
     stats, grads, _ = run_step(model, g.batch(0), g.step_masks(0))
